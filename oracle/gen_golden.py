@@ -1,0 +1,165 @@
+"""Generate tests/golden/*.npz by running the REFERENCE itself on CPU (build container only).
+
+TEST INFRASTRUCTURE ONLY.  Run from the repo root, once per architecture, in the container
+that has /root/reference mounted (it does not exist on the GPU box; nothing at test time
+reads it):
+
+    python oracle/gen_golden.py --net_res 128
+    python oracle/gen_golden.py --net_res 32
+
+The reference parses sys.argv at import (model/ifnet.py:8) and imports visualisation-only
+packages that are absent here (util/visualize.py:1-6), so argv is cleaned and those three
+names are stubbed with empty modules before the import.  Only inputs/outputs are stored;
+weights are name-seeded (oracle.ifnet_oracle.name_seeded_state) and rebuilt by the tests.
+"""
+import argparse
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+from oracle import ifnet_oracle as O  # noqa: E402
+
+REF = os.environ.get("SVR_REFERENCE", "/root/reference")
+OUT = os.path.join(REPO, "tests", "golden")
+GAIN = 3.0
+
+
+def sample(t, cap=4096):
+    f = t.detach().reshape(-1)
+    stride = max(1, -(-f.numel() // cap))
+    return f[::stride].contiguous().numpy().copy()
+
+
+def make_inputs(seed, B, dims, N, spread=1.0, density=0.05):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    x = (torch.rand(B, 1, *dims, generator=g) < density).float()
+    pts = (torch.rand(B, N, 3, generator=g) - 0.5) * spread
+    occ = (torch.rand(B, N, generator=g) < 0.5).float()
+    return x, pts, occ
+
+
+def ifnet_case(IFNet, net_res, tag, seed, B, dims, N, spread=1.0):
+    torch.manual_seed(0)
+    x, pts, occ = make_inputs(seed, B, dims, N, spread)
+    st = O.name_seeded_state(net_res, GAIN)
+    ref = IFNet()
+    missing = ref.load_state_dict(st, strict=False)
+    assert not missing.unexpected_keys and all("num_batches" in k for k in missing.missing_keys), missing
+    ref.train()
+    opt = torch.optim.Adam(ref.parameters(), lr=1e-4)
+
+    # intermediate features of the reference extractor (first 8 points only)
+    feats = ref.ifnet_feature_extractor(x, pts)              # (B, sumC, 1, 7, N); also steps BN buffers
+    feats8 = feats[..., :8].detach().clone()
+    # reset BN buffers touched by the probe forward
+    ref.load_state_dict(st, strict=False)
+
+    logits = ref(x, pts)
+    loss = torch.nn.functional.binary_cross_entropy_with_logits(logits, occ, reduction="none").sum(-1).mean()
+    opt.zero_grad()
+    loss.backward()
+    out = {
+        "meta": np.array([net_res, seed, B, dims[0], dims[1], dims[2], N], dtype=np.int64),
+        "spread": np.float32(spread), "gain": np.float32(GAIN),
+        "x_bits": np.packbits(x.numpy().astype(np.uint8)),
+        "points": pts.numpy(), "occupancies": occ.numpy().astype(np.uint8),
+        "logits": logits.detach().numpy(), "loss": np.float64(loss.item()),
+        "features8": feats8.numpy(),
+    }
+    for name, p in ref.named_parameters():
+        g = p.grad
+        out["grad_norm/" + name] = np.float64(g.double().norm().item())
+        out["grad/" + name] = sample(g)
+    opt.step()
+    sd = ref.state_dict()
+    for name, t in sd.items():
+        if "num_batches" in name:
+            continue
+        if O.is_buffer(name):
+            out["buf/" + name] = t.numpy().copy()
+        else:
+            out["adam/" + name] = sample(t)
+    # eval-mode logits with the updated parameters and buffers
+    ref.eval()
+    with torch.no_grad():
+        out["logits_eval_after_step"] = ref(x, pts).numpy()
+    path = os.path.join(OUT, f"ifnet_{tag}.npz")
+    np.savez_compressed(path, **out)
+    print(f"{path}: loss={loss.item():.6f} logits std={logits.std().item():.4f} "
+          f"absmax={logits.abs().max().item():.4f} size={os.path.getsize(path)/1024:.0f} KiB")
+
+
+def project_case(project, tag, seed, B, dims, kernel, sigma, scale):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    depth = torch.rand(B, 240, 320, generator=g) * 5 + 0.5
+    wsel = torch.rand(B, 1, *dims, generator=g)
+    depth.requires_grad_(True)
+    mod = project(dims, list(kernel), torch.tensor(sigma, dtype=torch.float32))
+    grid_pc = mod.depthmap_to_gridspace(depth, scale)
+    grid_pc_keep = grid_pc.detach().clone()
+    norm_pc = mod.norm_grid_space(grid_pc.clone())
+    norm_keep = norm_pc.detach().clone()
+    vox_raw = mod.pc_voxels(norm_pc)
+    occ = mod(norm_pc)
+    obj = (occ * wsel).sum()
+    obj.backward()
+    valid = torch.all((norm_keep < 0.5 - 1e-6) & (norm_keep > -0.5 + 1e-6), dim=-1)
+    gi = ((norm_keep + 0.5) * (mod.vox_size - 1)).floor().to(torch.int16)
+    stride = 37
+    out = {
+        "meta": np.array([seed, B, dims[0], dims[1], dims[2], kernel[0], kernel[1], kernel[2], scale], dtype=np.int64),
+        "sigma": np.array(sigma, dtype=np.float32),
+        "depth_s": sample(depth), "wsel_s": sample(wsel),
+        "grid_pc_s": grid_pc_keep.reshape(-1, 3)[::stride].numpy().copy(),
+        "norm_pc_s": norm_keep.reshape(-1, 3)[::stride].numpy().copy(),
+        "valid_bits": np.packbits(valid.numpy().astype(np.uint8)),
+        "vox_idx_s": gi.reshape(-1, 3)[::stride].numpy().copy(),
+        "vox_idx_sum": np.int64(gi.long()[valid].sum().item()),
+        "vox_raw_s": sample(vox_raw, 16384), "vox_raw_sum": np.float64(vox_raw.double().sum().item()),
+        "occ_s": sample(occ, 16384), "occ_sum": np.float64(occ.double().sum().item()),
+        "obj": np.float64(obj.item()),
+        "sigma_grad": mod.sigma.grad.numpy().copy(),
+        "depth_grad_s": sample(depth.grad, 16384),
+        "depth_grad_norm": np.float64(depth.grad.double().norm().item()),
+        "stride": np.int64(stride),
+    }
+    path = os.path.join(OUT, f"project_{tag}.npz")
+    np.savez_compressed(path, **out)
+    print(f"{path}: occ_sum={out['occ_sum']:.3f} valid={valid.float().mean().item():.3f} "
+          f"sigma_grad={out['sigma_grad']} size={os.path.getsize(path)/1024:.0f} KiB")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--net_res", type=int, default=128)
+    a = ap.parse_args()
+    os.makedirs(OUT, exist_ok=True)
+    os.chdir(REF)                       # project() reads data/raw/overfit/00000/intrinsic.txt relative to cwd
+    sys.path.insert(0, REF)
+    sys.dont_write_bytecode = True
+    sys.argv = ["x", "--net_res", str(a.net_res)]
+    for n in ("marching_cubes", "trimesh", "pyexr"):
+        sys.modules.setdefault(n, types.ModuleType(n))
+    import warnings
+    warnings.filterwarnings("ignore")
+    from model.ifnet import IFNet
+    from model.projection import project
+    torch.set_num_threads(8)
+    if a.net_res == 128:
+        ifnet_case(IFNet, 128, "cfg1", 101, 1, (32, 32, 32), 2048)                 # BASELINE configs[0]
+        ifnet_case(IFNet, 128, "odd", 111, 2, (35, 26, 28), 600, spread=1.25)      # ragged dims, OOB points
+        ifnet_case(IFNet, 128, "b3", 112, 3, (16, 16, 16), 257)                    # smallest legal pyramid
+        project_case(project, "full", 105, 2, (139, 104, 112), (3, 3, 3), (1.5, 1.5, 1.5), 1)
+        project_case(project, "half", 106, 1, (70, 52, 56), (11, 9, 9), (2.0, 1.5, 1.0), 2)
+        project_case(project, "cube", 107, 2, (48, 40, 56), (5, 3, 3), (0.8, 1.2, 1.7), 2)
+    else:
+        ifnet_case(IFNet, 32, "res32", 121, 2, (16, 12, 20), 512, spread=1.1)
+
+
+if __name__ == "__main__":
+    main()
