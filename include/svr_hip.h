@@ -1,0 +1,201 @@
+/*
+ * svr_hip.h -- C ABI of libsvr_hip.so: the MI355X (gfx950) kernels behind the IF-Net
+ * occupancy-query hot path of nihalsid/single-view-3d-reconstruction.
+ *
+ * The reference has no FFI layer of its own: the path sits behind torch nn.Modules
+ * (model/ifnet.py:10-199, model/projection.py:21-218) and every arithmetic step is a stock
+ * torch op.  Each entry point below therefore names the torch call site(s) it replaces.
+ *
+ * Conventions (all entry points):
+ *   - plain device pointers + sizes, no torch types; the CALLER owns every buffer
+ *     (inputs, outputs, workspaces) and keeps it alive until the stream work completes;
+ *   - asynchronous: work is only enqueued on `stream` (a hipStream_t passed as void*),
+ *     no device synchronisation, no allocation, no default-stream work;
+ *   - return 0 on success, a negative SVR_E_* code for a bad argument, or a positive
+ *     hipError_t for a launch failure; svr_last_error() gives the text (thread local);
+ *   - volumes are channels-last: (B, D, H, W, C) float32, C contiguous;
+ *   - "feature rows": (B*N, FS) float32, FS = row stride >= svr_feature_width(); column
+ *     layout is level-major, see svr_feature_layout().
+ */
+#ifndef SVR_HIP_H
+#define SVR_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SVR_OK 0
+#define SVR_E_BADARG (-1)
+#define SVR_E_BADSHAPE (-2)
+#define SVR_E_ALIGN (-3)
+#define SVR_E_UNSUPPORTED (-4)
+
+#define SVR_MAX_LEVELS 6
+
+int svr_version(void);
+const char *svr_last_error(void);
+
+/* ---------------------------------------------------------------------------------------
+ * Trilinear multi-level feature gather  (replaces: coordinate prep model/ifnet.py:156-161,
+ * the six F.grid_sample calls :162,168,175,181,187,193, torch.cat :197 and the reshape
+ * model/ifnet.py:43-45; 32-variant :93-118).
+ * ------------------------------------------------------------------------------------- */
+typedef struct svr_level {
+  const float *vol; /* (B, D, H, W, C) channels-last                                  */
+  float *gvol;      /* backward only: gradient volume, same shape, accumulated into   */
+  int32_t C, D, H, W;
+  int32_t col;      /* first column of this level inside a feature row                */
+} svr_level;
+
+typedef struct svr_gather_desc {
+  int32_t n_levels;
+  int32_t B, N;           /* batch, query points per sample                          */
+  int32_t row_stride;     /* FS: floats per feature row (>= used width, multiple of 4) */
+  int32_t align_corners;  /* 0: 128-architecture, 1: 32-architecture                   */
+  float displacement;     /* 0.0722 / 0.035 (model/ifnet.py:144,82)                    */
+  svr_level level[SVR_MAX_LEVELS];
+} svr_gather_desc;
+
+/* features[b*N+n][level.col + j*C + c] = trilinear sample j of channel c (zeros padding). */
+int svr_gather_trilinear_fwd(const svr_gather_desc *d, const float *points /*(B,N,3)*/,
+                             float *features, void *stream);
+/* gvol[level] += scatter of gfeatures (autograd of grid_sample wrt the volume);
+ * levels with gvol == NULL are skipped.  gpoints (B,N,3) may be NULL; when given it is
+ * OVERWRITTEN with the gradient wrt the query points.                                   */
+int svr_gather_trilinear_bwd(const svr_gather_desc *d, const float *points, const float *gfeatures,
+                             float *gpoints, void *stream);
+/* Integer base corner (z0,y0,x0) of every sample: out (B,7,N,3) int32 -- the bit-exact gate. */
+int svr_gather_corner_indices(const svr_gather_desc *d, int32_t level, const float *points,
+                              int32_t *out, void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Dense f32 GEMMs on MFMA (replaces nn.Conv1d(.,.,1) fc_0/fc_1/fc_2 model/ifnet.py:19-21,55-57
+ * and their autograd).  Row-major everywhere.
+ * ------------------------------------------------------------------------------------- */
+#define SVR_EPI_NONE 0
+#define SVR_EPI_BIAS 1       /* + bias[n]                       */
+#define SVR_EPI_BIAS_RELU 2  /* relu(. + bias[n])               */
+#define SVR_EPI_MASK 3       /* . * (mask[m][n] > 0)  (ReLU backward with the saved output) */
+
+/* Y[M,N] = epi( X[M,K](ldx) * W[N,K](ldw)^T )                                           */
+int svr_linear_fwd(const float *X, int64_t ldx, const float *W, int64_t ldw, const float *bias,
+                   float *Y, int64_t ldy, int64_t M, int64_t N, int64_t K, int epilogue,
+                   const float *mask, int64_t ldmask, void *stream);
+/* dX[M,K] = epi( dY[M,N](lddy) * W[N,K](ldw) ), epilogue NONE or MASK (mask is [M,K])    */
+int svr_linear_bwd_data(const float *dY, int64_t lddy, const float *W, int64_t ldw, float *dX,
+                        int64_t lddx, int64_t M, int64_t N, int64_t K, int epilogue,
+                        const float *mask, int64_t ldmask, void *stream);
+/* dW[N,K](lddw) = dY[M,N]^T * X[M,K];  db[N] = column sums of dY (db may be NULL).
+ * workspace: svr_linear_bwd_weight_workspace() bytes.  Deterministic (slab + ordered sum). */
+int64_t svr_linear_bwd_weight_workspace(int64_t M, int64_t N, int64_t K);
+int svr_linear_bwd_weight(const float *dY, int64_t lddy, const float *X, int64_t ldx, float *dW,
+                          int64_t lddw, float *db, int64_t M, int64_t N, int64_t K,
+                          void *workspace, void *stream);
+
+/* fc_out (Conv1d(hidden,1,1), model/ifnet.py:35,58-59): logits[m] = H[m,:].w + b           */
+int svr_fc_out_fwd(const float *H, int64_t ldh, const float *w, const float *b, float *logits,
+                   int64_t M, int64_t K, void *stream);
+/* dH[m,k] = dlogits[m]*w[k]*(H[m,k]>0);  dw[k] = sum_m dlogits[m]*H[m,k];  db = sum dlogits.
+ * workspace: svr_fc_out_bwd_workspace() bytes.                                            */
+int64_t svr_fc_out_bwd_workspace(int64_t M, int64_t K);
+int svr_fc_out_bwd(const float *H, int64_t ldh, const float *w, const float *dlogits, float *dH,
+                   int64_t lddh, float *dw, float *db, int64_t M, int64_t K, void *workspace,
+                   void *stream);
+
+/* BCE-with-logits, reduction 'none' -> sum over points -> mean over batch
+ * (trainer/trainer_ifnet.py:46).  loss: 1 float; dlogits (B,N) = gscale*(sigmoid(z)-y)/B
+ * (dlogits may be NULL).  workspace: B doubles.                                           */
+int svr_bce_logits_sum_mean(const float *logits, const float *targets, float *loss, float *dlogits,
+                            int64_t B, int64_t N, float gscale, void *workspace, void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * 3x3x3 convolution, padding 1, channels-last (replaces nn.Conv3d(.,.,3,padding=1) + ReLU
+ * model/ifnet.py:126-135,164-191 and autograd).  Weights in the packed layout made by
+ * svr_conv3d_pack_weight: fwd  Wp[tap][ci][co],  bwd-data  Wp[tap'][co][ci] (flipped taps).
+ * ------------------------------------------------------------------------------------- */
+int svr_conv3d_pack_weight(const float *W /*(Co,Ci,3,3,3)*/, float *Wp_fwd, float *Wp_bwd,
+                           int32_t Ci, int32_t Co, void *stream);
+int svr_conv3d_unpack_wgrad(const float *dWp /*[tap][ci][co]*/, float *dW /*(Co,Ci,3,3,3)*/,
+                            int32_t Ci, int32_t Co, void *stream);
+/* out(B,D,H,W,Co) = epi( conv(in(B,D,H,W,Ci), Wp) ): epilogue BIAS / BIAS_RELU / NONE / MASK.
+ * Used for forward (Wp_fwd) and for backward-data (Wp_bwd, Ci<->Co swapped by the caller). */
+int svr_conv3d_k3(const float *in, const float *Wp, const float *bias, float *out, int32_t B,
+                  int32_t D, int32_t H, int32_t W, int32_t Ci, int32_t Co, int epilogue,
+                  const float *mask, void *stream);
+/* dWp[tap][ci][co] = sum_m in[m+tap][ci]*dout[m][co]; db[co] = sum_m dout[m][co] (may be NULL). */
+int64_t svr_conv3d_k3_bwd_weight_workspace(int32_t B, int32_t D, int32_t H, int32_t W, int32_t Ci,
+                                           int32_t Co);
+int svr_conv3d_k3_bwd_weight(const float *in, const float *dout, float *dWp, float *db, int32_t B,
+                             int32_t D, int32_t H, int32_t W, int32_t Ci, int32_t Co,
+                             void *workspace, void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * BatchNorm3d (training or eval) + MaxPool3d(2), channels-last
+ * (replaces nn.BatchNorm3d model/ifnet.py:138-142,165-192 and nn.MaxPool3d(2) :136,169-188).
+ * ------------------------------------------------------------------------------------- */
+/* stats[0:C] = mean, stats[C:2C] = biased variance over (B,D,H,W) in float64.
+ * workspace: svr_bn_stats_workspace() bytes.                                              */
+int64_t svr_bn_stats_workspace(int64_t rows, int32_t C);
+int svr_bn_stats(const float *x, double *stats, int64_t rows /*B*D*H*W*/, int32_t C,
+                 void *workspace, void *stream);
+/* scale_shift[0:C] = gamma*invstd, [C:2C] = beta - mean*gamma*invstd, [2C:3C] = invstd (f32);
+ * training != 0 also updates running_mean/var (momentum, unbiased var) like torch.          */
+int svr_bn_finalize(const double *stats, const float *gamma, const float *beta, float *running_mean,
+                    float *running_var, float *scale_shift, float *mean_f32, int64_t rows,
+                    int32_t C, float eps, float momentum, int training, void *stream);
+/* y = x*scale + shift (full resolution);  pooled (B,D/2,H/2,W/2,C) = 2x2x2 max of y (floor),
+ * argmax (uint8 0..7, first maximum in z,y,x scan order) -- pooled/argmax may be NULL.      */
+int svr_bn_apply_pool(const float *x, const float *scale_shift, float *y, float *pooled,
+                      uint8_t *argmax, int32_t B, int32_t D, int32_t H, int32_t W, int32_t C,
+                      void *stream);
+/* Backward of [ReLU ->] BN -> {sample, pool}:
+ *   dy_total = dy (may be NULL = 0) + unpool(dpooled via argmax) (dpooled may be NULL)
+ *   sums[0:C] = sum dy_total, sums[C:2C] = sum dy_total*xhat   (float64, step 1)
+ *   dx = gamma*invstd*(dy_total - sum1/n - xhat*sum2/n) * (x > 0 if relu_mask)     (step 2)
+ *   dgamma = sum2, dbeta = sum1.                                                            */
+int svr_bn_bwd_reduce(const float *x, const float *dy, const float *dpooled, const uint8_t *argmax,
+                      const float *mean_f32, const float *scale_shift, double *sums, int32_t B,
+                      int32_t D, int32_t H, int32_t W, int32_t C, void *workspace, void *stream);
+int svr_bn_bwd_apply(const float *x, const float *dy, const float *dpooled, const uint8_t *argmax,
+                     const float *mean_f32, const float *scale_shift, const float *gamma,
+                     const double *sums, float *dx, float *dgamma, float *dbeta, int32_t B,
+                     int32_t D, int32_t H, int32_t W, int32_t C, int relu_mask, void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Depth -> point cloud -> voxel grid  (model/projection.py).
+ * ------------------------------------------------------------------------------------- */
+/* pc[b][v*Wi+u] = (c2f * [X,Y,Z,1]) then optionally (p - dims/2)/dims  (projection.py:150-163,
+ * 199-206, 124-132).  consts: f, cx, cy, c2f[0][0], c2f[0][3], c2f[1][1], c2f[1][3], c2f[2][2],
+ * c2f[2][3], dims0, dims1, dims2 (12 floats, host memory).  gdepth/gpc for the backward.   */
+int svr_unproject_fwd(const float *depth, float *pc, int32_t B, int32_t Hi, int32_t Wi,
+                      const float *consts, int normalize, void *stream);
+int svr_unproject_bwd(const float *depth, const float *gpc, float *gdepth, int32_t B, int32_t Hi,
+                      int32_t Wi, const float *consts, int normalize, void *stream);
+/* acc (B,D0,D1,D2) += trilinear splat of valid points (projection.py:39-78); acc must be zeroed
+ * by the caller.  base (B,N,3) int32 and valid (B,N) uint8 are optional outputs (bit-exact gate). */
+int svr_voxelize_splat_fwd(const float *pts, float *acc, int32_t *base, uint8_t *valid, int32_t B,
+                           int32_t N, int32_t D0, int32_t D1, int32_t D2, void *stream);
+/* gpts (B,N,3) = gradient wrt the normalised points given gacc (gradient wrt acc).          */
+int svr_voxelize_splat_bwd(const float *pts, const float *gacc, float *gpts, int32_t B, int32_t N,
+                           int32_t D0, int32_t D1, int32_t D2, void *stream);
+/* out = clamp(scale*in, 0, 1): scale 8 = the reference's x8 alias quirk (projection.py:75-80),
+ * scale 1 = the final clamp of the blur (:116).  bwd: gin = scale*gout where 0 <= scale*in <= 1. */
+int svr_scale_clamp01_fwd(const float *in, float *out, int64_t n, float scale, void *stream);
+int svr_scale_clamp01_bwd(const float *in, const float *gout, float *gin, int64_t n, float scale,
+                          void *stream);
+/* One axis pass of the separable blur (projection.py:96-114): out = correlation along `axis`
+ * (0 = first spatial) with taps[K] (device memory, K odd <= 15), zero padding K/2.           */
+int svr_blur_axis_fwd(const float *in, const float *taps, float *out, int32_t B, int32_t D0,
+                      int32_t D1, int32_t D2, int32_t axis, int32_t K, void *stream);
+/* gin = adjoint pass of gout (gin may be NULL); gtaps[K] (float64, zeroed by the caller) +=
+ * sum_i gout[i]*in[i + t - K/2]  (gtaps may be NULL).                                        */
+int svr_blur_axis_bwd(const float *in, const float *taps, const float *gout, float *gin,
+                      double *gtaps, int32_t B, int32_t D0, int32_t D1, int32_t D2, int32_t axis,
+                      int32_t K, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SVR_HIP_H */

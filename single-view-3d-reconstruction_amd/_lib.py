@@ -1,0 +1,87 @@
+"""ctypes binding of libsvr_hip.so (the C ABI declared in include/svr_hip.h).
+
+There is NO fallback: if the library is missing this raises, and every op raises on a
+non-GPU tensor.  (The CPU oracle lives under oracle/ and is test infrastructure only.)
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libsvr_hip.so")
+
+SVR_MAX_LEVELS = 6
+EPI_NONE, EPI_BIAS, EPI_BIAS_RELU, EPI_MASK = 0, 1, 2, 3
+
+P = C.c_void_p
+I32, I64, F32 = C.c_int32, C.c_int64, C.c_float
+
+
+class Level(C.Structure):
+    _fields_ = [("vol", P), ("gvol", P), ("C", I32), ("D", I32), ("H", I32), ("W", I32), ("col", I32)]
+
+
+class GatherDesc(C.Structure):
+    _fields_ = [("n_levels", I32), ("B", I32), ("N", I32), ("row_stride", I32), ("align_corners", I32),
+                ("displacement", F32), ("level", Level * SVR_MAX_LEVELS)]
+
+
+# name -> (restype, argtypes): exactly the declarations of include/svr_hip.h
+SIGNATURES = {
+    "svr_version": (C.c_int, []),
+    "svr_last_error": (C.c_char_p, []),
+    "svr_gather_trilinear_fwd": (C.c_int, [C.POINTER(GatherDesc), P, P, P]),
+    "svr_gather_trilinear_bwd": (C.c_int, [C.POINTER(GatherDesc), P, P, P, P]),
+    "svr_gather_corner_indices": (C.c_int, [C.POINTER(GatherDesc), I32, P, P, P]),
+    "svr_linear_fwd": (C.c_int, [P, I64, P, I64, P, P, I64, I64, I64, I64, C.c_int, P, I64, P]),
+    "svr_linear_bwd_data": (C.c_int, [P, I64, P, I64, P, I64, I64, I64, I64, C.c_int, P, I64, P]),
+    "svr_linear_bwd_weight_workspace": (I64, [I64, I64, I64]),
+    "svr_linear_bwd_weight": (C.c_int, [P, I64, P, I64, P, I64, P, I64, I64, I64, P, P]),
+    "svr_fc_out_fwd": (C.c_int, [P, I64, P, P, P, I64, I64, P]),
+    "svr_fc_out_bwd_workspace": (I64, [I64, I64]),
+    "svr_fc_out_bwd": (C.c_int, [P, I64, P, P, P, I64, P, P, I64, I64, P, P]),
+    "svr_bce_logits_sum_mean": (C.c_int, [P, P, P, P, I64, I64, F32, P, P]),
+    "svr_conv3d_pack_weight": (C.c_int, [P, P, P, I32, I32, P]),
+    "svr_conv3d_unpack_wgrad": (C.c_int, [P, P, I32, I32, P]),
+    "svr_conv3d_k3": (C.c_int, [P, P, P, P, I32, I32, I32, I32, I32, I32, C.c_int, P, P]),
+    "svr_conv3d_k3_bwd_weight_workspace": (I64, [I32, I32, I32, I32, I32, I32]),
+    "svr_conv3d_k3_bwd_weight": (C.c_int, [P, P, P, P, I32, I32, I32, I32, I32, I32, P, P]),
+    "svr_bn_stats_workspace": (I64, [I64, I32]),
+    "svr_bn_stats": (C.c_int, [P, P, I64, I32, P, P]),
+    "svr_bn_finalize": (C.c_int, [P, P, P, P, P, P, P, I64, I32, F32, F32, C.c_int, P]),
+    "svr_bn_apply_pool": (C.c_int, [P, P, P, P, P, I32, I32, I32, I32, I32, P]),
+    "svr_bn_bwd_reduce": (C.c_int, [P, P, P, P, P, P, P, I32, I32, I32, I32, I32, P, P]),
+    "svr_bn_bwd_apply": (C.c_int, [P, P, P, P, P, P, P, P, P, P, P, I32, I32, I32, I32, I32, C.c_int, P]),
+    "svr_unproject_fwd": (C.c_int, [P, P, I32, I32, I32, C.POINTER(F32), C.c_int, P]),
+    "svr_unproject_bwd": (C.c_int, [P, P, P, I32, I32, I32, C.POINTER(F32), C.c_int, P]),
+    "svr_voxelize_splat_fwd": (C.c_int, [P, P, P, P, I32, I32, I32, I32, I32, P]),
+    "svr_voxelize_splat_bwd": (C.c_int, [P, P, P, I32, I32, I32, I32, I32, P]),
+    "svr_scale_clamp01_fwd": (C.c_int, [P, P, I64, F32, P]),
+    "svr_scale_clamp01_bwd": (C.c_int, [P, P, P, I64, F32, P]),
+    "svr_blur_axis_fwd": (C.c_int, [P, P, P, I32, I32, I32, I32, I32, I32, P]),
+    "svr_blur_axis_bwd": (C.c_int, [P, P, P, P, P, I32, I32, I32, I32, I32, I32, P]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load (once) and return the bound library; raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950).  There is no CPU fallback for the HIP path.")
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)          # AttributeError here = header/library mismatch
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib().svr_last_error()
+        raise RuntimeError(f"libsvr_hip {what} failed (rc={rc}): {msg.decode(errors='replace') if msg else ''}")

@@ -1,0 +1,71 @@
+"""Build libsvr_hip.so (gfx950) in-tree with hipcc.  No JIT cache: the .so sits next to the
+sources so it travels with the repo snapshot to the GPU box."""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+INCLUDE = os.path.join(os.path.dirname(HERE), "include")
+LIBDIR = os.path.join(HERE, "lib")
+LIB = os.path.join(LIBDIR, "libsvr_hip.so")
+
+# file -> extra flags.  Index/weight arithmetic that must round like ATen's CPU kernels is
+# compiled with FP contraction off (see gather.hip / projection.hip headers).
+SOURCES = {
+    "capi.cpp": [],
+    "gather.hip": ["-ffp-contract=off"],
+    "gemm.hip": [],
+    "conv3d.hip": [],
+    "bn_pool.hip": [],
+    "projection.hip": ["-ffp-contract=off"],
+}
+COMMON = ["-O3", "-fPIC", "--offload-arch=gfx950", "-munsafe-fp-atomics", "-std=c++17", "-I" + INCLUDE, "-I" + CSRC]
+
+
+def _hipcc():
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    return "hipcc"
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    os.makedirs(LIBDIR, exist_ok=True)
+    objdir = os.path.join(HERE, "build")
+    os.makedirs(objdir, exist_ok=True)
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    headers.append(os.path.join(INCLUDE, "svr_hip.h"))
+    objs, procs = [], []
+    for src, extra in SOURCES.items():
+        path = os.path.join(CSRC, src)
+        if not os.path.exists(path):
+            continue
+        obj = os.path.join(objdir, src.rsplit(".", 1)[0] + ".o")
+        objs.append(obj)
+        if force or _stale(obj, [path] + headers):
+            cmd = [_hipcc()] + COMMON + extra + (["-x", "hip"] if src.endswith(".cpp") else []) + ["-c", path, "-o", obj]
+            if verbose:
+                print(" ".join(cmd), file=sys.stderr)
+            procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    for src, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError(f"hipcc failed on {src}:\n{out.decode(errors='replace')}")
+    if force or procs or _stale(LIB, objs):
+        cmd = [_hipcc(), "-shared", "-fPIC", "--offload-arch=gfx950", "-o", LIB] + objs
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+        if r.returncode != 0:
+            raise RuntimeError("link failed:\n" + r.stdout.decode(errors="replace"))
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,346 @@
+// BatchNorm3d (training / eval) fused with MaxPool3d(2), channels-last, gfx950.
+//
+// Replaces nn.BatchNorm3d after the ReLU of every encoder stage and the nn.MaxPool3d(2)
+// between stages (reference model/ifnet.py:136-142,165-192; 32-variant :76-80,102-114), and
+// their autograd.  The BN output is what gets sampled AND pooled, so one pass over the
+// activation writes the full-resolution normalised volume, the pooled volume and the pool
+// argmax; the backward merges {gather gradient, un-pooled gradient} -> BN backward -> ReLU mask.
+//
+// Bandwidth bound (HBM): every element is read once / written once per pass, float4 per lane.
+// Statistics are accumulated in short f32 runs and carried in f64 (torch's CPU kernel uses a
+// double accumulator for float input), so mean / variance are good to ~1e-7 relative.
+#include "common.h"
+
+using namespace svr;
+
+namespace {
+
+constexpr int STAT_BLOCKS_MAX = 2048;
+
+// ---------------------------------------------------------------- statistics
+// thread -> (row lane r = tid / Q, quad q = tid % Q); rows strided by 256/Q.
+__global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float *__restrict__ x, double *__restrict__ part,
+                                                               int64_t rows, int C, int64_t rows_per_block) {
+  const int Q = C / 4;
+  const int q = threadIdx.x % Q, rl = threadIdx.x / Q, RL = 256 / Q;
+  int64_t r0 = (int64_t)blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+  double s[4] = {0, 0, 0, 0}, ss[4] = {0, 0, 0, 0};
+  int64_t r = r0 + rl;
+  while (r < r1) {
+    float fs[4] = {0, 0, 0, 0}, fss[4] = {0, 0, 0, 0};
+    for (int it = 0; it < 16 && r < r1; ++it, r += RL) {
+      float4 v = *reinterpret_cast<const float4 *>(x + r * C + q * 4);
+      fs[0] += v.x; fs[1] += v.y; fs[2] += v.z; fs[3] += v.w;
+      fss[0] += v.x * v.x; fss[1] += v.y * v.y; fss[2] += v.z * v.z; fss[3] += v.w * v.w;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { s[i] += (double)fs[i]; ss[i] += (double)fss[i]; }
+  }
+  __shared__ double red[256 * 8];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { red[threadIdx.x * 8 + i] = s[i]; red[threadIdx.x * 8 + 4 + i] = ss[i]; }
+  __syncthreads();
+  if ((int)threadIdx.x < Q) {
+    double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int k = 0; k < RL; ++k)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) a[i] += red[(k * Q + q) * 8 + i];
+    double *o = part + (int64_t)blockIdx.x * 2 * C;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { o[q * 4 + i] = a[i]; o[C + q * 4 + i] = a[4 + i]; }
+  }
+}
+
+__global__ void bn_stats_final_kernel(const double *__restrict__ part, double *__restrict__ stats, int64_t rows, int C,
+                                      int blocks) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0, ss = 0;
+  for (int b = 0; b < blocks; ++b) { s += part[(int64_t)b * 2 * C + c]; ss += part[(int64_t)b * 2 * C + C + c]; }
+  double mean = s / (double)rows;
+  double var = ss / (double)rows - mean * mean;
+  stats[c] = mean;
+  stats[C + c] = var > 0 ? var : 0;
+}
+
+__global__ void bn_finalize_kernel(const double *__restrict__ stats, const float *__restrict__ gamma,
+                                   const float *__restrict__ beta, float *__restrict__ rmean, float *__restrict__ rvar,
+                                   float *__restrict__ ss, float *__restrict__ mean_f32, int64_t rows, int C, float eps,
+                                   float momentum, int training) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double mean, var;
+  if (training) {
+    mean = stats[c];
+    var = stats[C + c];
+    if (rmean) rmean[c] = (float)((1.0 - (double)momentum) * (double)rmean[c] + (double)momentum * mean);
+    if (rvar) {
+      double unb = rows > 1 ? var * (double)rows / (double)(rows - 1) : var;
+      rvar[c] = (float)((1.0 - (double)momentum) * (double)rvar[c] + (double)momentum * unb);
+    }
+  } else {
+    mean = (double)rmean[c];
+    var = (double)rvar[c];
+  }
+  double invstd = 1.0 / sqrt(var + (double)eps);
+  float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+  float scale = (float)invstd * g;
+  ss[c] = scale;
+  ss[C + c] = b - (float)mean * scale;
+  ss[2 * C + c] = (float)invstd;
+  mean_f32[c] = (float)mean;
+}
+
+// ---------------------------------------------------------------- apply + pool
+struct Vol {
+  int B, D, H, W, C;
+};
+
+// one thread = one 2x2x2 cell (ceil-div grid, so odd trailing voxels are still normalised) x 4 channels
+__global__ __launch_bounds__(256) void bn_apply_pool_kernel(const float *__restrict__ x, const float *__restrict__ ss,
+                                                            float *__restrict__ y, float *__restrict__ pooled,
+                                                            uint8_t *__restrict__ argmax, Vol v, int64_t total) {
+  int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= total) return;
+  const int Q = v.C / 4;
+  const int Dc = (v.D + 1) / 2, Hc = (v.H + 1) / 2, Wc = (v.W + 1) / 2;
+  const int Dp = v.D / 2, Hp = v.H / 2, Wp = v.W / 2;
+  int q = (int)(gid % Q);
+  int64_t cell = gid / Q;
+  int cx = (int)(cell % Wc); cell /= Wc;
+  int cy = (int)(cell % Hc); cell /= Hc;
+  int cz = (int)(cell % Dc);
+  int64_t b = cell / Dc;
+  float4 sc = *reinterpret_cast<const float4 *>(ss + q * 4);
+  float4 sh = *reinterpret_cast<const float4 *>(ss + v.C + q * 4);
+  float4 best = make_float4(0.f, 0.f, 0.f, 0.f);
+  int am[4] = {0, 0, 0, 0};
+  bool first = true;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    int z = cz * 2 + (k >> 2), yy = cy * 2 + ((k >> 1) & 1), xx = cx * 2 + (k & 1);
+    if (z < v.D && yy < v.H && xx < v.W) {
+      int64_t off = (((b * v.D + z) * v.H + yy) * v.W + xx) * v.C + q * 4;
+      float4 a = *reinterpret_cast<const float4 *>(x + off);
+      float4 o;
+      o.x = a.x * sc.x + sh.x; o.y = a.y * sc.y + sh.y; o.z = a.z * sc.z + sh.z; o.w = a.w * sc.w + sh.w;
+      *reinterpret_cast<float4 *>(y + off) = o;
+      // first maximum in (z,y,x) scan order wins, NaN propagates (ATen max_pool3d: val > max || isnan(val))
+      if (first) { best = o; first = false; }
+      else {
+        if (o.x > best.x || o.x != o.x) { best.x = o.x; am[0] = k; }
+        if (o.y > best.y || o.y != o.y) { best.y = o.y; am[1] = k; }
+        if (o.z > best.z || o.z != o.z) { best.z = o.z; am[2] = k; }
+        if (o.w > best.w || o.w != o.w) { best.w = o.w; am[3] = k; }
+      }
+    }
+  }
+  if (pooled && cz < Dp && cy < Hp && cx < Wp) {
+    int64_t po = (((b * Dp + cz) * Hp + cy) * Wp + cx) * v.C + q * 4;
+    *reinterpret_cast<float4 *>(pooled + po) = best;
+    if (argmax) *reinterpret_cast<uint32_t *>(argmax + po) = (uint32_t)am[0] | ((uint32_t)am[1] << 8) | ((uint32_t)am[2] << 16) | ((uint32_t)am[3] << 24);
+  }
+}
+
+// ---------------------------------------------------------------- backward
+// dy_total at the 8 voxels of a cell = dy (gather gradient, optional) + dpooled routed by argmax.
+template <bool APPLY>
+__global__ __launch_bounds__(256) void bn_bwd_kernel(const float *__restrict__ x, const float *__restrict__ dy,
+                                                     const float *__restrict__ dpooled,
+                                                     const uint8_t *__restrict__ argmax,
+                                                     const float *__restrict__ mean, const float *__restrict__ ss,
+                                                     const double *__restrict__ sums, double *__restrict__ part,
+                                                     float *__restrict__ dx, Vol v, int64_t cells, int relu_mask) {
+  const int Q = v.C / 4;
+  const int q = threadIdx.x % Q, cl = threadIdx.x / Q, CL = 256 / Q;
+  const int Dc = (v.D + 1) / 2, Hc = (v.H + 1) / 2, Wc = (v.W + 1) / 2;
+  const int Dp = v.D / 2, Hp = v.H / 2, Wp = v.W / 2;
+  const double n = (double)v.B * v.D * v.H * v.W;
+  float4 mu = *reinterpret_cast<const float4 *>(mean + q * 4);
+  float4 sc = *reinterpret_cast<const float4 *>(ss + q * 4);          // gamma*invstd
+  float4 is = *reinterpret_cast<const float4 *>(ss + 2 * v.C + q * 4);  // invstd
+  float m1[4] = {0, 0, 0, 0}, m2[4] = {0, 0, 0, 0};
+  if (APPLY) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      m1[i] = (float)(sums[q * 4 + i] / n);
+      m2[i] = (float)(sums[v.C + q * 4 + i] / n);
+    }
+  }
+  double s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+  for (int64_t cell = (int64_t)blockIdx.x * CL + cl; cell < cells; cell += (int64_t)gridDim.x * CL) {
+    int64_t t = cell;
+    int cx = (int)(t % Wc); t /= Wc;
+    int cy = (int)(t % Hc); t /= Hc;
+    int cz = (int)(t % Dc);
+    int64_t b = t / Dc;
+    float4 dp = make_float4(0.f, 0.f, 0.f, 0.f);
+    uint32_t am = 0xffffffffu;
+    if (dpooled && cz < Dp && cy < Hp && cx < Wp) {
+      int64_t po = (((b * Dp + cz) * Hp + cy) * Wp + cx) * v.C + q * 4;
+      dp = *reinterpret_cast<const float4 *>(dpooled + po);
+      am = *reinterpret_cast<const uint32_t *>(argmax + po);
+    }
+    float f1[4] = {0, 0, 0, 0}, f2[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      int z = cz * 2 + (k >> 2), yy = cy * 2 + ((k >> 1) & 1), xx = cx * 2 + (k & 1);
+      if (z < v.D && yy < v.H && xx < v.W) {
+        int64_t off = (((b * v.D + z) * v.H + yy) * v.W + xx) * v.C + q * 4;
+        float4 a = *reinterpret_cast<const float4 *>(x + off);
+        float4 g = dy ? *reinterpret_cast<const float4 *>(dy + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+        if ((am & 0xff) == (uint32_t)k) g.x += dp.x;
+        if (((am >> 8) & 0xff) == (uint32_t)k) g.y += dp.y;
+        if (((am >> 16) & 0xff) == (uint32_t)k) g.z += dp.z;
+        if (((am >> 24) & 0xff) == (uint32_t)k) g.w += dp.w;
+        float xh[4] = {(a.x - mu.x) * is.x, (a.y - mu.y) * is.y, (a.z - mu.z) * is.z, (a.w - mu.w) * is.w};
+        float gg[4] = {g.x, g.y, g.z, g.w};
+        if (APPLY) {
+          float av[4] = {a.x, a.y, a.z, a.w};
+          float scv[4] = {sc.x, sc.y, sc.z, sc.w};
+          float o[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            o[i] = scv[i] * (gg[i] - m1[i] - xh[i] * m2[i]);
+            if (relu_mask && !(av[i] > 0.f)) o[i] = 0.f;
+          }
+          *reinterpret_cast<float4 *>(dx + off) = make_float4(o[0], o[1], o[2], o[3]);
+        } else {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) { f1[i] += gg[i]; f2[i] += gg[i] * xh[i]; }
+        }
+      }
+    }
+    if (!APPLY) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { s1[i] += (double)f1[i]; s2[i] += (double)f2[i]; }
+    }
+  }
+  if (!APPLY) {
+    __shared__ double red[256 * 8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { red[threadIdx.x * 8 + i] = s1[i]; red[threadIdx.x * 8 + 4 + i] = s2[i]; }
+    __syncthreads();
+    if ((int)threadIdx.x < Q) {
+      double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      for (int k = 0; k < CL; ++k)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) a[i] += red[(k * Q + q) * 8 + i];
+      double *o = part + (int64_t)blockIdx.x * 2 * v.C;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { o[q * 4 + i] = a[i]; o[v.C + q * 4 + i] = a[4 + i]; }
+    }
+  }
+}
+
+__global__ void sum_parts_kernel(const double *__restrict__ part, double *__restrict__ out, int cols, int blocks) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= cols) return;
+  double s = 0;
+  for (int b = 0; b < blocks; ++b) s += part[(int64_t)b * cols + c];
+  out[c] = s;
+}
+
+__global__ void bn_param_grads_kernel(const double *__restrict__ sums, float *__restrict__ dgamma,
+                                      float *__restrict__ dbeta, int C) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  if (dbeta) dbeta[c] = (float)sums[c];
+  if (dgamma) dgamma[c] = (float)sums[C + c];
+}
+
+int check_c(int C) {
+  SVR_CHECK(C >= 4 && C <= 256 && C % 4 == 0 && 256 % (C / 4) == 0, SVR_E_UNSUPPORTED, "bn: C=%d (need 4 | C, C/4 | 256)", C);
+  return SVR_OK;
+}
+
+int stats_blocks(int64_t rows, int64_t *rows_per_block) {
+  int64_t b = cdiv(rows, 256);
+  if (b > STAT_BLOCKS_MAX) b = STAT_BLOCKS_MAX;
+  if (b < 1) b = 1;
+  *rows_per_block = cdiv(rows, b);
+  return (int)cdiv(rows, *rows_per_block);
+}
+
+int bwd_blocks(int64_t cells, int C) {
+  int CL = 256 / (C / 4);
+  int64_t b = cdiv(cells, CL);
+  if (b > STAT_BLOCKS_MAX) b = STAT_BLOCKS_MAX;
+  return (int)(b < 1 ? 1 : b);
+}
+
+}  // namespace
+
+extern "C" int64_t svr_bn_stats_workspace(int64_t rows, int32_t C) {
+  (void)rows;
+  return (int64_t)STAT_BLOCKS_MAX * 2 * C * (int64_t)sizeof(double);
+}
+
+extern "C" int svr_bn_stats(const float *x, double *stats, int64_t rows, int32_t C, void *workspace, void *stream) {
+  if (int rc = check_c(C)) return rc;
+  SVR_CHECK(x && stats && workspace && rows > 0, SVR_E_BADARG, "bn_stats: bad argument");
+  hipStream_t s = (hipStream_t)stream;
+  int64_t rpb;
+  int blocks = stats_blocks(rows, &rpb);
+  hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(blocks), dim3(256), 0, s, x, (double *)workspace, rows, C, rpb);
+  hipLaunchKernelGGL(bn_stats_final_kernel, dim3(cdiv(C, 64)), dim3(64), 0, s, (const double *)workspace, stats, rows, C, blocks);
+  return launch_status("bn_stats");
+}
+
+extern "C" int svr_bn_finalize(const double *stats, const float *gamma, const float *beta, float *running_mean,
+                               float *running_var, float *scale_shift, float *mean_f32, int64_t rows, int32_t C, float eps,
+                               float momentum, int training, void *stream) {
+  SVR_CHECK(scale_shift && mean_f32 && (training ? stats != nullptr : (running_mean && running_var)), SVR_E_BADARG, "bn_finalize: bad argument");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 64)), dim3(64), 0, (hipStream_t)stream, stats, gamma, beta,
+                     running_mean, running_var, scale_shift, mean_f32, rows, C, eps, momentum, training);
+  return launch_status("bn_finalize");
+}
+
+extern "C" int svr_bn_apply_pool(const float *x, const float *scale_shift, float *y, float *pooled, uint8_t *argmax,
+                                 int32_t B, int32_t D, int32_t H, int32_t W, int32_t C, void *stream) {
+  if (int rc = check_c(C)) return rc;
+  SVR_CHECK(x && scale_shift && y, SVR_E_BADARG, "bn_apply_pool: null pointer");
+  Vol v{B, D, H, W, C};
+  int64_t total = (int64_t)B * ((D + 1) / 2) * ((H + 1) / 2) * ((W + 1) / 2) * (C / 4);
+  if (total == 0) return SVR_OK;
+  hipLaunchKernelGGL(bn_apply_pool_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, x,
+                     scale_shift, y, pooled, argmax, v, total);
+  return launch_status("bn_apply_pool");
+}
+
+extern "C" int svr_bn_bwd_reduce(const float *x, const float *dy, const float *dpooled, const uint8_t *argmax,
+                                 const float *mean_f32, const float *scale_shift, double *sums, int32_t B, int32_t D,
+                                 int32_t H, int32_t W, int32_t C, void *workspace, void *stream) {
+  if (int rc = check_c(C)) return rc;
+  SVR_CHECK(x && mean_f32 && scale_shift && sums && workspace, SVR_E_BADARG, "bn_bwd_reduce: null pointer");
+  SVR_CHECK(!dpooled || argmax, SVR_E_BADARG, "bn_bwd_reduce: dpooled needs argmax");
+  hipStream_t s = (hipStream_t)stream;
+  Vol v{B, D, H, W, C};
+  int64_t cells = (int64_t)B * ((D + 1) / 2) * ((H + 1) / 2) * ((W + 1) / 2);
+  int blocks = bwd_blocks(cells, C);
+  hipLaunchKernelGGL(bn_bwd_kernel<false>, dim3(blocks), dim3(256), 0, s, x, dy, dpooled, argmax, mean_f32, scale_shift,
+                     (const double *)nullptr, (double *)workspace, (float *)nullptr, v, cells, 0);
+  hipLaunchKernelGGL(sum_parts_kernel, dim3(cdiv(2 * C, 64)), dim3(64), 0, s, (const double *)workspace, sums, 2 * C, blocks);
+  return launch_status("bn_bwd_reduce");
+}
+
+extern "C" int svr_bn_bwd_apply(const float *x, const float *dy, const float *dpooled, const uint8_t *argmax,
+                                const float *mean_f32, const float *scale_shift, const float *gamma, const double *sums,
+                                float *dx, float *dgamma, float *dbeta, int32_t B, int32_t D, int32_t H, int32_t W,
+                                int32_t C, int relu_mask, void *stream) {
+  (void)gamma;
+  if (int rc = check_c(C)) return rc;
+  SVR_CHECK(x && mean_f32 && scale_shift && sums && dx, SVR_E_BADARG, "bn_bwd_apply: null pointer");
+  SVR_CHECK(!dpooled || argmax, SVR_E_BADARG, "bn_bwd_apply: dpooled needs argmax");
+  hipStream_t s = (hipStream_t)stream;
+  Vol v{B, D, H, W, C};
+  int64_t cells = (int64_t)B * ((D + 1) / 2) * ((H + 1) / 2) * ((W + 1) / 2);
+  int CL = 256 / (C / 4);
+  int64_t blocks = cdiv(cells, CL);
+  if (blocks > 65535 * 16) blocks = 65535 * 16;
+  hipLaunchKernelGGL(bn_bwd_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, x, dy, dpooled, argmax, mean_f32,
+                     scale_shift, sums, (double *)nullptr, dx, v, cells, relu_mask);
+  if (dgamma || dbeta)
+    hipLaunchKernelGGL(bn_param_grads_kernel, dim3(cdiv(C, 64)), dim3(64), 0, s, sums, dgamma, dbeta, C);
+  return launch_status("bn_bwd_apply");
+}

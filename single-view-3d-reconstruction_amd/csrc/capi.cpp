@@ -1,0 +1,16 @@
+// Error plumbing + version for the C ABI (include/svr_hip.h).
+#include "common.h"
+#include <string.h>
+
+namespace svr {
+static thread_local char g_err[512] = "";
+void set_error(const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+}  // namespace svr
+
+extern "C" int svr_version(void) { return 100; }
+extern "C" const char *svr_last_error(void) { return svr::g_err; }

@@ -1,0 +1,434 @@
+// 3x3x3 / padding-1 convolution on channels-last volumes for gfx950, exact-f32 MFMA.
+//
+// Replaces nn.Conv3d(ci, co, 3, padding=1) (+ fused bias / ReLU) of the IF-Net encoder
+// (reference model/ifnet.py:126-135 and :164-191; 32-variant :69-74,100-113) and its autograd:
+//   forward / backward-data : implicit GEMM  out[m][co] = sum_{tap,ci} in[m+tap][ci] Wp[tap][ci][co]
+//                             (M = B*D*H*W voxels, K = 27*Ci), LDS-tiled, shared core gemm_core.h;
+//   backward-weight         : dWp[tap][ci][co] = sum_m in[m+tap][ci] dout[m][co]; the reduction
+//                             dimension (voxels) is the MFMA k, operands go straight from global
+//                             memory to the matrix core (a half wave reads 32 consecutive channels
+//                             of one voxel = one 128-B line), per-wave partial slabs + ordered sum;
+//   Ci == 1 (conv_in)       : direct stencil kernels (bandwidth bound, not GEMM shaped).
+#include "common.h"
+#include "gemm_core.h"
+
+using namespace svr;
+
+namespace svr {
+// defined in gemm.hip
+void colsum_launch(const float *Y, int64_t ldy, float *out, float *part, int64_t M, int64_t N, hipStream_t s);
+int64_t colsum_workspace_floats(int64_t M, int64_t N);
+}  // namespace svr
+
+namespace {
+
+__global__ void pack_weight_kernel(const float *__restrict__ W, float *__restrict__ Wf, float *__restrict__ Wb, int Ci,
+                                   int Co) {
+  int idx = blockIdx.x * blockDim.x + threadIdx.x;  // over (co, ci, tap) in the source order
+  if (idx >= Co * Ci * 27) return;
+  int tap = idx % 27, ci = (idx / 27) % Ci, co = idx / (27 * Ci);
+  float v = W[idx];
+  if (Wf) Wf[((size_t)tap * Ci + ci) * Co + co] = v;
+  if (Wb) Wb[((size_t)(26 - tap) * Co + co) * Ci + ci] = v;
+}
+
+__global__ void unpack_wgrad_kernel(const float *__restrict__ dWp, float *__restrict__ dW, int Ci, int Co) {
+  int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= Co * Ci * 27) return;
+  int tap = idx % 27, ci = (idx / 27) % Ci, co = idx / (27 * Ci);
+  dW[idx] = dWp[((size_t)tap * Ci + ci) * Co + co];
+}
+
+struct ConvShape {
+  int B, D, H, W, Ci, Co;
+};
+
+// A operand of the implicit GEMM: row = output voxel, 16 consecutive k = 16 channels of one tap.
+template <int ROWS>
+struct ConvALoader {
+  static constexpr int R = ROWS / 64;
+  static constexpr int LD = ROWS + 2;
+  const float *in;
+  int D, H, W, Ci;
+  int vz[R], vy[R], vx[R];
+  int64_t vbase[R];  // voxel index of (b,0,0,0), or -1 for rows past M
+  float4 v[R];
+  __device__ __forceinline__ void init(const float *in_, const ConvShape &s, int64_t m0, int64_t M) {
+    in = in_;
+    D = s.D; H = s.H; W = s.W; Ci = s.Ci;
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+      int64_t m = m0 + (t >> 2) + 64 * i;
+      if (m < M) {
+        int x = (int)(m % W);
+        int64_t r = m / W;
+        int y = (int)(r % H);
+        r /= H;
+        int z = (int)(r % D);
+        int64_t b = r / D;
+        vx[i] = x; vy[i] = y; vz[i] = z;
+        vbase[i] = b * D * H * W;
+      } else {
+        vx[i] = vy[i] = vz[i] = 0;
+        vbase[i] = -1;
+      }
+    }
+  }
+  __device__ __forceinline__ void load(int kt) {
+    const int t = threadIdx.x;
+    const int k0 = kt * BK;
+    const int tap = k0 / Ci, ci0 = k0 - tap * Ci;
+    const int dz = tap / 9 - 1, dy = (tap / 3) % 3 - 1, dx = tap % 3 - 1;
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+      int z = vz[i] + dz, y = vy[i] + dy, x = vx[i] + dx;
+      bool ok = vbase[i] >= 0 && z >= 0 && z < D && y >= 0 && y < H && x >= 0 && x < W;
+      if (ok) {
+        const float *p = in + (vbase[i] + ((int64_t)z * H + y) * W + x) * Ci + ci0 + (t & 3) * 4;
+        v[i] = *reinterpret_cast<const float4 *>(p);
+      } else {
+        v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+  }
+  __device__ __forceinline__ void store(float *tile) const {
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+      float *d = tile + ((t & 3) * 4) * LD + (t >> 2) + 64 * i;
+      d[0] = v[i].x;
+      d[LD] = v[i].y;
+      d[2 * LD] = v[i].z;
+      d[3 * LD] = v[i].w;
+    }
+  }
+};
+
+template <class Cfg>
+__global__ __launch_bounds__(256) void conv3d_igemm_kernel(const float *__restrict__ in, const float *__restrict__ Wp,
+                                                           const float *__restrict__ bias, float *__restrict__ out,
+                                                           const float *__restrict__ mask, ConvShape s, int mode) {
+  const int64_t M = (int64_t)s.B * s.D * s.H * s.W;
+  const int64_t m0 = (int64_t)blockIdx.x * Cfg::BM;
+  const int n0 = blockIdx.y * Cfg::BN;
+  const int Co = s.Co;
+  auto bfn = [=](int k, int col4, int kt) -> const float * {
+    int c = n0 + col4;
+    return c < Co ? Wp + ((int64_t)kt * BK + k) * Co + c : nullptr;
+  };
+  typedef ConvALoader<Cfg::BM> AL;
+  typedef KRowLoader<Cfg::BN, decltype(bfn)> BL;
+  __shared__ GemmSmem<Cfg, AL, BL> sm;
+  AL al;
+  al.init(in, s, m0, M);
+  BL bl{bfn};
+  f32x16 acc[Cfg::TM][Cfg::TN];
+  gemm_mainloop<Cfg>(al, bl, sm, 0, 27 * s.Ci / BK, acc);
+  gemm_foreach<Cfg>(acc, [&](int row, int col, float v) {
+    int64_t m = m0 + row;
+    int n = n0 + col;
+    if (m < M && n < Co) {
+      if (mode == SVR_EPI_BIAS || mode == SVR_EPI_BIAS_RELU) v += bias[n];
+      if (mode == SVR_EPI_BIAS_RELU) v = fmaxf(v, 0.f);
+      if (mode == SVR_EPI_MASK) v = (mask[m * Co + n] > 0.f) ? v : 0.f;
+      out[m * Co + n] = v;
+    }
+  });
+}
+
+// ---- Ci == 1 forward: one thread per output voxel, CO outputs each (conv_in 1->16, 32-variant 1->32)
+template <int CO>
+__global__ __launch_bounds__(256) void conv3d_c1_fwd_kernel(const float *__restrict__ in, const float *__restrict__ Wp,
+                                                            const float *__restrict__ bias, float *__restrict__ out,
+                                                            ConvShape s, int mode) {
+  __shared__ float w[27 * CO + CO];
+  for (int i = threadIdx.x; i < 27 * CO; i += blockDim.x) w[i] = Wp[i];
+  for (int i = threadIdx.x; i < CO; i += blockDim.x) w[27 * CO + i] = (mode == SVR_EPI_NONE) ? 0.f : bias[i];
+  __syncthreads();
+  const int64_t M = (int64_t)s.B * s.D * s.H * s.W;
+  int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= M) return;
+  int x = (int)(m % s.W);
+  int64_t r = m / s.W;
+  int y = (int)(r % s.H);
+  r /= s.H;
+  int z = (int)(r % s.D);
+  int64_t b = r / s.D;
+  const float *ib = in + b * s.D * s.H * s.W;
+  float acc[CO];
+#pragma unroll
+  for (int c = 0; c < CO; ++c) acc[c] = w[27 * CO + c];
+#pragma unroll
+  for (int tap = 0; tap < 27; ++tap) {
+    int zz = z + tap / 9 - 1, yy = y + (tap / 3) % 3 - 1, xx = x + tap % 3 - 1;
+    float v = 0.f;
+    if (zz >= 0 && zz < s.D && yy >= 0 && yy < s.H && xx >= 0 && xx < s.W) v = ib[((int64_t)zz * s.H + yy) * s.W + xx];
+#pragma unroll
+    for (int c = 0; c < CO; ++c) acc[c] += v * w[tap * CO + c];
+  }
+  float *o = out + m * CO;
+#pragma unroll
+  for (int c = 0; c < CO; c += 4) {
+    float4 t = make_float4(acc[c], acc[c + 1], acc[c + 2], acc[c + 3]);
+    if (mode == SVR_EPI_BIAS_RELU) {
+      t.x = fmaxf(t.x, 0.f); t.y = fmaxf(t.y, 0.f); t.z = fmaxf(t.z, 0.f); t.w = fmaxf(t.w, 0.f);
+    }
+    *reinterpret_cast<float4 *>(o + c) = t;
+  }
+}
+
+// ---- Co == 1 "forward" = backward-data of a Ci==1 conv: out[m] = sum_{tap,ci} in[m+tap][ci] Wp[tap][ci]
+template <int CI>
+__global__ __launch_bounds__(256) void conv3d_to1_kernel(const float *__restrict__ in, const float *__restrict__ Wp,
+                                                         float *__restrict__ out, ConvShape s) {
+  __shared__ float w[27 * CI];
+  for (int i = threadIdx.x; i < 27 * CI; i += blockDim.x) w[i] = Wp[i];
+  __syncthreads();
+  const int64_t M = (int64_t)s.B * s.D * s.H * s.W;
+  int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= M) return;
+  int x = (int)(m % s.W);
+  int64_t r = m / s.W;
+  int y = (int)(r % s.H);
+  r /= s.H;
+  int z = (int)(r % s.D);
+  int64_t b = r / s.D;
+  const float *ib = in + b * s.D * s.H * s.W * CI;
+  float acc = 0.f;
+  for (int tap = 0; tap < 27; ++tap) {
+    int zz = z + tap / 9 - 1, yy = y + (tap / 3) % 3 - 1, xx = x + tap % 3 - 1;
+    if (zz >= 0 && zz < s.D && yy >= 0 && yy < s.H && xx >= 0 && xx < s.W) {
+      const float *p = ib + (((int64_t)zz * s.H + yy) * s.W + xx) * CI;
+#pragma unroll
+      for (int c = 0; c < CI; c += 4) {
+        float4 v = *reinterpret_cast<const float4 *>(p + c);
+        acc += v.x * w[tap * CI + c] + v.y * w[tap * CI + c + 1] + v.z * w[tap * CI + c + 2] + v.w * w[tap * CI + c + 3];
+      }
+    }
+  }
+  out[m] = acc;
+}
+
+// ---- backward-weight: one tap and one (32 ci x 32 co) tile per workgroup, waves split the x-rows.
+//      slab[(chunk*4 + wave)][tap][ci][co] partials.
+constexpr int BW_ROWS = 256;  // (b,z,y) rows per workgroup
+
+__global__ __launch_bounds__(256) void conv3d_bwd_weight_kernel(const float *__restrict__ in,
+                                                                const float *__restrict__ dout,
+                                                                float *__restrict__ slab, ConvShape s, int ci_tiles,
+                                                                int co_tiles) {
+  const int tap = blockIdx.x;
+  const int tile = blockIdx.y;
+  const int ci0 = (tile / co_tiles) * 32, co0 = (tile % co_tiles) * 32;
+  const int chunk = blockIdx.z;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int dz = tap / 9 - 1, dy = (tap / 3) % 3 - 1, dx = tap % 3 - 1;
+  const int64_t nrows = (int64_t)s.B * s.D * s.H;
+  const int64_t r0 = (int64_t)chunk * BW_ROWS;
+  const bool ci_ok = ci0 + l31 < s.Ci, co_ok = co0 + l31 < s.Co;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  for (int64_t row = r0 + wave; row < r0 + BW_ROWS && row < nrows; row += 4) {
+    int y = (int)(row % s.H);
+    int64_t t = row / s.H;
+    int z = (int)(t % s.D);
+    int64_t b = t / s.D;
+    int zz = z + dz, yy = y + dy;
+    if (zz < 0 || zz >= s.D || yy < 0 || yy >= s.H) continue;
+    const float *arow = in + ((b * s.D + zz) * s.H + yy) * (int64_t)s.W * s.Ci + ci0 + l31;
+    const float *brow = dout + row * (int64_t)s.W * s.Co + co0 + l31;
+    for (int x0 = 0; x0 < s.W; x0 += 8) {
+      float av[4], bv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        int x = x0 + 2 * u + lh, xs = x + dx;
+        av[u] = (ci_ok && x < s.W && xs >= 0 && xs < s.W) ? arow[(int64_t)xs * s.Ci] : 0.f;
+        bv[u] = (co_ok && x < s.W) ? brow[(int64_t)x * s.Co] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u], acc, 0, 0, 0);
+    }
+  }
+  // slab layout: [chunk*4+wave][tap][tile][32][32]
+  float *o = slab + ((((int64_t)chunk * 4 + wave) * 27 + tap) * (ci_tiles * co_tiles) + tile) * 1024;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    int i = (r & 3) + 8 * (r >> 2) + 4 * lh;
+    o[i * 32 + l31] = acc[r];
+  }
+}
+
+__global__ void conv3d_bwd_weight_reduce_kernel(const float *__restrict__ slab, float *__restrict__ dWp, int Ci, int Co,
+                                                int ci_tiles, int co_tiles, int parts) {
+  int idx = blockIdx.x * blockDim.x + threadIdx.x;  // over [tap][tile][32][32]
+  int per = 27 * ci_tiles * co_tiles * 1024;
+  if (idx >= per) return;
+  int j = idx & 31, i = (idx >> 5) & 31;
+  int tile = (idx >> 10) % (ci_tiles * co_tiles), tap = idx / (1024 * ci_tiles * co_tiles);
+  int ci = (tile / co_tiles) * 32 + i, co = (tile % co_tiles) * 32 + j;
+  if (ci >= Ci || co >= Co) return;
+  double sum = 0.0;
+  for (int p = 0; p < parts; ++p) sum += (double)slab[(int64_t)p * per + idx];
+  dWp[((size_t)tap * Ci + ci) * Co + co] = (float)sum;
+}
+
+// ---- Ci == 1 backward-weight: A[i = tap][k = voxel] = in[voxel + tap], B[k = voxel][j = co] = dout
+__global__ __launch_bounds__(256) void conv3d_c1_bwd_weight_kernel(const float *__restrict__ in,
+                                                                   const float *__restrict__ dout,
+                                                                   float *__restrict__ slab, ConvShape s) {
+  const int chunk = blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int tap = l31;  // as the A row
+  const int dz = tap / 9 - 1, dy = (tap / 3) % 3 - 1, dx = tap % 3 - 1;
+  const bool tap_ok = tap < 27, co_ok = l31 < s.Co;
+  const int64_t nrows = (int64_t)s.B * s.D * s.H;
+  const int64_t r0 = (int64_t)chunk * BW_ROWS;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  for (int64_t row = r0 + wave; row < r0 + BW_ROWS && row < nrows; row += 4) {
+    int y = (int)(row % s.H);
+    int64_t t = row / s.H;
+    int z = (int)(t % s.D);
+    int64_t b = t / s.D;
+    int zz = z + dz, yy = y + dy;
+    bool rok = tap_ok && zz >= 0 && zz < s.D && yy >= 0 && yy < s.H;
+    const float *arow = in + ((b * s.D + (rok ? zz : 0)) * s.H + (rok ? yy : 0)) * (int64_t)s.W;
+    const float *brow = dout + row * (int64_t)s.W * s.Co + l31;
+    for (int x0 = 0; x0 < s.W; x0 += 8) {
+      float av[4], bv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        int x = x0 + 2 * u + lh, xs = x + dx;
+        av[u] = (rok && x < s.W && xs >= 0 && xs < s.W) ? arow[xs] : 0.f;
+        bv[u] = (co_ok && x < s.W) ? brow[(int64_t)x * s.Co] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u], acc, 0, 0, 0);
+    }
+  }
+  float *o = slab + ((int64_t)chunk * 4 + wave) * 1024;  // [tap 32][co 32]
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    int i = (r & 3) + 8 * (r >> 2) + 4 * lh;
+    o[i * 32 + l31] = acc[r];
+  }
+}
+
+__global__ void conv3d_c1_bwd_weight_reduce_kernel(const float *__restrict__ slab, float *__restrict__ dWp, int Co,
+                                                   int parts) {
+  int idx = blockIdx.x * blockDim.x + threadIdx.x;  // [tap 32][co 32]
+  if (idx >= 1024) return;
+  int tap = idx >> 5, co = idx & 31;
+  if (tap >= 27 || co >= Co) return;
+  double sum = 0.0;
+  for (int p = 0; p < parts; ++p) sum += (double)slab[(int64_t)p * 1024 + idx];
+  dWp[tap * Co + co] = (float)sum;
+}
+
+int check_shape(int B, int D, int H, int W, int Ci, int Co) {
+  SVR_CHECK(B > 0 && D > 0 && H > 0 && W > 0, SVR_E_BADSHAPE, "conv3d: empty volume %dx%dx%dx%d", B, D, H, W);
+  SVR_CHECK(Ci >= 1 && Co >= 1, SVR_E_BADSHAPE, "conv3d: Ci=%d Co=%d", Ci, Co);
+  return SVR_OK;
+}
+
+}  // namespace
+
+extern "C" int svr_conv3d_pack_weight(const float *W, float *Wp_fwd, float *Wp_bwd, int32_t Ci, int32_t Co, void *stream) {
+  SVR_CHECK(W && (Wp_fwd || Wp_bwd), SVR_E_BADARG, "pack_weight: null pointer");
+  int n = Ci * Co * 27;
+  hipLaunchKernelGGL(pack_weight_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, W, Wp_fwd, Wp_bwd, Ci, Co);
+  return launch_status("pack_weight");
+}
+
+extern "C" int svr_conv3d_unpack_wgrad(const float *dWp, float *dW, int32_t Ci, int32_t Co, void *stream) {
+  SVR_CHECK(dWp && dW, SVR_E_BADARG, "unpack_wgrad: null pointer");
+  int n = Ci * Co * 27;
+  hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, dWp, dW, Ci, Co);
+  return launch_status("unpack_wgrad");
+}
+
+extern "C" int svr_conv3d_k3(const float *in, const float *Wp, const float *bias, float *out, int32_t B, int32_t D,
+                             int32_t H, int32_t W, int32_t Ci, int32_t Co, int epilogue, const float *mask, void *stream) {
+  if (int rc = check_shape(B, D, H, W, Ci, Co)) return rc;
+  SVR_CHECK(in && Wp && out, SVR_E_BADARG, "conv3d: null pointer");
+  SVR_CHECK(epilogue >= SVR_EPI_NONE && epilogue <= SVR_EPI_MASK, SVR_E_BADARG, "conv3d: epilogue %d", epilogue);
+  SVR_CHECK(!(epilogue == SVR_EPI_BIAS || epilogue == SVR_EPI_BIAS_RELU) || bias, SVR_E_BADARG, "conv3d: epilogue needs bias");
+  SVR_CHECK(epilogue != SVR_EPI_MASK || mask, SVR_E_BADARG, "conv3d: epilogue needs mask");
+  hipStream_t s = (hipStream_t)stream;
+  ConvShape sh{B, D, H, W, Ci, Co};
+  const int64_t M = (int64_t)B * D * H * W;
+  if (Ci == 1) {
+    SVR_CHECK(epilogue != SVR_EPI_MASK, SVR_E_UNSUPPORTED, "conv3d: Ci=1 with mask epilogue");
+    unsigned grid = (unsigned)cdiv(M, 256);
+    if (Co == 16) hipLaunchKernelGGL(conv3d_c1_fwd_kernel<16>, dim3(grid), dim3(256), 0, s, in, Wp, bias, out, sh, epilogue);
+    else if (Co == 32) hipLaunchKernelGGL(conv3d_c1_fwd_kernel<32>, dim3(grid), dim3(256), 0, s, in, Wp, bias, out, sh, epilogue);
+    else SVR_CHECK(false, SVR_E_UNSUPPORTED, "conv3d: Ci=1 supports Co in {16,32}, got %d", Co);
+    return launch_status("conv3d_c1_fwd");
+  }
+  if (Co == 1) {
+    SVR_CHECK(epilogue == SVR_EPI_NONE, SVR_E_UNSUPPORTED, "conv3d: Co=1 supports no epilogue");
+    unsigned grid = (unsigned)cdiv(M, 256);
+    if (Ci == 16) hipLaunchKernelGGL(conv3d_to1_kernel<16>, dim3(grid), dim3(256), 0, s, in, Wp, out, sh);
+    else if (Ci == 32) hipLaunchKernelGGL(conv3d_to1_kernel<32>, dim3(grid), dim3(256), 0, s, in, Wp, out, sh);
+    else SVR_CHECK(false, SVR_E_UNSUPPORTED, "conv3d: Co=1 supports Ci in {16,32}, got %d", Ci);
+    return launch_status("conv3d_to1");
+  }
+  SVR_CHECK(Ci % 16 == 0 && Co % 4 == 0, SVR_E_UNSUPPORTED, "conv3d: need Ci %% 16 == 0 and Co %% 4 == 0 (Ci=%d Co=%d)", Ci, Co);
+  SVR_CHECK((((uintptr_t)in | (uintptr_t)Wp) & 15) == 0, SVR_E_ALIGN, "conv3d: operands must be 16-byte aligned");
+  if (Co <= 32) {
+    typedef TileCfg<4, 1, 1, 1> Cfg;
+    dim3 grid((unsigned)cdiv(M, Cfg::BM), (unsigned)cdiv(Co, Cfg::BN));
+    hipLaunchKernelGGL(conv3d_igemm_kernel<Cfg>, grid, dim3(256), 0, s, in, Wp, bias, out, mask, sh, epilogue);
+  } else if (Co <= 64) {
+    typedef TileCfg<4, 1, 1, 2> Cfg;
+    dim3 grid((unsigned)cdiv(M, Cfg::BM), (unsigned)cdiv(Co, Cfg::BN));
+    hipLaunchKernelGGL(conv3d_igemm_kernel<Cfg>, grid, dim3(256), 0, s, in, Wp, bias, out, mask, sh, epilogue);
+  } else {
+    typedef TileCfg<2, 2, 2, 2> Cfg;
+    dim3 grid((unsigned)cdiv(M, Cfg::BM), (unsigned)cdiv(Co, Cfg::BN));
+    hipLaunchKernelGGL(conv3d_igemm_kernel<Cfg>, grid, dim3(256), 0, s, in, Wp, bias, out, mask, sh, epilogue);
+  }
+  return launch_status("conv3d_igemm");
+}
+
+extern "C" int64_t svr_conv3d_k3_bwd_weight_workspace(int32_t B, int32_t D, int32_t H, int32_t W, int32_t Ci, int32_t Co) {
+  int64_t nrows = (int64_t)B * D * H;
+  int64_t chunks = cdiv(nrows, BW_ROWS);
+  int64_t M = nrows * W;
+  int64_t cs = colsum_workspace_floats(M, Co);
+  if (Ci == 1) return (chunks * 4 * 1024 + cs) * (int64_t)sizeof(float);
+  int64_t tiles = cdiv(Ci, 32) * cdiv(Co, 32);
+  return (chunks * 4 * 27 * tiles * 1024 + cs) * (int64_t)sizeof(float);
+}
+
+extern "C" int svr_conv3d_k3_bwd_weight(const float *in, const float *dout, float *dWp, float *db, int32_t B, int32_t D,
+                                        int32_t H, int32_t W, int32_t Ci, int32_t Co, void *workspace, void *stream) {
+  if (int rc = check_shape(B, D, H, W, Ci, Co)) return rc;
+  SVR_CHECK(in && dout && dWp && workspace, SVR_E_BADARG, "conv3d_bwd_weight: null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  ConvShape sh{B, D, H, W, Ci, Co};
+  const int64_t nrows = (int64_t)B * D * H;
+  const int chunks = (int)cdiv(nrows, BW_ROWS);
+  float *slab = (float *)workspace;
+  int64_t slab_floats;
+  if (Ci == 1) {
+    SVR_CHECK(Co <= 32, SVR_E_UNSUPPORTED, "conv3d_bwd_weight: Ci=1 needs Co<=32 (got %d)", Co);
+    hipLaunchKernelGGL(conv3d_c1_bwd_weight_kernel, dim3(chunks), dim3(256), 0, s, in, dout, slab, sh);
+    hipLaunchKernelGGL(conv3d_c1_bwd_weight_reduce_kernel, dim3(4), dim3(256), 0, s, slab, dWp, Co, chunks * 4);
+    slab_floats = (int64_t)chunks * 4 * 1024;
+  } else {
+    int cit = (int)cdiv(Ci, 32), cot = (int)cdiv(Co, 32);
+    dim3 grid(27, (unsigned)(cit * cot), (unsigned)chunks);
+    hipLaunchKernelGGL(conv3d_bwd_weight_kernel, grid, dim3(256), 0, s, in, dout, slab, sh, cit, cot);
+    int per = 27 * cit * cot * 1024;
+    hipLaunchKernelGGL(conv3d_bwd_weight_reduce_kernel, dim3(cdiv(per, 256)), dim3(256), 0, s, slab, dWp, Ci, Co, cit, cot, chunks * 4);
+    slab_floats = (int64_t)chunks * 4 * per;
+  }
+  if (db) colsum_launch(dout, Co, db, slab + slab_floats, nrows * W, Co, s);
+  return launch_status("conv3d_bwd_weight");
+}

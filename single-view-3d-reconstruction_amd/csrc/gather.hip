@@ -1,0 +1,307 @@
+// Trilinear multi-level feature gather / scatter for gfx950.
+//
+// Replaces, for the IF-Net extractor (reference model/ifnet.py:156-197, :93-118):
+//   coordinate prep (swap xyz->zyx, x2, 7 axis displacements), the per-level
+//   F.grid_sample(bilinear, zeros, align_corners False/True), torch.cat and the reshape.
+//
+// Build this file with -ffp-contract=off: the source-index arithmetic must round after
+// every operation exactly like ATen's grid_sampler_unnormalize
+// (torch/include/ATen/native/GridSampler.h:27-36), or floor() flips at cell boundaries and
+// the bit-exact corner-index gate fails.  Accumulation order of the 8 corners and the
+// (x*y)*z weight products follow grid_sampler_3d's CPU kernel so features match bit for bit.
+//
+// Layout: volumes channels-last (B,D,H,W,C); one corner = one contiguous C-vector, read as
+// float4 per lane; a point's 7*C outputs of one level are contiguous in its feature row.
+#include "common.h"
+
+namespace {
+
+struct LevelArgs {
+  const float *vol;
+  float *gvol;
+  int C, D, H, W, col;
+};
+
+struct Corner {
+  float ix, iy, iz;     // f32 source index
+  float x0f, y0f, z0f;  // floor()
+};
+
+__device__ __forceinline__ float unnormalize(float g, int S, int align_corners) {
+  if (align_corners) return ((g + 1.0f) / 2.0f) * (float)(S - 1);
+  return ((g + 1.0f) * (float)S - 1.0f) / 2.0f;
+}
+
+// j: 0 centre, 1/2 -+d on grid-x, 3/4 on grid-y, 5/6 on grid-z (model/ifnet.py:144-153).
+__device__ __forceinline__ Corner sample_corner(const float *__restrict__ pt, int j, float disp,
+                                                int D, int H, int W, int ac) {
+  float gx = 2.0f * pt[2], gy = 2.0f * pt[1], gz = 2.0f * pt[0];
+  float dj = (j & 1) ? -disp : disp;
+  if (j == 1 || j == 2) gx = gx + dj;
+  if (j == 3 || j == 4) gy = gy + dj;
+  if (j == 5 || j == 6) gz = gz + dj;
+  Corner c;
+  c.ix = unnormalize(gx, W, ac);
+  c.iy = unnormalize(gy, H, ac);
+  c.iz = unnormalize(gz, D, ac);
+  c.x0f = floorf(c.ix);
+  c.y0f = floorf(c.iy);
+  c.z0f = floorf(c.iz);
+  return c;
+}
+
+__device__ __forceinline__ int clamp_int(float f) {
+  f = fminf(fmaxf(f, -1.0e9f), 1.0e9f);
+  return (f != f) ? -1000000000 : (int)f;
+}
+
+// weights of corner (a,b,c): wx[a]*wy[b]*wz[c] with w[0] = (i0+1) - i, w[1] = i - i0.
+struct Weights {
+  float wx[2], wy[2], wz[2];
+  int x0, y0, z0;
+};
+
+__device__ __forceinline__ Weights corner_weights(const Corner &c) {
+  Weights w;
+  w.wx[0] = (c.x0f + 1.0f) - c.ix;
+  w.wx[1] = c.ix - c.x0f;
+  w.wy[0] = (c.y0f + 1.0f) - c.iy;
+  w.wy[1] = c.iy - c.y0f;
+  w.wz[0] = (c.z0f + 1.0f) - c.iz;
+  w.wz[1] = c.iz - c.z0f;
+  w.x0 = clamp_int(c.x0f);
+  w.y0 = clamp_int(c.y0f);
+  w.z0 = clamp_int(c.z0f);
+  return w;
+}
+
+template <int C>
+__global__ __launch_bounds__(256) void gather_fwd_kernel(LevelArgs L, const float *__restrict__ points,
+                                                         float *__restrict__ feat, int64_t total,
+                                                         int N, int row_stride, float disp, int ac) {
+  constexpr int V = (C >= 4) ? C / 4 : 1;
+  int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= total) return;
+  int q = (int)(gid % V);
+  int j = (int)((gid / V) % 7);
+  int64_t pn = gid / (7 * V);
+  int b = (int)(pn / N);
+  Corner c = sample_corner(points + pn * 3, j, disp, L.D, L.H, L.W, ac);
+  Weights w = corner_weights(c);
+  const float *vb = L.vol + (size_t)b * L.D * L.H * L.W * C;
+  if constexpr (C >= 4) {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int dz = 0; dz < 2; ++dz)
+#pragma unroll
+      for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 2; ++dx) {
+          int z = w.z0 + dz, y = w.y0 + dy, x = w.x0 + dx;
+          if (z >= 0 && z < L.D && y >= 0 && y < L.H && x >= 0 && x < L.W) {
+            float wt = (w.wx[dx] * w.wy[dy]) * w.wz[dz];
+            float4 v = *reinterpret_cast<const float4 *>(vb + (((size_t)z * L.H + y) * L.W + x) * C + q * 4);
+            acc.x = acc.x + v.x * wt;
+            acc.y = acc.y + v.y * wt;
+            acc.z = acc.z + v.z * wt;
+            acc.w = acc.w + v.w * wt;
+          }
+        }
+    *reinterpret_cast<float4 *>(feat + pn * row_stride + L.col + j * C + q * 4) = acc;
+  } else {
+    float acc = 0.f;
+#pragma unroll
+    for (int dz = 0; dz < 2; ++dz)
+#pragma unroll
+      for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 2; ++dx) {
+          int z = w.z0 + dz, y = w.y0 + dy, x = w.x0 + dx;
+          if (z >= 0 && z < L.D && y >= 0 && y < L.H && x >= 0 && x < L.W) {
+            float wt = (w.wx[dx] * w.wy[dy]) * w.wz[dz];
+            acc = acc + vb[(((size_t)z * L.H + y) * L.W + x) * C] * wt;
+          }
+        }
+    feat[pn * row_stride + L.col + j] = acc;
+  }
+}
+
+// Backward: scatter-add into gvol (f32 atomics) and, optionally, the gradient wrt the points.
+template <int C, bool GVOL, bool GPTS>
+__global__ __launch_bounds__(256) void gather_bwd_kernel(LevelArgs L, const float *__restrict__ points,
+                                                         const float *__restrict__ gfeat,
+                                                         float *__restrict__ gpoints, int64_t total,
+                                                         int N, int row_stride, float disp, int ac) {
+  constexpr int V = (C >= 4) ? C / 4 : 1;
+  int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  bool live = gid < total;
+  if (!live) gid = total - 1;  // keep the wave converged for the shuffles below
+  int q = (int)(gid % V);
+  int j = (int)((gid / V) % 7);
+  int64_t pn = gid / (7 * V);
+  int b = (int)(pn / N);
+  Corner c = sample_corner(points + pn * 3, j, disp, L.D, L.H, L.W, ac);
+  Weights w = corner_weights(c);
+  size_t vbase = (size_t)b * L.D * L.H * L.W * C;
+  float g[4] = {0.f, 0.f, 0.f, 0.f};
+  if constexpr (C >= 4) {
+    float4 t = *reinterpret_cast<const float4 *>(gfeat + pn * row_stride + L.col + j * C + q * 4);
+    g[0] = t.x; g[1] = t.y; g[2] = t.z; g[3] = t.w;
+  } else {
+    g[0] = gfeat[pn * row_stride + L.col + j];
+  }
+  float gix = 0.f, giy = 0.f, giz = 0.f;
+#pragma unroll
+  for (int dz = 0; dz < 2; ++dz)
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 2; ++dx) {
+        int z = w.z0 + dz, y = w.y0 + dy, x = w.x0 + dx;
+        if (z >= 0 && z < L.D && y >= 0 && y < L.H && x >= 0 && x < L.W) {
+          size_t off = vbase + (((size_t)z * L.H + y) * L.W + x) * C + (C >= 4 ? q * 4 : 0);
+          if constexpr (GVOL) {
+            if (live) {
+              float wt = (w.wx[dx] * w.wy[dy]) * w.wz[dz];
+#pragma unroll
+              for (int i = 0; i < (C >= 4 ? 4 : 1); ++i) atomicAdd(L.gvol + off + i, g[i] * wt);
+            }
+          }
+          if constexpr (GPTS) {
+            float dot = 0.f;
+#pragma unroll
+            for (int i = 0; i < (C >= 4 ? 4 : 1); ++i) dot += L.vol[off + i] * g[i];
+            float sx = dx ? 1.f : -1.f, sy = dy ? 1.f : -1.f, sz = dz ? 1.f : -1.f;
+            gix += sx * w.wy[dy] * w.wz[dz] * dot;
+            giy += sy * w.wx[dx] * w.wz[dz] * dot;
+            giz += sz * w.wx[dx] * w.wy[dy] * dot;
+          }
+        }
+      }
+  if constexpr (GPTS) {
+#pragma unroll
+    for (int s = 1; s < V; s <<= 1) {
+      gix += __shfl_xor(gix, s);
+      giy += __shfl_xor(giy, s);
+      giz += __shfl_xor(giz, s);
+    }
+    if (live && q == 0) {
+      float mx = ac ? (float)(L.W - 1) / 2.f : (float)L.W / 2.f;
+      float my = ac ? (float)(L.H - 1) / 2.f : (float)L.H / 2.f;
+      float mz = ac ? (float)(L.D - 1) / 2.f : (float)L.D / 2.f;
+      // grid x <- 2*pt[2], y <- 2*pt[1], z <- 2*pt[0]   (model/ifnet.py:157)
+      atomicAdd(gpoints + pn * 3 + 2, 2.f * mx * gix);
+      atomicAdd(gpoints + pn * 3 + 1, 2.f * my * giy);
+      atomicAdd(gpoints + pn * 3 + 0, 2.f * mz * giz);
+    }
+  }
+}
+
+__global__ void corner_index_kernel(const float *__restrict__ points, int32_t *__restrict__ out,
+                                    int64_t total, int N, int D, int H, int W, float disp, int ac) {
+  int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // over (b, j, n)
+  if (gid >= total) return;
+  int n = (int)(gid % N);
+  int j = (int)((gid / N) % 7);
+  int64_t b = gid / ((int64_t)7 * N);
+  Corner c = sample_corner(points + (b * N + n) * 3, j, disp, D, H, W, ac);
+  out[gid * 3 + 0] = clamp_int(c.z0f);
+  out[gid * 3 + 1] = clamp_int(c.y0f);
+  out[gid * 3 + 2] = clamp_int(c.x0f);
+}
+
+int check_desc(const svr_gather_desc *d, bool bwd) {
+  SVR_CHECK(d != nullptr, SVR_E_BADARG, "gather: null descriptor");
+  SVR_CHECK(d->n_levels >= 1 && d->n_levels <= SVR_MAX_LEVELS, SVR_E_BADARG, "gather: n_levels=%d", d->n_levels);
+  SVR_CHECK(d->B >= 0 && d->N >= 0, SVR_E_BADSHAPE, "gather: B=%d N=%d", d->B, d->N);
+  SVR_CHECK(d->row_stride % 4 == 0, SVR_E_ALIGN, "gather: row_stride %d not a multiple of 4", d->row_stride);
+  for (int l = 0; l < d->n_levels; ++l) {
+    const svr_level &L = d->level[l];
+    SVR_CHECK(L.vol != nullptr || (bwd && L.gvol == nullptr), SVR_E_BADARG, "gather: level %d has no volume", l);
+    SVR_CHECK(L.C == 1 || L.C == 16 || L.C == 32 || L.C == 64 || L.C == 128, SVR_E_UNSUPPORTED,
+              "gather: level %d: C=%d (supported: 1,16,32,64,128)", l, L.C);
+    SVR_CHECK(L.D > 0 && L.H > 0 && L.W > 0, SVR_E_BADSHAPE, "gather: level %d: empty volume", l);
+    SVR_CHECK(L.col >= 0 && L.col + 7 * L.C <= d->row_stride, SVR_E_BADSHAPE,
+              "gather: level %d: columns [%d,%d) exceed row stride %d", l, L.col, L.col + 7 * L.C, d->row_stride);
+    SVR_CHECK(L.C == 1 || L.col % 4 == 0, SVR_E_ALIGN, "gather: level %d: col %d not 16-byte aligned", l, L.col);
+    SVR_CHECK(((uintptr_t)L.vol & 15) == 0 && ((uintptr_t)L.gvol & 15) == 0, SVR_E_ALIGN,
+              "gather: level %d: volume pointer not 16-byte aligned", l);
+  }
+  return SVR_OK;
+}
+
+LevelArgs level_args(const svr_level &L) { return LevelArgs{L.vol, L.gvol, L.C, L.D, L.H, L.W, L.col}; }
+
+}  // namespace
+
+#define DISPATCH_C(Cval, ...)                         \
+  switch (Cval) {                                     \
+    case 1: { constexpr int CC = 1; __VA_ARGS__; } break;     \
+    case 16: { constexpr int CC = 16; __VA_ARGS__; } break;   \
+    case 32: { constexpr int CC = 32; __VA_ARGS__; } break;   \
+    case 64: { constexpr int CC = 64; __VA_ARGS__; } break;   \
+    case 128: { constexpr int CC = 128; __VA_ARGS__; } break; \
+  }
+
+extern "C" int svr_gather_trilinear_fwd(const svr_gather_desc *d, const float *points, float *features,
+                                        void *stream) {
+  if (int rc = check_desc(d, false)) return rc;
+  SVR_CHECK(points && features, SVR_E_BADARG, "gather_fwd: null points/features");
+  SVR_CHECK(((uintptr_t)features & 15) == 0, SVR_E_ALIGN, "gather_fwd: features not 16-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+  int64_t BN = (int64_t)d->B * d->N;
+  if (BN == 0) return SVR_OK;
+  for (int l = 0; l < d->n_levels; ++l) {
+    LevelArgs L = level_args(d->level[l]);
+    int V = L.C >= 4 ? L.C / 4 : 1;
+    int64_t total = BN * 7 * V;
+    unsigned grid = (unsigned)svr::cdiv(total, 256);
+    DISPATCH_C(L.C, hipLaunchKernelGGL(gather_fwd_kernel<CC>, dim3(grid), dim3(256), 0, s, L, points, features,
+                                       total, d->N, d->row_stride, d->displacement, d->align_corners));
+  }
+  return svr::launch_status("gather_fwd");
+}
+
+extern "C" int svr_gather_trilinear_bwd(const svr_gather_desc *d, const float *points, const float *gfeatures,
+                                        float *gpoints, void *stream) {
+  if (int rc = check_desc(d, true)) return rc;
+  SVR_CHECK(points && gfeatures, SVR_E_BADARG, "gather_bwd: null points/gfeatures");
+  hipStream_t s = (hipStream_t)stream;
+  int64_t BN = (int64_t)d->B * d->N;
+  if (BN == 0) return SVR_OK;
+  if (gpoints) {
+    hipError_t e = hipMemsetAsync(gpoints, 0, (size_t)BN * 3 * sizeof(float), s);
+    SVR_CHECK(e == hipSuccess, (int)e, "gather_bwd: memset failed: %s", hipGetErrorString(e));
+  }
+  for (int l = 0; l < d->n_levels; ++l) {
+    LevelArgs L = level_args(d->level[l]);
+    bool gv = L.gvol != nullptr;
+    if (!gv && !gpoints) continue;
+    SVR_CHECK(L.vol != nullptr || !gpoints, SVR_E_BADARG, "gather_bwd: level %d needs vol for the point gradient", l);
+    int V = L.C >= 4 ? L.C / 4 : 1;
+    int64_t total = BN * 7 * V;
+    unsigned grid = (unsigned)svr::cdiv(total, 256);
+#define LAUNCH_BWD(GV, GP)                                                                                   \
+  DISPATCH_C(L.C, hipLaunchKernelGGL((gather_bwd_kernel<CC, GV, GP>), dim3(grid), dim3(256), 0, s, L, points, \
+                                     gfeatures, gpoints, total, d->N, d->row_stride, d->displacement,        \
+                                     d->align_corners))
+    if (gv && gpoints) { LAUNCH_BWD(true, true); }
+    else if (gv) { LAUNCH_BWD(true, false); }
+    else { LAUNCH_BWD(false, true); }
+#undef LAUNCH_BWD
+  }
+  return svr::launch_status("gather_bwd");
+}
+
+extern "C" int svr_gather_corner_indices(const svr_gather_desc *d, int32_t level, const float *points,
+                                         int32_t *out, void *stream) {
+  if (int rc = check_desc(d, false)) return rc;
+  SVR_CHECK(level >= 0 && level < d->n_levels, SVR_E_BADARG, "corner_indices: level %d", level);
+  SVR_CHECK(points && out, SVR_E_BADARG, "corner_indices: null pointer");
+  const svr_level &L = d->level[level];
+  int64_t total = (int64_t)d->B * 7 * d->N;
+  if (total == 0) return SVR_OK;
+  hipLaunchKernelGGL(corner_index_kernel, dim3((unsigned)svr::cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                     points, out, total, d->N, L.D, L.H, L.W, d->displacement, d->align_corners);
+  return svr::launch_status("corner_indices");
+}

@@ -1,0 +1,1 @@
+from .ifnet import IFNet, IFNetFeatureExtractor, IFNetFeatureExtractor128, evaluate_network_on_grid, make_3d_grid  # noqa: F401

@@ -1,0 +1,283 @@
+"""IF-Net on MI355X: host-side mirror of the reference's model/ifnet.py.
+
+Same public surface as the reference (model/ifnet.py:10-61,64-199,202-229): ``IFNet(hidden_dim)``
+with ``forward(x (B,1,D,H,W), points (B,N,3)) -> logits (B,N)``, submodule / parameter names of
+SURVEY.md App. A.1 (so Lightning checkpoints `ifnet.*` load), feature extractors
+``IFNetFeatureExtractor128`` / ``IFNetFeatureExtractor`` and the inference helpers
+``make_3d_grid`` / ``evaluate_network_on_grid``.  The one deliberate difference: the architecture
+is a constructor argument (``net_res=128``) instead of a value parsed from sys.argv at import
+(model/ifnet.py:8).
+
+Every arithmetic step runs in the HIP kernels of libsvr_hip.so (include/svr_hip.h).  The
+nn.Conv3d / nn.BatchNorm3d / nn.Conv1d submodules only HOLD the parameters and buffers; their
+torch forward is never called.  There is no CPU fallback.
+"""
+import torch
+import torch.nn as nn
+
+from .. import ops
+
+_ARCH = {
+    # stages: ((conv attr names), bn attr name); channels per stage; gather displacement; align_corners
+    128: dict(stages=[(("conv_in",), "conv_in_bn"), (("conv_0", "conv_0_1"), "conv0_1_bn"),
+                      (("conv_1", "conv_1_1"), "conv1_1_bn"), (("conv_2", "conv_2_1"), "conv2_1_bn"),
+                      (("conv_3", "conv_3_1"), "conv3_1_bn")],
+              disp=0.0722, align_corners=False),
+    32: dict(stages=[(("conv_1", "conv_1_1"), "conv1_1_bn"), (("conv_2", "conv_2_1"), "conv2_1_bn"),
+                     (("conv_3", "conv_3_1"), "conv3_1_bn")],
+             disp=0.035, align_corners=True),
+}
+
+
+def _displacements(d):
+    rows = [[0.0, 0.0, 0.0]]
+    for axis in range(3):
+        for sign in (-1, 1):
+            r = [0.0, 0.0, 0.0]
+            r[axis] = sign * d
+            rows.append(r)
+    return torch.tensor(rows)
+
+
+class _EncoderGatherFn(torch.autograd.Function):
+    """x, points, encoder parameters -> feature rows (B*N, FS) in the internal column layout.
+
+    forward  = reference model/ifnet.py:155-198 (conv/ReLU/BN/pool pyramid + 6 grid_samples + cat)
+    backward = autograd of the same, hand-scheduled (gather scatter -> BN -> ReLU -> conv per stage).
+    """
+
+    @staticmethod
+    def forward(ctx, ext, x, points, *params):
+        B = x.shape[0]
+        D, H, W = x.shape[2:]
+        training = ext.training
+        x_cl = x.contiguous().view(B, D, H, W, 1)
+        pts = points.contiguous()
+        levels = [x_cl]
+        saved = []
+        inp = x_cl
+        nst = len(ext._stages)
+        for si, (convs, bn) in enumerate(ext._stages):
+            acts, packed = [], []
+            cur = inp
+            for conv in convs:
+                wf, wb = ops.conv3d_pack_weight(conv.weight.detach(), want_bwd=True)
+                cur = ops.conv3d_k3(cur, wf, conv.bias.detach(), relu=True)
+                acts.append(cur)
+                packed.append(wb)
+            y, pooled, argmax, ss, mean = ops.bn_forward(
+                cur, bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var, training,
+                eps=bn.eps, momentum=bn.momentum, want_pool=(si + 1 < nst))
+            if training:
+                bn.num_batches_tracked += 1
+            levels.append(y)
+            saved.append((inp, acts, packed, argmax, ss, mean))
+            inp = pooled
+        feat = ops.gather_fwd(levels, pts, ext._layout, ext._disp, ext._align)
+        ctx.ext, ctx.saved, ctx.levels, ctx.pts = ext, saved, levels, pts
+        ctx.x_shape = x.shape
+        ctx.training = training
+        return feat
+
+    @staticmethod
+    def backward(ctx, gfeat):
+        ext, saved, levels, pts = ctx.ext, ctx.saved, ctx.levels, ctx.pts
+        if not ctx.training:
+            raise RuntimeError("IF-Net HIP path: backward through eval-mode BatchNorm is not implemented")
+        need_x, need_pts = ctx.needs_input_grad[1], ctx.needs_input_grad[2]
+        gfeat = gfeat.contiguous()
+        gvols = [torch.zeros_like(levels[0]) if need_x else None] + [torch.zeros_like(v) for v in levels[1:]]
+        gpts = ops.gather_bwd(levels, gvols, pts, gfeat, ext._layout, ext._disp, ext._align, want_gpoints=need_pts)
+        grads = {}
+        dpooled = None
+        gx = None
+        for si in range(len(ext._stages) - 1, -1, -1):
+            convs, bn = ext._stages[si]
+            inp, acts, packed, argmax, ss, mean = saved[si]
+            dout, dgamma, dbeta = ops.bn_backward(acts[-1], gvols[si + 1], dpooled, argmax if dpooled is not None else None,
+                                                  mean, ss, relu_mask=True)
+            grads[bn.weight], grads[bn.bias] = dgamma, dbeta
+            for k in range(len(convs) - 1, -1, -1):
+                conv = convs[k]
+                cin = acts[k - 1] if k > 0 else inp
+                Co, Ci = conv.weight.shape[0], conv.weight.shape[1]
+                dwp, db = ops.conv3d_k3_bwd_weight(cin, dout)
+                grads[conv.weight] = ops.conv3d_unpack_wgrad(dwp, Ci, Co)
+                grads[conv.bias] = db
+                if k > 0:
+                    dout = ops.conv3d_k3(dout, packed[k], mask=acts[k - 1])
+                elif si > 0:
+                    dpooled = ops.conv3d_k3(dout, packed[k])
+                elif need_x:
+                    gx = ops.conv3d_k3(dout, packed[k])
+        if need_x:
+            gx = (gx + gvols[0]).view(ctx.x_shape)
+        out = [None, gx, gpts]
+        for p in ext._param_list:
+            out.append(grads.get(p))
+        return tuple(out)
+
+
+class _PointMLPFn(torch.autograd.Function):
+    """feature rows (B*N, FS) -> logits (B*N): fc_0, fc_1, fc_2 with ReLU, fc_out
+    (reference model/ifnet.py:55-59) on the f32 matrix cores."""
+
+    @staticmethod
+    def forward(ctx, feat, w0p, b0, w1, b1, w2, b2, wo, bo):
+        h0 = ops.linear_fwd(feat, w0p, b0, relu=True)
+        h1 = ops.linear_fwd(h0, w1, b1, relu=True)
+        h2 = ops.linear_fwd(h1, w2, b2, relu=True)
+        logits = ops.fc_out_fwd(h2, wo, bo)
+        ctx.save_for_backward(feat, w0p, w1, w2, wo, h0, h1, h2)
+        return logits
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        feat, w0p, w1, w2, wo, h0, h1, h2 = ctx.saved_tensors
+        dh2, dwo, dbo = ops.fc_out_bwd(h2, wo, dlogits.contiguous())          # dh2 already masked by h2 > 0
+        dw2, db2 = ops.linear_bwd_weight(dh2, h1)
+        dh1 = ops.linear_bwd_data(dh2, w2, mask=h1)
+        dw1, db1 = ops.linear_bwd_weight(dh1, h0)
+        dh0 = ops.linear_bwd_data(dh1, w1, mask=h0)
+        dw0, db0 = ops.linear_bwd_weight(dh0, feat)
+        dfeat = ops.linear_bwd_data(dh0, w0p) if ctx.needs_input_grad[0] else None
+        return dfeat, dw0, db0, dw1, db1, dw2, db2, dwo, dbo
+
+
+class _ExtractorBase(nn.Module):
+    """Shared host logic of the two extractor variants."""
+
+    def _finish_init(self, net_res):
+        a = _ARCH[net_res]
+        self._stages = [([getattr(self, c) for c in convs], getattr(self, bn)) for convs, bn in a["stages"]]
+        self._disp = float(torch.tensor(a["disp"], dtype=torch.float32))
+        self._align = a["align_corners"]
+        self.displacments = _displacements(a["disp"])            # plain attribute, like the reference
+        chans = [1] + [convs[-1].out_channels for convs, _ in self._stages]
+        self._layout = ops.FeatureLayout(chans)
+        self._param_list = []
+        for convs, bn in self._stages:
+            for c in convs:
+                self._param_list += [c.weight, c.bias]
+            self._param_list += [bn.weight, bn.bias]
+
+    def feature_rows(self, x, points):
+        """(B*N, FS) rows in the internal column layout (what the point MLP consumes)."""
+        if not x.is_cuda:
+            raise RuntimeError("IF-Net HIP path needs GPU tensors (no CPU fallback)")
+        return _EncoderGatherFn.apply(self, x.float(), points.float(), *self._param_list)
+
+    def forward(self, x, points):
+        """Reference layout (B, sumC, 1, 7, N) -- model/ifnet.py:197; used by API-compat callers."""
+        B, N = points.shape[0], points.shape[1]
+        rows = self.feature_rows(x, points)
+        perm = self._layout.reference_permutation().to(rows.device)
+        inv = torch.empty(self._layout.width, dtype=torch.long, device=rows.device)
+        valid = perm >= 0
+        inv[perm[valid]] = torch.nonzero(valid).squeeze(1)
+        f = rows[:, inv].view(B, N, -1, 7).permute(0, 2, 3, 1)
+        return f.unsqueeze(2)
+
+
+class IFNetFeatureExtractor128(_ExtractorBase):
+    def __init__(self):
+        super().__init__()
+        self.conv_in = nn.Conv3d(1, 16, 3, padding=1)
+        self.conv_0 = nn.Conv3d(16, 32, 3, padding=1)
+        self.conv_0_1 = nn.Conv3d(32, 32, 3, padding=1)
+        self.conv_1 = nn.Conv3d(32, 64, 3, padding=1)
+        self.conv_1_1 = nn.Conv3d(64, 64, 3, padding=1)
+        self.conv_2 = nn.Conv3d(64, 128, 3, padding=1)
+        self.conv_2_1 = nn.Conv3d(128, 128, 3, padding=1)
+        self.conv_3 = nn.Conv3d(128, 128, 3, padding=1)
+        self.conv_3_1 = nn.Conv3d(128, 128, 3, padding=1)
+        self.actvn = nn.ReLU()
+        self.maxpool = nn.MaxPool3d(2)
+        self.conv_in_bn = nn.BatchNorm3d(16)
+        self.conv0_1_bn = nn.BatchNorm3d(32)
+        self.conv1_1_bn = nn.BatchNorm3d(64)
+        self.conv2_1_bn = nn.BatchNorm3d(128)
+        self.conv3_1_bn = nn.BatchNorm3d(128)
+        self._finish_init(128)
+
+
+class IFNetFeatureExtractor(_ExtractorBase):
+    def __init__(self, f1, f2, f3, f4):
+        super().__init__()
+        self.conv_1 = nn.Conv3d(1, f1, 3, padding=1)
+        self.conv_1_1 = nn.Conv3d(f1, f2, 3, padding=1)
+        self.conv_2 = nn.Conv3d(f2, f3, 3, padding=1)
+        self.conv_2_1 = nn.Conv3d(f3, f4, 3, padding=1)
+        self.conv_3 = nn.Conv3d(f4, f4, 3, padding=1)
+        self.conv_3_1 = nn.Conv3d(f4, f4, 3, padding=1)
+        self.actvn = nn.ReLU()
+        self.maxpool = nn.MaxPool3d(2)
+        self.conv1_1_bn = nn.BatchNorm3d(f2)
+        self.conv2_1_bn = nn.BatchNorm3d(f4)
+        self.conv3_1_bn = nn.BatchNorm3d(f4)
+        self._finish_init(32)
+
+
+class IFNet(nn.Module):
+    def __init__(self, hidden_dim=256, net_res=128):
+        super().__init__()
+        self.net_res = net_res
+        if net_res == 128:
+            self.ifnet_feature_extractor = IFNetFeatureExtractor128()
+            feature_size = (1 + 16 + 32 + 64 + 128 + 128) * 7
+            self.fc_0 = nn.Conv1d(feature_size, hidden_dim, 1)
+            self.fc_1 = nn.Conv1d(hidden_dim, hidden_dim, 1)
+            self.fc_2 = nn.Conv1d(hidden_dim, hidden_dim, 1)
+        elif net_res == 32:
+            self.ifnet_feature_extractor = IFNetFeatureExtractor(32, 64, 128, 128)
+            feature_size = (1 + 64 + 128 + 128) * 7
+            self.fc_0 = nn.Conv1d(feature_size, hidden_dim * 2, 1)
+            self.fc_1 = nn.Conv1d(hidden_dim * 2, hidden_dim, 1)
+            self.fc_2 = nn.Conv1d(hidden_dim, hidden_dim, 1)
+        else:
+            # the reference *returns* NotImplementedError here (model/ifnet.py:31-32); raise instead
+            raise NotImplementedError(f"net_res={net_res}")
+        self.fc_out = nn.Conv1d(hidden_dim, 1, 1)
+        self.actvn = nn.ReLU()
+        self.register_buffer("_fc0_perm", self.ifnet_feature_extractor._layout.reference_permutation(), persistent=False)
+
+    def _fc0_internal(self):
+        """fc_0.weight (H, F, 1) with reference column order k = c*7+j -> (H, FS) in the internal
+        column order (zero weight on padding columns).  The checkpoint layout never changes."""
+        w = self.fc_0.weight.squeeze(2)
+        perm = self._fc0_perm
+        wz = torch.cat([w, w.new_zeros(w.shape[0], 1)], dim=1)
+        return wz[:, torch.where(perm >= 0, perm, torch.full_like(perm, w.shape[1]))].contiguous()
+
+    def forward(self, x, points):
+        B, N = points.shape[0], points.shape[1]
+        rows = self.ifnet_feature_extractor.feature_rows(x, points)
+        logits = _PointMLPFn.apply(rows, self._fc0_internal(), self.fc_0.bias,
+                                   self.fc_1.weight.squeeze(2), self.fc_1.bias,
+                                   self.fc_2.weight.squeeze(2), self.fc_2.bias,
+                                   self.fc_out.weight.reshape(-1), self.fc_out.bias)
+        return logits.view(B, N)
+
+
+def make_3d_grid(bb_min, bb_max, shape, res_increase=1):
+    """Lattice of query points, C-order with the last axis fastest (model/ifnet.py:202-212)."""
+    shape = [int(s) for s in shape]
+    size = shape[0] * shape[1] * shape[2] * res_increase ** 3
+    full = [s * res_increase for s in shape]
+    pxs = torch.linspace(bb_min[0], bb_max[0], full[0]).view(-1, 1, 1).expand(*full).contiguous().view(size)
+    pys = torch.linspace(bb_min[1], bb_max[1], full[1]).view(1, -1, 1).expand(*full).contiguous().view(size)
+    pzs = torch.linspace(bb_min[2], bb_max[2], full[2]).view(1, 1, -1).expand(*full).contiguous().view(size)
+    return torch.stack([pxs, pys, pzs], dim=1)
+
+
+def evaluate_network_on_grid(network, x, resolution, res_increase=1, points_batch_size=2048 * 16):
+    """Occupancy probabilities on the dense lattice (model/ifnet.py:215-229).  Results stay on the
+    device until the end (one D2H copy instead of one per chunk)."""
+    pointsf = make_3d_grid((-0.5,) * 3, (0.5,) * 3, resolution, res_increase).to(x.device)
+    values = []
+    with torch.no_grad():
+        for pi in torch.split(pointsf, points_batch_size):
+            values.append(torch.sigmoid(network(x, pi.unsqueeze(0))).squeeze(0))
+    value = torch.cat(values, dim=0).cpu().numpy()
+    r = [int(s) * res_increase for s in resolution]
+    return value.reshape(r[0], r[1], r[2])

@@ -1,0 +1,277 @@
+"""Thin tensor-level wrappers over the C ABI: check device/dtype/contiguity, pass raw device
+pointers and the current HIP stream.  torch is used for memory and streams only."""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import EPI_BIAS, EPI_BIAS_RELU, EPI_MASK, EPI_NONE, GatherDesc, check  # noqa: F401
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    if t is None:
+        return C.c_void_p(0)
+    if not t.is_cuda:
+        raise RuntimeError("svr_amd ops need GPU tensors (the HIP path has no CPU fallback)")
+    if not t.is_contiguous():
+        raise RuntimeError("svr_amd ops need contiguous tensors")
+    return C.c_void_p(t.data_ptr())
+
+
+def _f32(*ts):
+    for t in ts:
+        if t is not None and t.dtype != torch.float32:
+            raise RuntimeError(f"expected float32, got {t.dtype}")
+
+
+# ------------------------------------------------------------------------------------------
+# feature-row layout
+# ------------------------------------------------------------------------------------------
+class FeatureLayout:
+    """Column layout of a feature row: levels with C>=4 first (each 7*C wide, sample-major,
+    channel contiguous, 16-float aligned), the C==1 level last; row stride padded to 32."""
+
+    def __init__(self, channels):
+        self.channels = list(channels)
+        order = [l for l, c in enumerate(self.channels) if c >= 4] + [l for l, c in enumerate(self.channels) if c < 4]
+        self.col = [0] * len(self.channels)
+        off = 0
+        for l in order:
+            self.col[l] = off
+            off += 7 * self.channels[l]
+        self.width = off
+        self.row_stride = (off + 31) // 32 * 32
+
+    def reference_permutation(self):
+        """perm[k_internal] = reference feature row k = c_global*7 + j (model/ifnet.py:43-45,197);
+        -1 for padding columns."""
+        perm = torch.full((self.row_stride,), -1, dtype=torch.long)
+        cbase = 0
+        for l, c in enumerate(self.channels):
+            j = torch.arange(7).view(7, 1)
+            ch = torch.arange(c).view(1, c)
+            perm[self.col[l]: self.col[l] + 7 * c] = ((cbase + ch) * 7 + j).reshape(-1)
+            cbase += c
+        return perm
+
+
+def make_gather_desc(vols, gvols, layout, B, N, displacement, align_corners):
+    d = GatherDesc()
+    d.n_levels = len(vols)
+    d.B, d.N = B, N
+    d.row_stride = layout.row_stride
+    d.align_corners = int(align_corners)
+    d.displacement = displacement
+    for l, v in enumerate(vols):
+        g = gvols[l] if gvols is not None else None
+        ref = v if v is not None else g
+        _f32(v, g)
+        if ref.dim() != 5 or ref.shape[0] != B or ref.shape[4] != layout.channels[l]:
+            raise RuntimeError(f"level {l}: expected (B,D,H,W,{layout.channels[l]}) channels-last, got {tuple(ref.shape)}")
+        L = d.level[l]
+        L.vol, L.gvol = _p(v), _p(g)
+        L.C, L.D, L.H, L.W = ref.shape[4], ref.shape[1], ref.shape[2], ref.shape[3]
+        L.col = layout.col[l]
+    return d
+
+
+def gather_fwd(vols, points, layout, displacement, align_corners, out=None):
+    B, N, _ = points.shape
+    _f32(points)
+    d = make_gather_desc(vols, None, layout, B, N, displacement, align_corners)
+    if out is None:
+        out = torch.zeros(B * N, layout.row_stride, device=points.device, dtype=torch.float32)
+    check(_lib.lib().svr_gather_trilinear_fwd(C.byref(d), _p(points), _p(out), _stream()), "gather_fwd")
+    return out
+
+
+def gather_bwd(vols, gvols, points, gfeat, layout, displacement, align_corners, want_gpoints=False):
+    B, N, _ = points.shape
+    d = make_gather_desc(vols, gvols, layout, B, N, displacement, align_corners)
+    gp = torch.empty_like(points) if want_gpoints else None
+    check(_lib.lib().svr_gather_trilinear_bwd(C.byref(d), _p(points), _p(gfeat), _p(gp), _stream()), "gather_bwd")
+    return gp
+
+
+def corner_indices(vols, points, layout, level, displacement, align_corners):
+    B, N, _ = points.shape
+    d = make_gather_desc(vols, None, layout, B, N, displacement, align_corners)
+    out = torch.empty(B, 7, N, 3, device=points.device, dtype=torch.int32)
+    check(_lib.lib().svr_gather_corner_indices(C.byref(d), level, _p(points), _p(out), _stream()), "corner_indices")
+    return out
+
+
+# ------------------------------------------------------------------------------------------
+# point MLP
+# ------------------------------------------------------------------------------------------
+def linear_fwd(x, w, bias, relu=True, out=None):
+    """y = [relu](x @ w.T + bias); x (M,K) row stride may exceed K (padded feature rows)."""
+    _f32(x, w, bias)
+    M, K = x.shape
+    N = w.shape[0]
+    assert w.shape[1] == K and x.stride(1) == 1 and w.stride(1) == 1
+    if out is None:
+        out = torch.empty(M, N, device=x.device, dtype=torch.float32)
+    epi = EPI_NONE if bias is None else (EPI_BIAS_RELU if relu else EPI_BIAS)
+    check(_lib.lib().svr_linear_fwd(C.c_void_p(x.data_ptr()), x.stride(0), C.c_void_p(w.data_ptr()), w.stride(0),
+                                    _p(bias), _p(out), out.stride(0), M, N, K, epi, C.c_void_p(0), 0, _stream()),
+          "linear_fwd")
+    return out
+
+
+def linear_bwd_data(dy, w, mask=None, out=None):
+    """dx = (dy @ w) [* (mask > 0)]; dy (M,N), w (N,K)."""
+    _f32(dy, w, mask)
+    M, N = dy.shape
+    K = w.shape[1]
+    if out is None:
+        out = torch.empty(M, K, device=dy.device, dtype=torch.float32)
+    epi = EPI_MASK if mask is not None else EPI_NONE
+    check(_lib.lib().svr_linear_bwd_data(C.c_void_p(dy.data_ptr()), dy.stride(0), C.c_void_p(w.data_ptr()), w.stride(0),
+                                         C.c_void_p(out.data_ptr()), out.stride(0), M, N, K, epi,
+                                         C.c_void_p(mask.data_ptr()) if mask is not None else C.c_void_p(0),
+                                         mask.stride(0) if mask is not None else 0, _stream()), "linear_bwd_data")
+    return out
+
+
+def linear_bwd_weight(dy, x, want_bias=True):
+    """dW (N,K) = dy.T @ x, db (N) = dy.sum(0)."""
+    _f32(dy, x)
+    M, N = dy.shape
+    K = x.shape[1]
+    l = _lib.lib()
+    ws = torch.empty(l.svr_linear_bwd_weight_workspace(M, N, K), device=dy.device, dtype=torch.uint8)
+    dw = torch.empty(N, K, device=dy.device, dtype=torch.float32)
+    db = torch.empty(N, device=dy.device, dtype=torch.float32) if want_bias else None
+    check(l.svr_linear_bwd_weight(C.c_void_p(dy.data_ptr()), dy.stride(0), C.c_void_p(x.data_ptr()), x.stride(0),
+                                  _p(dw), dw.stride(0), _p(db), M, N, K, _p(ws), _stream()), "linear_bwd_weight")
+    return dw, db
+
+
+def fc_out_fwd(h, w, b):
+    _f32(h, w, b)
+    M, K = h.shape
+    out = torch.empty(M, device=h.device, dtype=torch.float32)
+    check(_lib.lib().svr_fc_out_fwd(_p(h), h.stride(0), _p(w), _p(b), _p(out), M, K, _stream()), "fc_out_fwd")
+    return out
+
+
+def fc_out_bwd(h, w, dlogits):
+    _f32(h, w, dlogits)
+    M, K = h.shape
+    l = _lib.lib()
+    ws = torch.empty(l.svr_fc_out_bwd_workspace(M, K), device=h.device, dtype=torch.uint8)
+    dh = torch.empty(M, K, device=h.device, dtype=torch.float32)
+    dw = torch.empty(K, device=h.device, dtype=torch.float32)
+    db = torch.empty(1, device=h.device, dtype=torch.float32)
+    check(l.svr_fc_out_bwd(_p(h), h.stride(0), _p(w), _p(dlogits), _p(dh), dh.stride(0), _p(dw), _p(db), M, K, _p(ws),
+                           _stream()), "fc_out_bwd")
+    return dh, dw, db
+
+
+def bce_logits_sum_mean(logits, targets, want_grad=True, gscale=1.0):
+    _f32(logits, targets)
+    B, N = logits.shape
+    loss = torch.empty(1, device=logits.device, dtype=torch.float32)
+    dz = torch.empty_like(logits) if want_grad else None
+    ws = torch.empty(B, device=logits.device, dtype=torch.float64)
+    check(_lib.lib().svr_bce_logits_sum_mean(_p(logits), _p(targets), _p(loss), _p(dz), B, N, gscale, _p(ws), _stream()),
+          "bce")
+    return loss, dz
+
+
+# ------------------------------------------------------------------------------------------
+# encoder: conv3d / batch-norm / max-pool (channels-last volumes (B,D,H,W,C))
+# ------------------------------------------------------------------------------------------
+def conv3d_pack_weight(w, want_bwd=True):
+    """(Co,Ci,3,3,3) -> Wp_fwd [27][Ci][Co], Wp_bwd [27][Co][Ci] (taps flipped)."""
+    _f32(w)
+    Co, Ci = w.shape[0], w.shape[1]
+    wf = torch.empty(27, Ci, Co, device=w.device, dtype=torch.float32)
+    wb = torch.empty(27, Co, Ci, device=w.device, dtype=torch.float32) if want_bwd else None
+    check(_lib.lib().svr_conv3d_pack_weight(_p(w), _p(wf), _p(wb), Ci, Co, _stream()), "conv3d_pack_weight")
+    return wf, wb
+
+
+def conv3d_unpack_wgrad(dwp, Ci, Co):
+    dw = torch.empty(Co, Ci, 3, 3, 3, device=dwp.device, dtype=torch.float32)
+    check(_lib.lib().svr_conv3d_unpack_wgrad(_p(dwp), _p(dw), Ci, Co, _stream()), "conv3d_unpack_wgrad")
+    return dw
+
+
+def conv3d_k3(x, wp, bias=None, relu=False, mask=None):
+    """x (B,D,H,W,Ci), wp [27][Ci][Co] -> (B,D,H,W,Co); epilogue: bias[+relu] or mask or none."""
+    _f32(x, wp, bias, mask)
+    B, D, H, W, Ci = x.shape
+    Co = wp.shape[2]
+    assert wp.shape[1] == Ci
+    out = torch.empty(B, D, H, W, Co, device=x.device, dtype=torch.float32)
+    if mask is not None:
+        epi = EPI_MASK
+    elif bias is not None:
+        epi = EPI_BIAS_RELU if relu else EPI_BIAS
+    else:
+        epi = EPI_NONE
+    check(_lib.lib().svr_conv3d_k3(_p(x), _p(wp), _p(bias), _p(out), B, D, H, W, Ci, Co, epi, _p(mask), _stream()), "conv3d_k3")
+    return out
+
+
+def conv3d_k3_bwd_weight(x, dout, want_bias=True):
+    """dWp [27][Ci][Co], db (Co)."""
+    _f32(x, dout)
+    B, D, H, W, Ci = x.shape
+    Co = dout.shape[4]
+    l = _lib.lib()
+    ws = torch.empty(l.svr_conv3d_k3_bwd_weight_workspace(B, D, H, W, Ci, Co), device=x.device, dtype=torch.uint8)
+    dwp = torch.empty(27, Ci, Co, device=x.device, dtype=torch.float32)
+    db = torch.empty(Co, device=x.device, dtype=torch.float32) if want_bias else None
+    check(l.svr_conv3d_k3_bwd_weight(_p(x), _p(dout), _p(dwp), _p(db), B, D, H, W, Ci, Co, _p(ws), _stream()),
+          "conv3d_k3_bwd_weight")
+    return dwp, db
+
+
+def bn_forward(x, gamma, beta, running_mean, running_var, training, eps=1e-5, momentum=0.1, want_pool=True):
+    """x (B,D,H,W,C) -> y, pooled, argmax, scale_shift(3C), mean(C)."""
+    _f32(x, gamma, beta, running_mean, running_var)
+    B, D, H, W, Cc = x.shape
+    rows = B * D * H * W
+    l = _lib.lib()
+    dev = x.device
+    stats = None
+    if training:
+        stats = torch.empty(2 * Cc, device=dev, dtype=torch.float64)
+        ws = torch.empty(l.svr_bn_stats_workspace(rows, Cc), device=dev, dtype=torch.uint8)
+        check(l.svr_bn_stats(_p(x), _p(stats), rows, Cc, _p(ws), _stream()), "bn_stats")
+    ss = torch.empty(3 * Cc, device=dev, dtype=torch.float32)
+    mean = torch.empty(Cc, device=dev, dtype=torch.float32)
+    check(l.svr_bn_finalize(_p(stats), _p(gamma), _p(beta), _p(running_mean), _p(running_var), _p(ss), _p(mean), rows, Cc,
+                            eps, momentum, int(training), _stream()), "bn_finalize")
+    y = torch.empty_like(x)
+    pooled = argmax = None
+    if want_pool:
+        pooled = torch.empty(B, D // 2, H // 2, W // 2, Cc, device=dev, dtype=torch.float32)
+        argmax = torch.empty(B, D // 2, H // 2, W // 2, Cc, device=dev, dtype=torch.uint8)
+    check(l.svr_bn_apply_pool(_p(x), _p(ss), _p(y), _p(pooled), _p(argmax), B, D, H, W, Cc, _stream()), "bn_apply_pool")
+    return y, pooled, argmax, ss, mean
+
+
+def bn_backward(x, dy, dpooled, argmax, mean, ss, relu_mask=True):
+    """-> dx (grad wrt the conv pre-activation when relu_mask), dgamma, dbeta."""
+    _f32(x, dy, dpooled, mean, ss)
+    B, D, H, W, Cc = x.shape
+    l = _lib.lib()
+    dev = x.device
+    sums = torch.empty(2 * Cc, device=dev, dtype=torch.float64)
+    ws = torch.empty(l.svr_bn_stats_workspace(B * D * H * W, Cc), device=dev, dtype=torch.uint8)
+    check(l.svr_bn_bwd_reduce(_p(x), _p(dy), _p(dpooled), _p(argmax), _p(mean), _p(ss), _p(sums), B, D, H, W, Cc, _p(ws),
+                              _stream()), "bn_bwd_reduce")
+    dx = torch.empty_like(x)
+    dgamma = torch.empty(Cc, device=dev, dtype=torch.float32)
+    dbeta = torch.empty(Cc, device=dev, dtype=torch.float32)
+    check(l.svr_bn_bwd_apply(_p(x), _p(dy), _p(dpooled), _p(argmax), _p(mean), _p(ss), C.c_void_p(0), _p(sums), _p(dx),
+                             _p(dgamma), _p(dbeta), B, D, H, W, Cc, int(relu_mask), _stream()), "bn_bwd_apply")
+    return dx, dgamma, dbeta

@@ -1,0 +1,214 @@
+"""GPU parity of the individual HIP kernels (through the C ABI) against the CPU oracle /
+stock torch CPU ops on the same seeded inputs.  Integer work is bit-exact, floating point
+within the tolerance written in each test."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import ifnet_oracle as O
+from tests import _golden as G
+
+pytestmark = pytest.mark.gpu
+
+
+def _ops():
+    import svr_amd  # noqa: F401
+    from svr_amd import ops
+    return ops
+
+
+def _cl(v):  # NCDHW -> channels-last (B,D,H,W,C) on the GPU
+    return v.permute(0, 2, 3, 4, 1).contiguous().cuda()
+
+
+def _ncdhw(v):  # channels-last GPU -> NCDHW CPU
+    return v.cpu().permute(0, 4, 1, 2, 3).contiguous()
+
+
+def _rand_levels(B, dims, chans, seed):
+    g = torch.Generator().manual_seed(seed)
+    vols = []
+    d = list(dims)
+    for i, c in enumerate(chans):
+        vols.append(torch.randn(B, c, *d, generator=g))
+        if i >= 1:
+            d = [max(1, s // 2) for s in d]
+    return vols
+
+
+@pytest.mark.parametrize("B,dims,N,spread", [(2, (16, 16, 16), 777, 1.0), (1, (35, 26, 28), 500, 1.3), (3, (32, 32, 32), 1, 1.0)])
+def test_gather_fwd_indices_and_features(B, dims, N, spread):
+    ops = _ops()
+    chans = [1, 16, 32, 64, 128, 128]
+    vols = _rand_levels(B, dims, chans, 5)
+    g = torch.Generator().manual_seed(6)
+    pts = (torch.rand(B, N, 3, generator=g) - 0.5) * spread
+    layout = ops.FeatureLayout(chans)
+    vols_g = [_cl(v) for v in vols]
+    rows = ops.gather_fwd(vols_g, pts.cuda(), layout, float(np.float32(0.0722)), False)
+    # bit-exact corner indices on every level
+    for l, v in enumerate(vols):
+        idx = ops.corner_indices(vols_g, pts.cuda(), layout, l, float(np.float32(0.0722)), False).cpu()
+        ref, _ = O.corner_indices(pts, v.shape[2:], 128)
+        assert torch.equal(idx, ref), f"level {l}"
+    # features vs F.grid_sample (reference layout), tolerance 1e-6 relative (bit-exact expected)
+    ref = O.gather_features(vols, pts, 128)                           # (B, sumC*7, N)
+    perm = layout.reference_permutation()
+    got = rows.cpu().view(B, N, -1)
+    valid = perm >= 0
+    got_ref_order = torch.empty(B, N, int(valid.sum()))
+    got_ref_order[:, :, perm[valid]] = got[:, :, valid]
+    got_ref_order = got_ref_order.permute(0, 2, 1)
+    assert G.rel_err(got_ref_order.numpy(), ref.numpy()) <= 1e-6
+    assert torch.all(got[:, :, ~valid] == 0)
+    print("gather bit-exact:", torch.equal(got_ref_order, ref))
+
+
+def test_gather_fwd_align_corners_variant():
+    ops = _ops()
+    chans = [1, 64, 128, 128]
+    B, dims, N = 2, (16, 12, 20), 300
+    vols = _rand_levels(B, dims, chans, 9)
+    g = torch.Generator().manual_seed(10)
+    pts = (torch.rand(B, N, 3, generator=g) - 0.5) * 1.1
+    layout = ops.FeatureLayout(chans)
+    rows = ops.gather_fwd([_cl(v) for v in vols], pts.cuda(), layout, float(np.float32(0.035)), True)
+    ref = O.gather_features(vols, pts, 32)
+    perm = layout.reference_permutation()
+    valid = perm >= 0
+    got = rows.cpu().view(B, N, -1)
+    out = torch.empty(B, N, int(valid.sum()))
+    out[:, :, perm[valid]] = got[:, :, valid]
+    assert G.rel_err(out.permute(0, 2, 1).numpy(), ref.numpy()) <= 1e-6
+
+
+def test_gather_bwd_volume_and_point_grads():
+    ops = _ops()
+    chans = [1, 16, 32, 64, 128, 128]
+    B, dims, N = 2, (16, 16, 16), 400
+    vols = [v.requires_grad_(True) for v in _rand_levels(B, dims, chans, 11)]
+    g = torch.Generator().manual_seed(12)
+    pts = ((torch.rand(B, N, 3, generator=g) - 0.5) * 1.1).requires_grad_(True)
+    ref = O.gather_features(vols, pts, 128)
+    w = torch.randn(ref.shape, generator=g)
+    (ref * w).sum().backward()
+    layout = ops.FeatureLayout(chans)
+    perm = layout.reference_permutation()
+    gfeat = torch.zeros(B, N, layout.row_stride)
+    valid = perm >= 0
+    gfeat[:, :, valid] = w.permute(0, 2, 1)[:, :, perm[valid]]
+    vols_g = [_cl(v.detach()) for v in vols]
+    gvols = [torch.zeros_like(v) for v in vols_g]
+    gp = ops.gather_bwd(vols_g, gvols, pts.detach().cuda(), gfeat.view(B * N, -1).cuda(), layout,
+                        float(np.float32(0.0722)), False, want_gpoints=True)
+    for l, v in enumerate(vols):
+        assert G.rel_err(_ncdhw(gvols[l]).numpy(), v.grad.numpy()) < 1e-5, f"level {l}"
+    assert G.rel_err(gp.cpu().numpy(), pts.grad.numpy()) < 1e-4
+
+
+@pytest.mark.parametrize("M,N,K", [(1000, 256, 2592), (130, 512, 64), (4099, 256, 256)])
+def test_linear_fwd_bwd(M, N, K):
+    ops = _ops()
+    g = torch.Generator().manual_seed(M + N)
+    x = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) / K ** 0.5
+    b = torch.randn(N, generator=g)
+    y_ref = F.relu(x.double() @ w.double().t() + b.double())
+    y = ops.linear_fwd(x.cuda(), w.cuda(), b.cuda(), relu=True)
+    assert G.rel_err(y.cpu().numpy(), y_ref.numpy()) < 2e-6
+    dy = torch.randn(M, N, generator=g)
+    dx_ref = (dy.double() @ w.double()) * (x.double() > 0)
+    dx = ops.linear_bwd_data(dy.cuda(), w.cuda(), mask=x.cuda())
+    assert G.rel_err(dx.cpu().numpy(), dx_ref.numpy()) < 2e-6
+    dw, db = ops.linear_bwd_weight(dy.cuda(), x.cuda())
+    assert G.rel_err(dw.cpu().numpy(), (dy.double().t() @ x.double()).numpy()) < 2e-6
+    assert G.rel_err(db.cpu().numpy(), dy.double().sum(0).numpy()) < 2e-6
+
+
+def test_fc_out_and_bce():
+    ops = _ops()
+    g = torch.Generator().manual_seed(3)
+    M, K, B = 3000, 256, 3
+    h = F.relu(torch.randn(M, K, generator=g))
+    w = torch.randn(K, generator=g) / 16
+    b = torch.randn(1, generator=g)
+    z = ops.fc_out_fwd(h.cuda(), w.cuda(), b.cuda())
+    z_ref = h.double() @ w.double() + b.double()
+    assert G.rel_err(z.cpu().numpy(), z_ref.numpy()) < 1e-6
+    dz = torch.randn(M, generator=g)
+    dh, dw, db = ops.fc_out_bwd(h.cuda(), w.cuda(), dz.cuda())
+    assert G.rel_err(dh.cpu().numpy(), (dz[:, None] * w[None, :] * (h > 0)).numpy()) < 1e-6
+    assert G.rel_err(dw.cpu().numpy(), (dz.double() @ h.double()).numpy()) < 1e-6
+    assert abs(db.item() - dz.double().sum().item()) < 1e-4
+    logits = z_ref.float().view(B, M // B)
+    t = (torch.rand(B, M // B, generator=g) < 0.5).float()
+    lz = logits.clone().requires_grad_(True)
+    ref = F.binary_cross_entropy_with_logits(lz, t, reduction="none").sum(-1).mean()
+    ref.backward()
+    loss, dl = ops.bce_logits_sum_mean(logits.cuda(), t.cuda())
+    assert abs(loss.item() - ref.item()) < 1e-5 * abs(ref.item())
+    assert G.rel_err(dl.cpu().numpy(), lz.grad.numpy()) < 1e-5
+
+
+@pytest.mark.parametrize("B,dims,Ci,Co", [(2, (9, 7, 11), 1, 16), (1, (8, 8, 8), 1, 32), (2, (10, 6, 12), 16, 32),
+                                           (1, (8, 8, 8), 32, 32), (2, (7, 5, 6), 32, 64), (1, (6, 6, 6), 64, 64),
+                                           (1, (4, 5, 6), 64, 128), (2, (4, 4, 4), 128, 128)])
+def test_conv3d_fwd_bwd(B, dims, Ci, Co):
+    ops = _ops()
+    g = torch.Generator().manual_seed(Ci * 1000 + Co)
+    x = torch.randn(B, Ci, *dims, generator=g).requires_grad_(True)
+    w = (torch.randn(Co, Ci, 3, 3, 3, generator=g) / (27 * Ci) ** 0.5).requires_grad_(True)
+    b = torch.randn(Co, generator=g).requires_grad_(True)
+    y_ref = F.relu(F.conv3d(x.double(), w.double(), b.double(), padding=1))
+    dy = torch.randn(y_ref.shape, generator=g)
+    pre = F.conv3d(x.double(), w.double(), b.double(), padding=1)
+    gx, gw, gb = torch.autograd.grad(pre, (x, w, b), dy.double())
+    wf, wb = ops.conv3d_pack_weight(w.detach().cuda())
+    y = ops.conv3d_k3(_cl(x.detach()), wf, b.detach().cuda(), relu=True)
+    assert G.rel_err(_ncdhw(y).numpy(), y_ref.detach().numpy()) < 3e-6
+    dwp, db = ops.conv3d_k3_bwd_weight(_cl(x.detach()), _cl(dy))
+    dw = ops.conv3d_unpack_wgrad(dwp, Ci, Co)
+    assert G.rel_err(dw.cpu().numpy(), gw.numpy()) < 3e-6
+    assert G.rel_err(db.cpu().numpy(), gb.numpy()) < 3e-6
+    dx = ops.conv3d_k3(_cl(dy), wb)
+    assert G.rel_err(_ncdhw(dx).numpy(), gx.numpy()) < 3e-6
+    if Ci > 1:
+        dxm = ops.conv3d_k3(_cl(dy), wb, mask=_cl(x.detach()))
+        assert G.rel_err(_ncdhw(dxm).numpy(), (gx * (x > 0)).detach().numpy()) < 3e-6
+
+
+@pytest.mark.parametrize("B,dims,C,pool", [(2, (9, 7, 10), 16, True), (1, (8, 8, 8), 32, True), (2, (5, 4, 6), 64, True),
+                                           (3, (4, 4, 4), 128, True), (2, (3, 2, 2), 128, False)])
+def test_bn_pool_fwd_bwd(B, dims, C, pool):
+    ops = _ops()
+    g = torch.Generator().manual_seed(C + B)
+    pre = torch.randn(B, C, *dims, generator=g)
+    x = F.relu(pre).requires_grad_(True)       # BN input is a ReLU output (many exact zeros -> pool ties)
+    gamma = (torch.rand(C, generator=g) + 0.5).requires_grad_(True)
+    beta = (torch.rand(C, generator=g) - 0.5).requires_grad_(True)
+    rm, rv = torch.zeros(C), torch.ones(C)
+    y_ref = F.batch_norm(x, rm, rv, gamma, beta, True, 0.1, 1e-5)
+    rm_g, rv_g = torch.zeros(C).cuda(), torch.ones(C).cuda()
+    y, pooled, argmax, ss, mean = ops.bn_forward(_cl(x.detach()), gamma.detach().cuda(), beta.detach().cuda(), rm_g, rv_g,
+                                                 True, want_pool=pool)
+    assert G.rel_err(_ncdhw(y).numpy(), y_ref.detach().numpy()) < 2e-6
+    assert G.rel_err(rm_g.cpu().numpy(), rm.numpy()) < 1e-6 and G.rel_err(rv_g.cpu().numpy(), rv.numpy()) < 1e-6
+    dy = torch.randn(y_ref.shape, generator=g)
+    obj = (y_ref * dy).sum()
+    dp = None
+    if pool:
+        p_ref = F.max_pool3d(y_ref, 2)
+        assert G.rel_err(_ncdhw(pooled).numpy(), p_ref.detach().numpy()) < 2e-6
+        dp = torch.randn(p_ref.shape, generator=g)
+        obj = obj + (p_ref * dp).sum()
+    gx, gg, gb = torch.autograd.grad(obj, (x, gamma, beta))
+    dx, dgamma, dbeta = ops.bn_backward(_cl(x.detach()), _cl(dy), _cl(dp) if pool else None, argmax, mean, ss, relu_mask=True)
+    ref_dx = gx * (x > 0)
+    assert G.rel_err(_ncdhw(dx).numpy(), ref_dx.detach().numpy()) < 1e-5
+    assert G.rel_err(dgamma.cpu().numpy(), gg.numpy()) < 1e-5
+    assert G.rel_err(dbeta.cpu().numpy(), gb.numpy()) < 1e-5
+    # eval mode uses the running statistics
+    ye_ref = F.batch_norm(x.detach(), rm, rv, gamma.detach(), beta.detach(), False, 0.1, 1e-5)
+    ye = ops.bn_forward(_cl(x.detach()), gamma.detach().cuda(), beta.detach().cuda(), rm_g, rv_g, False, want_pool=False)[0]
+    assert G.rel_err(_ncdhw(ye).numpy(), ye_ref.numpy()) < 2e-6
