@@ -222,10 +222,10 @@ extern "C" int svr_unproject_bwd(const float *depth, const float *gpc, float *gd
 
 extern "C" int svr_voxelize_splat_fwd(const float *pts, float *acc, int32_t *base, uint8_t *valid, int32_t B, int32_t N,
                                       int32_t D0, int32_t D1, int32_t D2, void *stream) {
+  int64_t total = (int64_t)B * N;
+  if (total <= 0) return SVR_OK;  // empty point cloud: nothing to add
   SVR_CHECK(pts && acc, SVR_E_BADARG, "splat_fwd: null pointer");
   SVR_CHECK(D0 > 0 && D1 > 0 && D2 > 0, SVR_E_BADSHAPE, "splat_fwd: dims %dx%dx%d", D0, D1, D2);
-  int64_t total = (int64_t)B * N;
-  if (total <= 0) return SVR_OK;
   hipLaunchKernelGGL(splat_fwd_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, pts, acc, base,
                      valid, total, N, D0, D1, D2);
   return launch_status("splat_fwd");
@@ -233,9 +233,9 @@ extern "C" int svr_voxelize_splat_fwd(const float *pts, float *acc, int32_t *bas
 
 extern "C" int svr_voxelize_splat_bwd(const float *pts, const float *gacc, float *gpts, int32_t B, int32_t N, int32_t D0,
                                       int32_t D1, int32_t D2, void *stream) {
-  SVR_CHECK(pts && gacc && gpts, SVR_E_BADARG, "splat_bwd: null pointer");
   int64_t total = (int64_t)B * N;
   if (total <= 0) return SVR_OK;
+  SVR_CHECK(pts && gacc && gpts, SVR_E_BADARG, "splat_bwd: null pointer");
   hipLaunchKernelGGL(splat_bwd_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, pts, gacc, gpts,
                      total, N, D0, D1, D2);
   return launch_status("splat_bwd");

@@ -1,0 +1,157 @@
+"""`project` on MI355X: host-side mirror of the reference's model/projection.py.
+
+Same surface as the reference module (model/projection.py:21-218): ``project(dims, kernel_size,
+sigma)`` with the learnable ``sigma`` Parameter(3), ``forward(point_cloud (B,M,3)) -> (B,1,D0,D1,D2)``,
+``depthmap_to_gridspace(depthmap, scale_factor)``, ``norm_grid_space`` / ``un_norm_grid_space``,
+``pc_voxels``, ``smoothing_kernel``, ``voxels_smooth``, ``voxel_occ_from_pc``.  Differences:
+the intrinsics are the constants of data/raw/overfit/00000/intrinsic.txt (or ``intrinsic=`` 4x4)
+instead of a file read relative to cwd (:208-218), and the normalisation helpers return new
+tensors instead of writing through slices.  Arithmetic runs in libsvr_hip.so (projection.hip).
+"""
+import torch
+import torch.nn as nn
+
+from .. import ops
+
+_FOCAL, _CX, _CY = 277.1281435, 159.5, 119.5
+
+
+def _camera_to_grid(intrinsic, scale_factor):
+    """Host-side constants of generate_frustum / generate_frustum_volume (projection.py:165-197):
+    tiny 4x4 float32 algebra, evaluated once per call on the CPU."""
+    Kinv = torch.inverse(intrinsic)
+    corners = []
+    for d in (0.4, 6.0):
+        for (u, v) in ((0, 0), (0, 240), (320, 240), (320, 0)):
+            corners.append([u * d, v * d, d, 1.0])
+    fr = torch.mm(Kinv, torch.tensor(corners, dtype=torch.float32).t()).t()[:, :3]
+    vs = 0.05 * scale_factor
+    lo = fr.min(dim=0).values / vs
+    hi = fr.max(dim=0).values / vs
+    dims = torch.ceil(hi - lo)
+    inv = torch.tensor(1.0 / vs, dtype=torch.float32)
+    return dims, inv, -lo
+
+
+class _UnprojectFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, depth, consts, normalize):
+        depth = depth.contiguous()
+        ctx.save_for_backward(depth)
+        ctx.consts, ctx.normalize = consts, normalize
+        return ops.unproject(depth, consts, normalize)
+
+    @staticmethod
+    def backward(ctx, gpc):
+        (depth,) = ctx.saved_tensors
+        return ops.unproject_bwd(depth, gpc.contiguous(), ctx.consts, ctx.normalize), None, None
+
+
+class _SplatFn(torch.autograd.Function):
+    """pc_voxels: clamp(8 * trilinear splat, 0, 1) -- projection.py:39-80 incl. the x8 alias quirk."""
+
+    @staticmethod
+    def forward(ctx, pts, dims):
+        pts = pts.contiguous()
+        acc, _, _ = ops.splat_fwd(pts, dims)
+        ctx.save_for_backward(pts, acc)
+        ctx.dims = dims
+        return ops.scale_clamp01(acc, 8.0)
+
+    @staticmethod
+    def backward(ctx, gvox):
+        pts, acc = ctx.saved_tensors
+        gacc = ops.scale_clamp01_bwd(acc, gvox.contiguous(), 8.0)
+        return ops.splat_bwd(pts, gacc, ctx.dims), None
+
+
+class _BlurFn(torch.autograd.Function):
+    """voxels_smooth: three axis passes (last axis first) + clamp -- projection.py:100-117."""
+
+    @staticmethod
+    def forward(ctx, vox, k_last, k_mid, k_first):
+        vox = vox.contiguous()
+        taps = [k_last.contiguous(), k_mid.contiguous(), k_first.contiguous()]
+        a1 = ops.blur_axis(vox, taps[0], 2)
+        a2 = ops.blur_axis(a1, taps[1], 1)
+        a3 = ops.blur_axis(a2, taps[2], 0)
+        ctx.save_for_backward(vox, a1, a2, a3, *taps)
+        return ops.scale_clamp01(a3, 1.0)
+
+    @staticmethod
+    def backward(ctx, gout):
+        vox, a1, a2, a3, t0, t1, t2 = ctx.saved_tensors
+        g3 = ops.scale_clamp01_bwd(a3, gout.contiguous(), 1.0)
+        g2, gt2 = ops.blur_axis_bwd(a2, t2, g3, 0)
+        g1, gt1 = ops.blur_axis_bwd(a1, t1, g2, 1)
+        g0, gt0 = ops.blur_axis_bwd(vox, t0, g1, 2, want_gin=ctx.needs_input_grad[0])
+        return g0, gt0.float(), gt1.float(), gt2.float()
+
+
+class project(nn.Module):
+    def __init__(self, dims, kernel_size, sigma, intrinsic=None):
+        super().__init__()
+        self.kernel_size = [int(k) for k in kernel_size]
+        self.sigma = nn.Parameter(torch.as_tensor(sigma, dtype=torch.float32).clone())
+        self.vox_size = torch.tensor([int(d) for d in dims])
+        self.intrinsic = intrinsic if intrinsic is not None else self.get_intrinsic()
+
+    @staticmethod
+    def get_intrinsic(intrinsic_path=None):
+        if intrinsic_path is not None:
+            l0, l1 = open(intrinsic_path).read().splitlines()[:2]
+            f = float(l0[2:].split(",")[0])
+            cx = float(l0[2:-2].split(",")[2].strip())
+            cy = float(l1[1:-2].split(",")[2].strip())
+        else:
+            f, cx, cy = _FOCAL, _CX, _CY
+        return torch.tensor([[f, 0, cx, 0], [0, f, cy, 0], [0, 0, 1, 0], [0, 0, 0, 1]], dtype=torch.float32)
+
+    def _dims(self):
+        return tuple(int(v) for v in self.vox_size)
+
+    def _consts(self, scale_factor):
+        _, inv, t = _camera_to_grid(self.intrinsic.cpu(), scale_factor)
+        K = self.intrinsic
+        d = self._dims()
+        return [float(K[0, 0]), float(K[0, 2]), float(K[1, 2]), float(inv), float(t[0]), float(inv), float(t[1]),
+                float(inv), float(t[2]), float(d[0]), float(d[1]), float(d[2])]
+
+    # -- depth -> points -------------------------------------------------------------------
+    def depthmap_to_gridspace(self, depthmap, scale_factor=1, normalize=False):
+        """(B,Hi,Wi) depth -> (B,Hi*Wi,3) grid-space points (projection.py:150-163); with
+        ``normalize=True`` the norm_grid_space step is fused into the same kernel."""
+        return _UnprojectFn.apply(depthmap.float(), self._consts(scale_factor), bool(normalize))
+
+    def norm_grid_space(self, pc):
+        d = self.vox_size.to(pc.device).to(pc.dtype)
+        return (pc - d / 2) / d
+
+    def un_norm_grid_space(self, pc):
+        d = self.vox_size.to(pc.device).to(pc.dtype)
+        return pc * d + d / 2
+
+    # -- points -> voxels ------------------------------------------------------------------
+    def pc_voxels(self, points, eps=1e-6):
+        return _SplatFn.apply(points.float(), self._dims())
+
+    def smoothing_kernel(self):
+        ks = []
+        for a in range(3):
+            K = self.kernel_size[a]
+            t = torch.arange(-K // 2 + 1.0, K // 2 + 1.0, device=self.sigma.device)
+            k = torch.exp(-t ** 2 / (2.0 * self.sigma[a] ** 2))
+            ks.append(k / k.sum())
+        return ks                      # ks[0] -> last spatial axis, ks[2] -> first (projection.py:96-98)
+
+    def voxels_smooth(self, voxels, kernels):
+        return _BlurFn.apply(voxels, kernels[0].reshape(-1), kernels[1].reshape(-1), kernels[2].reshape(-1))
+
+    def voxel_occ_from_pc(self, point_cloud):
+        vox = self.pc_voxels(point_cloud)
+        return self.voxels_smooth(vox, self.smoothing_kernel()).unsqueeze(1)
+
+    def forward(self, point_cloud):
+        if not point_cloud.is_cuda:
+            raise RuntimeError("project HIP path needs GPU tensors (no CPU fallback)")
+        return self.voxel_occ_from_pc(point_cloud)

@@ -275,3 +275,74 @@ def bn_backward(x, dy, dpooled, argmax, mean, ss, relu_mask=True):
     check(l.svr_bn_bwd_apply(_p(x), _p(dy), _p(dpooled), _p(argmax), _p(mean), _p(ss), C.c_void_p(0), _p(sums), _p(dx),
                              _p(dgamma), _p(dbeta), B, D, H, W, Cc, int(relu_mask), _stream()), "bn_bwd_apply")
     return dx, dgamma, dbeta
+
+
+# ------------------------------------------------------------------------------------------
+# projection: unproject / splat / clamp / blur
+# ------------------------------------------------------------------------------------------
+def _consts(c):
+    arr = (C.c_float * 12)(*[float(v) for v in c])
+    return arr
+
+
+def unproject(depth, consts, normalize):
+    _f32(depth)
+    B, Hi, Wi = depth.shape
+    pc = torch.empty(B, Hi * Wi, 3, device=depth.device, dtype=torch.float32)
+    check(_lib.lib().svr_unproject_fwd(_p(depth), _p(pc), B, Hi, Wi, _consts(consts), int(normalize), _stream()), "unproject_fwd")
+    return pc
+
+
+def unproject_bwd(depth, gpc, consts, normalize):
+    B, Hi, Wi = depth.shape
+    gd = torch.empty_like(depth)
+    check(_lib.lib().svr_unproject_bwd(_p(depth), _p(gpc), _p(gd), B, Hi, Wi, _consts(consts), int(normalize), _stream()),
+          "unproject_bwd")
+    return gd
+
+
+def splat_fwd(pts, dims, want_indices=False):
+    _f32(pts)
+    B, N, _ = pts.shape
+    acc = torch.zeros(B, *dims, device=pts.device, dtype=torch.float32)
+    base = torch.empty(B, N, 3, device=pts.device, dtype=torch.int32) if want_indices else None
+    valid = torch.empty(B, N, device=pts.device, dtype=torch.uint8) if want_indices else None
+    check(_lib.lib().svr_voxelize_splat_fwd(_p(pts), _p(acc), _p(base), _p(valid), B, N, dims[0], dims[1], dims[2], _stream()),
+          "splat_fwd")
+    return acc, base, valid
+
+
+def splat_bwd(pts, gacc, dims):
+    B, N, _ = pts.shape
+    gp = torch.empty_like(pts)
+    check(_lib.lib().svr_voxelize_splat_bwd(_p(pts), _p(gacc), _p(gp), B, N, dims[0], dims[1], dims[2], _stream()), "splat_bwd")
+    return gp
+
+
+def scale_clamp01(x, scale):
+    out = torch.empty_like(x)
+    check(_lib.lib().svr_scale_clamp01_fwd(_p(x), _p(out), x.numel(), scale, _stream()), "scale_clamp01_fwd")
+    return out
+
+
+def scale_clamp01_bwd(x, gout, scale):
+    gin = torch.empty_like(x)
+    check(_lib.lib().svr_scale_clamp01_bwd(_p(x), _p(gout), _p(gin), x.numel(), scale, _stream()), "scale_clamp01_bwd")
+    return gin
+
+
+def blur_axis(x, taps, axis):
+    _f32(x, taps)
+    B, D0, D1, D2 = x.shape
+    out = torch.empty_like(x)
+    check(_lib.lib().svr_blur_axis_fwd(_p(x), _p(taps), _p(out), B, D0, D1, D2, axis, taps.numel(), _stream()), "blur_fwd")
+    return out
+
+
+def blur_axis_bwd(x, taps, gout, axis, want_gin=True, want_gtaps=True):
+    B, D0, D1, D2 = x.shape
+    gin = torch.empty_like(x) if want_gin else None
+    gt = torch.zeros(taps.numel(), device=x.device, dtype=torch.float64) if want_gtaps else None
+    check(_lib.lib().svr_blur_axis_bwd(_p(x), _p(taps), _p(gout), _p(gin), _p(gt), B, D0, D1, D2, axis, taps.numel(),
+                                       _stream()), "blur_bwd")
+    return gin, gt
