@@ -1,0 +1,158 @@
+#!/usr/bin/env python
+"""Headline benchmark: query-points/sec, forward+backward(+Adam), IF-Net 128^3 grid x 50k points.
+
+    python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
+
+One "step" = one full training step of the hot path on one synthetic batch per GPU: 3D conv
+encoder + 6-level trilinear gather + point MLP + BCE loss, backward of all of it, gradient
+all-reduce (N>1) and the Adam update.  Workload at every N: BASELINE.json configs[2] per GPU
+(128^3 grid, 50 000 points, batch 8; configs[3] is the same per-GPU shard x 8 GPUs) -> weak
+scaling.  Inputs are resident in HBM before the timed region.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+GATHER_BYTES_PER_POINT_F32 = 93000          # 7*8*369 reads + 7*369 writes + 12 B coords
+HBM_PEAK_GBPS = 8000.0                       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def synth_batch(seed, B, D, N, device):
+    import torch
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    x = (torch.rand(B, 1, D, D, D, generator=g) < 0.05).float()
+    pts = torch.rand(B, N, 3, generator=g) - 0.5
+    occ = (torch.rand(B, N, generator=g) < 0.5).float()
+    return {"input": x.to(device), "points": pts.to(device), "occupancies": occ.to(device)}
+
+
+def cpu_baseline(D, N, max_seconds=40.0):
+    """The CPU oracle (= the reference's op sequence in stock torch CPU ops) on ONE sample of the
+    same workload, fwd+bwd, on this host's cores.  Bounded: one warm-up-free repetition."""
+    import torch
+    from oracle import ifnet_oracle as O
+    threads = torch.get_num_threads()
+    b = synth_batch(103, 1, D, N, "cpu")
+    st = O.make_leaf_state(O.name_seeded_state(128))
+    t0 = time.perf_counter()
+    out = O.training_step(st, b, 128)
+    out["loss"].backward()
+    dt = time.perf_counter() - t0
+    return {"value": N / dt, "unit": "query-points/s", "cores": threads, "kind": "port",
+            "sample": f"1 sample of the workload (B=1, {D}^3 grid, {N} points), fwd+bwd once, {dt:.1f} s, "
+                      f"torch CPU ops with {threads} threads (oracle/ifnet_oracle.py)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=8, help="samples per GPU")
+    ap.add_argument("--grid", type=int, default=128)
+    ap.add_argument("--points", type=int, default=50000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import svr_amd  # noqa: F401
+    from svr_amd import ops
+    from svr_amd.dp import DataParallelTrainer
+    from svr_amd.trainer import ImplicitRefinementTrainer
+    from oracle import ifnet_oracle as O            # name-seeded weights only (checker-side helper)
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    trainer = ImplicitRefinementTrainer()
+    trainer.ifnet.load_state_dict(O.name_seeded_state(128), strict=False)   # random init of the architecture
+    trainer = trainer.to(dev).train()
+    opt = torch.optim.Adam(trainer.ifnet.parameters(), lr=trainer.hparams.lr, fused=True)
+    dp = DataParallelTrainer(trainer, optimizer=opt)
+    batch = synth_batch(103 + rank, a.batch, a.grid, a.points, dev)
+
+    # live HIP-event timing of the roofline kernel (forward gather) on the stream it runs on
+    ev = []
+    orig_gather = ops.gather_fwd
+
+    def timed_gather(*args, **kw):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        r = orig_gather(*args, **kw)
+        e1.record()
+        ev.append((e0, e1))
+        return r
+
+    import importlib
+    ifnet_mod = importlib.import_module("single-view-3d-reconstruction_amd.model.ifnet")
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        dp.step(batch)
+    ifnet_mod.ops.gather_fwd = timed_gather
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        out = dp.step(batch)
+    sync()
+    dt = time.perf_counter() - t0
+    ifnet_mod.ops.gather_fwd = orig_gather
+    loss = float(out["loss"])
+    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax)
+    gather_ms = sum(e0.elapsed_time(e1) for e0, e1 in ev) / max(len(ev), 1)
+
+    if rank == 0:
+        pts_per_step = world * a.batch * a.points
+        value = pts_per_step * a.steps / dt
+        alg_bytes = a.batch * a.points * GATHER_BYTES_PER_POINT_F32
+        achieved = alg_bytes / (gather_ms * 1e-3) / 1e9 if gather_ms > 0 else 0.0
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "gather_fwd_traffic.json")
+        if os.path.exists(tfile):
+            try:
+                t = json.load(open(tfile))
+                if t.get("batch") == a.batch and t.get("grid") == a.grid and t.get("points") == a.points:
+                    traffic = t.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        res = {
+            "metric": "query-points/sec fwd+bwd (128^3 grid, 50k pts)", "value": value, "unit": "query-points/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[2] per GPU: {a.grid}^3 grid, {a.points} query points, batch "
+                                   f"{a.batch}/GPU, full 3D conv encoder + 6-level trilinear gather + occupancy MLP, "
+                                   "fwd+bwd+grad all-reduce+Adam",
+                       "global_batch": world * a.batch, "parallelism": f"dp{world}", "loss": loss},
+            "roofline": {"kernel": "svr_gather_trilinear_fwd (6 levels)", "bound": "hbm", "achieved": achieved,
+                         "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+                         "ms_per_launch": gather_ms, "algorithmic_bytes_per_launch": alg_bytes, "traffic": traffic},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(a.grid, a.points)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

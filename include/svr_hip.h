@@ -55,8 +55,17 @@ typedef struct svr_gather_desc {
   int32_t row_stride;     /* FS: floats per feature row (>= used width, multiple of 4) */
   int32_t align_corners;  /* 0: 128-architecture, 1: 32-architecture                   */
   float displacement;     /* 0.0722 / 0.035 (model/ifnet.py:144,82)                    */
+  const int32_t *order;   /* optional (B*N) processing order from svr_points_morton_order, or NULL */
   svr_level level[SVR_MAX_LEVELS];
 } svr_gather_desc;
+
+/* order[i] = index (b*N+n) of the i-th point in (sample, Morton code at 64^3) order.  Not a
+ * reference op: it only changes the order in which the gather / scatter kernels visit points
+ * (L2 locality, run-combining of atomics); outputs keep the caller's point order.
+ * workspace: svr_points_morton_order_workspace() bytes.                                      */
+int64_t svr_points_morton_order_workspace(int32_t B, int32_t N);
+int svr_points_morton_order(const float *points, int32_t *order, int32_t B, int32_t N, void *workspace,
+                            void *stream);
 
 /* features[b*N+n][level.col + j*C + c] = trilinear sample j of channel c (zeros padding). */
 int svr_gather_trilinear_fwd(const svr_gather_desc *d, const float *points /*(B,N,3)*/,

@@ -22,13 +22,15 @@ class Level(C.Structure):
 
 class GatherDesc(C.Structure):
     _fields_ = [("n_levels", I32), ("B", I32), ("N", I32), ("row_stride", I32), ("align_corners", I32),
-                ("displacement", F32), ("level", Level * SVR_MAX_LEVELS)]
+                ("displacement", F32), ("order", P), ("level", Level * SVR_MAX_LEVELS)]
 
 
 # name -> (restype, argtypes): exactly the declarations of include/svr_hip.h
 SIGNATURES = {
     "svr_version": (C.c_int, []),
     "svr_last_error": (C.c_char_p, []),
+    "svr_points_morton_order_workspace": (I64, [I32, I32]),
+    "svr_points_morton_order": (C.c_int, [P, P, I32, I32, P, P]),
     "svr_gather_trilinear_fwd": (C.c_int, [C.POINTER(GatherDesc), P, P, P]),
     "svr_gather_trilinear_bwd": (C.c_int, [C.POINTER(GatherDesc), P, P, P, P]),
     "svr_gather_corner_indices": (C.c_int, [C.POINTER(GatherDesc), I32, P, P, P]),

@@ -15,6 +15,7 @@ LIB = os.path.join(LIBDIR, "libsvr_hip.so")
 SOURCES = {
     "capi.cpp": [],
     "gather.hip": ["-ffp-contract=off"],
+    "sort.hip": [],
     "gemm.hip": [],
     "conv3d.hip": [],
     "bn_pool.hip": [],

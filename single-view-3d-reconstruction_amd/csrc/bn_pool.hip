@@ -51,16 +51,25 @@ __global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float *__re
   }
 }
 
-__global__ void bn_stats_final_kernel(const double *__restrict__ part, double *__restrict__ stats, int64_t rows, int C,
-                                      int blocks) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+// one workgroup per channel: f64 tree over the block partials (fixed order)
+__global__ __launch_bounds__(256) void bn_stats_final_kernel(const double *__restrict__ part, double *__restrict__ stats,
+                                                             int64_t rows, int C, int blocks) {
+  const int c = blockIdx.x;
   double s = 0, ss = 0;
-  for (int b = 0; b < blocks; ++b) { s += part[(int64_t)b * 2 * C + c]; ss += part[(int64_t)b * 2 * C + C + c]; }
-  double mean = s / (double)rows;
-  double var = ss / (double)rows - mean * mean;
-  stats[c] = mean;
-  stats[C + c] = var > 0 ? var : 0;
+  for (int b = threadIdx.x; b < blocks; b += 256) { s += part[(int64_t)b * 2 * C + c]; ss += part[(int64_t)b * 2 * C + C + c]; }
+  __shared__ double r1[256], r2[256];
+  r1[threadIdx.x] = s; r2[threadIdx.x] = ss;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) { r1[threadIdx.x] += r1[threadIdx.x + o]; r2[threadIdx.x] += r2[threadIdx.x + o]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    double mean = r1[0] / (double)rows;
+    double var = r2[0] / (double)rows - mean * mean;
+    stats[c] = mean;
+    stats[C + c] = var > 0 ? var : 0;
+  }
 }
 
 __global__ void bn_finalize_kernel(const double *__restrict__ stats, const float *__restrict__ gamma,
@@ -233,12 +242,19 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(const float *__restrict__ x
   }
 }
 
-__global__ void sum_parts_kernel(const double *__restrict__ part, double *__restrict__ out, int cols, int blocks) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= cols) return;
+__global__ __launch_bounds__(256) void sum_parts_kernel(const double *__restrict__ part, double *__restrict__ out, int cols,
+                                                        int blocks) {
+  const int c = blockIdx.x;
   double s = 0;
-  for (int b = 0; b < blocks; ++b) s += part[(int64_t)b * cols + c];
-  out[c] = s;
+  for (int b = threadIdx.x; b < blocks; b += 256) s += part[(int64_t)b * cols + c];
+  __shared__ double red[256];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[c] = red[0];
 }
 
 __global__ void bn_param_grads_kernel(const double *__restrict__ sums, float *__restrict__ dgamma,
@@ -283,7 +299,7 @@ extern "C" int svr_bn_stats(const float *x, double *stats, int64_t rows, int32_t
   int64_t rpb;
   int blocks = stats_blocks(rows, &rpb);
   hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(blocks), dim3(256), 0, s, x, (double *)workspace, rows, C, rpb);
-  hipLaunchKernelGGL(bn_stats_final_kernel, dim3(cdiv(C, 64)), dim3(64), 0, s, (const double *)workspace, stats, rows, C, blocks);
+  hipLaunchKernelGGL(bn_stats_final_kernel, dim3(C), dim3(256), 0, s, (const double *)workspace, stats, rows, C, blocks);
   return launch_status("bn_stats");
 }
 
@@ -320,7 +336,7 @@ extern "C" int svr_bn_bwd_reduce(const float *x, const float *dy, const float *d
   int blocks = bwd_blocks(cells, C);
   hipLaunchKernelGGL(bn_bwd_kernel<false>, dim3(blocks), dim3(256), 0, s, x, dy, dpooled, argmax, mean_f32, scale_shift,
                      (const double *)nullptr, (double *)workspace, (float *)nullptr, v, cells, 0);
-  hipLaunchKernelGGL(sum_parts_kernel, dim3(cdiv(2 * C, 64)), dim3(64), 0, s, (const double *)workspace, sums, 2 * C, blocks);
+  hipLaunchKernelGGL(sum_parts_kernel, dim3(2 * C), dim3(256), 0, s, (const double *)workspace, sums, 2 * C, blocks);
   return launch_status("bn_bwd_reduce");
 }
 

@@ -33,7 +33,7 @@ __device__ __forceinline__ float unnormalize(float g, int S, int align_corners) 
 }
 
 // j: 0 centre, 1/2 -+d on grid-x, 3/4 on grid-y, 5/6 on grid-z (model/ifnet.py:144-153).
-__device__ __forceinline__ Corner sample_corner(const float *__restrict__ pt, int j, float disp,
+__device__ __forceinline__ Corner sample_corner(const float *pt, int j, float disp,
                                                 int D, int H, int W, int ac) {
   float gx = 2.0f * pt[2], gy = 2.0f * pt[1], gz = 2.0f * pt[0];
   float dj = (j & 1) ? -disp : disp;
@@ -77,14 +77,15 @@ __device__ __forceinline__ Weights corner_weights(const Corner &c) {
 
 template <int C>
 __global__ __launch_bounds__(256) void gather_fwd_kernel(LevelArgs L, const float *__restrict__ points,
-                                                         float *__restrict__ feat, int64_t total,
-                                                         int N, int row_stride, float disp, int ac) {
+                                                         float *__restrict__ feat, const int32_t *__restrict__ order,
+                                                         int64_t total, int N, int row_stride, float disp, int ac) {
   constexpr int V = (C >= 4) ? C / 4 : 1;
   int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (gid >= total) return;
   int q = (int)(gid % V);
   int j = (int)((gid / V) % 7);
   int64_t pn = gid / (7 * V);
+  if (order) pn = order[pn];
   int b = (int)(pn / N);
   Corner c = sample_corner(points + pn * 3, j, disp, L.D, L.H, L.W, ac);
   Weights w = corner_weights(c);
@@ -197,6 +198,82 @@ __global__ __launch_bounds__(256) void gather_bwd_kernel(LevelArgs L, const floa
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Backward scatter, production path: run-combining + contiguous global atomics.
+//
+// Global f32 atomics run at ~1.3 TB/s chip-wide only when a wave-instruction adds to CONTIGUOUS
+// dwords (MI355X_MICROARCH.md "Global float atomics"); the coarse levels would need 11.5 GB of
+// them per level and step.  (LDS-privatised tiles were tried first and rejected: ds_add_f32
+// retires ~0.4 lanes/clk/CU on gfx950, 12 ms per coarse level -- profiles/r01_notes.md.)
+// Instead the points are visited in Morton order (sort.hip), so consecutive samples of one
+// displacement j mostly share their 8 corners at the coarse levels: a lane group keeps the 8
+// corner sums of its current run in registers and only flushes them (one 64..256-B contiguous
+// atomic per corner) when the base voxel changes.  lane = (run group, channel); the sample's
+// source index is uniform within a group.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float corner_w(const Weights &w, int k) {
+  return (w.wx[k & 1] * w.wy[(k >> 1) & 1]) * w.wz[k >> 2];
+}
+
+template <int C>
+__global__ __launch_bounds__(256) void gather_bwd_runs_kernel(LevelArgs L, const float *__restrict__ points,
+                                                              const float *__restrict__ gfeat,
+                                                              const int32_t *__restrict__ order, int64_t BN, int N,
+                                                              int row_stride, float disp, int ac, int64_t waves) {
+  constexpr int CW = C < 64 ? C : 64;  // channels per lane group
+  constexpr int G = 64 / CW;           // independent runs per wave
+  constexpr int CG = C / CW;           // channel groups per sample
+  constexpr int PG = 2 * CW;           // consecutive points per run group
+  const int lane = threadIdx.x & 63;
+  const int ch = lane % CW, grp = lane / CW;
+  const int64_t item = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;  // wave-uniform (chunk, j, cg)
+  if (item >= waves) return;
+  const int cg = (int)(item % CG);
+  const int j = (int)((item / CG) % 7);
+  const int64_t chunk = item / (7 * CG);
+  const int64_t i0 = (chunk * G + grp) * PG;
+  const int64_t i1 = min(BN, i0 + PG);
+  const int coff = L.col + j * C + cg * CW + ch;
+  float acc[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+  int cz = 0, cy = 0, cx = 0;
+  int64_t cb = -1;  // batch*volume offset of the current run, -1 = no run open
+
+  auto flush = [&]() {
+    if (cb >= 0) {
+      float *gb = L.gvol + (size_t)cb * C + cg * CW + ch;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int z = cz + (k >> 2), y = cy + ((k >> 1) & 1), x = cx + (k & 1);
+        if (z >= 0 && z < L.D && y >= 0 && y < L.H && x >= 0 && x < L.W)
+          atomicAdd(gb + (((size_t)z * L.H + y) * L.W + x) * C, acc[k]);
+      }
+    }
+  };
+
+  int64_t pn_next = (i0 < i1) ? (order ? (int64_t)order[i0] : i0) : 0;
+  for (int64_t i = i0; i < i1; ++i) {
+    const int64_t pn = pn_next;
+    if (i + 1 < i1) pn_next = order ? (int64_t)order[i + 1] : i + 1;
+    const float g = gfeat[pn * row_stride + coff];
+    const float p3[3] = {points[pn * 3], points[pn * 3 + 1], points[pn * 3 + 2]};
+    Corner c = sample_corner(p3, j, disp, L.D, L.H, L.W, ac);
+    Weights w = corner_weights(c);
+    const bool touches = w.z0 >= -1 && w.z0 < L.D && w.y0 >= -1 && w.y0 < L.H && w.x0 >= -1 && w.x0 < L.W;
+    const int64_t nb = touches ? (pn / N) * ((int64_t)L.D * L.H * L.W) : -1;
+    if (nb != cb || w.z0 != cz || w.y0 != cy || w.x0 != cx) {
+      flush();
+      cb = nb; cz = w.z0; cy = w.y0; cx = w.x0;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] += g * corner_w(w, k);
+  }
+  flush();
+}
+
 __global__ void corner_index_kernel(const float *__restrict__ points, int32_t *__restrict__ out,
                                     int64_t total, int N, int D, int H, int W, float disp, int ac) {
   int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // over (b, j, n)
@@ -256,7 +333,7 @@ extern "C" int svr_gather_trilinear_fwd(const svr_gather_desc *d, const float *p
     int V = L.C >= 4 ? L.C / 4 : 1;
     int64_t total = BN * 7 * V;
     unsigned grid = (unsigned)svr::cdiv(total, 256);
-    DISPATCH_C(L.C, hipLaunchKernelGGL(gather_fwd_kernel<CC>, dim3(grid), dim3(256), 0, s, L, points, features,
+    DISPATCH_C(L.C, hipLaunchKernelGGL(gather_fwd_kernel<CC>, dim3(grid), dim3(256), 0, s, L, points, features, d->order,
                                        total, d->N, d->row_stride, d->displacement, d->align_corners));
   }
   return svr::launch_status("gather_fwd");
@@ -278,17 +355,34 @@ extern "C" int svr_gather_trilinear_bwd(const svr_gather_desc *d, const float *p
     bool gv = L.gvol != nullptr;
     if (!gv && !gpoints) continue;
     SVR_CHECK(L.vol != nullptr || !gpoints, SVR_E_BADARG, "gather_bwd: level %d needs vol for the point gradient", l);
-    int V = L.C >= 4 ? L.C / 4 : 1;
-    int64_t total = BN * 7 * V;
-    unsigned grid = (unsigned)svr::cdiv(total, 256);
-#define LAUNCH_BWD(GV, GP)                                                                                   \
-  DISPATCH_C(L.C, hipLaunchKernelGGL((gather_bwd_kernel<CC, GV, GP>), dim3(grid), dim3(256), 0, s, L, points, \
-                                     gfeatures, gpoints, total, d->N, d->row_stride, d->displacement,        \
-                                     d->align_corners))
-    if (gv && gpoints) { LAUNCH_BWD(true, true); }
-    else if (gv) { LAUNCH_BWD(true, false); }
-    else { LAUNCH_BWD(false, true); }
-#undef LAUNCH_BWD
+    if (gpoints) {  // rare path (points require grad): per-thread float4 kernel, point gradient only
+      int V = L.C >= 4 ? L.C / 4 : 1;
+      int64_t total = BN * 7 * V;
+      unsigned grid = (unsigned)svr::cdiv(total, 256);
+      DISPATCH_C(L.C, hipLaunchKernelGGL((gather_bwd_kernel<CC, false, true>), dim3(grid), dim3(256), 0, s, L, points,
+                                         gfeatures, gpoints, total, d->N, d->row_stride, d->displacement,
+                                         d->align_corners));
+    }
+    if (!gv) continue;
+    if (L.C == 1) {  // level 0 (raw grid): scalar atomics
+      int64_t total = BN * 7;
+      hipLaunchKernelGGL((gather_bwd_kernel<1, true, false>), dim3((unsigned)svr::cdiv(total, 256)), dim3(256), 0, s, L,
+                         points, gfeatures, gpoints, total, d->N, d->row_stride, d->displacement, d->align_corners);
+      continue;
+    }
+    {
+      int cw = L.C < 64 ? L.C : 64;
+      int g = 64 / cw, cgn = L.C / cw, pg = 2 * cw;
+      int64_t chunks = svr::cdiv(BN, (int64_t)g * pg);
+      int64_t waves = chunks * 7 * cgn;
+      unsigned grid = (unsigned)svr::cdiv(waves * 64, 256);
+      switch (L.C) {
+        case 16: hipLaunchKernelGGL(gather_bwd_runs_kernel<16>, dim3(grid), dim3(256), 0, s, L, points, gfeatures, d->order, BN, d->N, d->row_stride, d->displacement, d->align_corners, waves); break;
+        case 32: hipLaunchKernelGGL(gather_bwd_runs_kernel<32>, dim3(grid), dim3(256), 0, s, L, points, gfeatures, d->order, BN, d->N, d->row_stride, d->displacement, d->align_corners, waves); break;
+        case 64: hipLaunchKernelGGL(gather_bwd_runs_kernel<64>, dim3(grid), dim3(256), 0, s, L, points, gfeatures, d->order, BN, d->N, d->row_stride, d->displacement, d->align_corners, waves); break;
+        case 128: hipLaunchKernelGGL(gather_bwd_runs_kernel<128>, dim3(grid), dim3(256), 0, s, L, points, gfeatures, d->order, BN, d->N, d->row_stride, d->displacement, d->align_corners, waves); break;
+      }
+    }
   }
   return svr::launch_status("gather_bwd");
 }

@@ -125,23 +125,57 @@ __global__ void slab_reduce_kernel(const float *__restrict__ slab, float *__rest
   out[(idx / cols) * ldo + (idx % cols)] = s;
 }
 
-// Column sums: part[chunk][n] = sum over the chunk's rows of Y[m][n]
-__global__ void colsum_partial_kernel(const float *__restrict__ Y, int64_t ldy, float *__restrict__ part, int64_t M,
-                                      int64_t N, int64_t rows_per_chunk) {
-  int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (n >= N) return;
-  int64_t r0 = (int64_t)blockIdx.y * rows_per_chunk, r1 = min(M, r0 + rows_per_chunk);
-  float s = 0.f;
-  for (int64_t m = r0; m < r1; ++m) s += Y[m * ldy + n];
-  part[(int64_t)blockIdx.y * N + n] = s;
+// Column sums: part[chunk][n] = sum over the chunk's rows of Y[m][n].
+// thread -> (row lane, column quad): float4 loads, a wave reads whole rows; LDS tree at the end.
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float *__restrict__ Y, int64_t ldy,
+                                                             float *__restrict__ part, int64_t M, int64_t N,
+                                                             int64_t rows_per_chunk) {
+  const int Q = (int)(N / 4);          // host guarantees Q | 256
+  const int q = threadIdx.x % Q, rl = threadIdx.x / Q, RL = 256 / Q;
+  int64_t r0 = (int64_t)blockIdx.x * rows_per_chunk, r1 = min(M, r0 + rows_per_chunk);
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int64_t m = r0 + rl; m < r1; m += RL) {
+    float4 v = *reinterpret_cast<const float4 *>(Y + m * ldy + q * 4);
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  }
+  __shared__ float4 red[256];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  if ((int)threadIdx.x < Q) {
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = 0; k < RL; ++k) {
+      float4 v = red[k * Q + q];
+      a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+    *reinterpret_cast<float4 *>(part + (int64_t)blockIdx.x * N + q * 4) = a;
+  }
 }
 
-__global__ void colsum_final_kernel(const float *__restrict__ part, float *__restrict__ out, int64_t N, int chunks) {
-  int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+// generic fallback (any N): one thread per column
+__global__ void colsum_partial_slow_kernel(const float *__restrict__ Y, int64_t ldy, float *__restrict__ part, int64_t M,
+                                           int64_t N, int64_t rows_per_chunk) {
+  int64_t n = (int64_t)blockIdx.y * blockDim.x + threadIdx.x;
   if (n >= N) return;
+  int64_t r0 = (int64_t)blockIdx.x * rows_per_chunk, r1 = min(M, r0 + rows_per_chunk);
+  float s = 0.f;
+  for (int64_t m = r0; m < r1; ++m) s += Y[m * ldy + n];
+  part[(int64_t)blockIdx.x * N + n] = s;
+}
+
+// out[n] = sum_chunks part[chunk][n]: one workgroup per column, f64 tree (fixed order: reproducible)
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float *__restrict__ part, float *__restrict__ out,
+                                                           int64_t N, int chunks) {
+  const int64_t n = blockIdx.x;
   double s = 0.0;
-  for (int c = 0; c < chunks; ++c) s += (double)part[(int64_t)c * N + n];
-  out[n] = (float)s;
+  for (int c = threadIdx.x; c < chunks; c += 256) s += (double)part[(int64_t)c * N + n];
+  __shared__ double red[256];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[n] = (float)red[0];
 }
 
 // fc_out forward: 16 lanes per row, float4 loads.
@@ -188,14 +222,22 @@ __global__ __launch_bounds__(256) void fc_out_bwd_kernel(const float *__restrict
   }
 }
 
-__global__ void fc_out_bwd_final_kernel(const float *__restrict__ part, float *__restrict__ dw, float *__restrict__ db,
-                                        int64_t K, int blocks) {
-  int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (k > K) return;
+__global__ __launch_bounds__(256) void fc_out_bwd_final_kernel(const float *__restrict__ part, float *__restrict__ dw,
+                                                               float *__restrict__ db, int64_t K, int blocks) {
+  const int64_t k = blockIdx.x;  // 0..K (K = the bias slot)
   double s = 0.0;
-  for (int b = 0; b < blocks; ++b) s += (double)part[(int64_t)b * (K + 1) + k];
-  if (k < K) dw[k] = (float)s;
-  else if (db) db[0] = (float)s;
+  for (int b = threadIdx.x; b < blocks; b += 256) s += (double)part[(int64_t)b * (K + 1) + k];
+  __shared__ double red[256];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    if (k < K) dw[k] = (float)red[0];
+    else if (db) db[0] = (float)red[0];
+  }
 }
 
 // BCE with logits: per-sample sums (double) then mean over the batch.
@@ -248,17 +290,25 @@ int tn_splits(int64_t M, int64_t N, int64_t K, int *steps_per_split) {
   return (int)splits;
 }
 
-constexpr int64_t COLSUM_CHUNK = 2048;
 
 }  // namespace
 
 namespace svr {
-int64_t colsum_workspace_floats(int64_t M, int64_t N) { return cdiv(M > 0 ? M : 1, COLSUM_CHUNK) * N; }
+static int64_t colsum_rows_per_chunk(int64_t M) {
+  int64_t r = cdiv(M > 0 ? M : 1, 2048);
+  return r < 256 ? 256 : r;
+}
+int64_t colsum_workspace_floats(int64_t M, int64_t N) { return cdiv(M > 0 ? M : 1, colsum_rows_per_chunk(M)) * N; }
 // out[n] = sum_m Y[m][n]; part: colsum_workspace_floats(M, N) floats
 void colsum_launch(const float *Y, int64_t ldy, float *out, float *part, int64_t M, int64_t N, hipStream_t s) {
-  int chunks = (int)cdiv(M, COLSUM_CHUNK);
-  hipLaunchKernelGGL(colsum_partial_kernel, dim3((unsigned)cdiv(N, 64), (unsigned)chunks), dim3(64), 0, s, Y, ldy, part, M, N, COLSUM_CHUNK);
-  hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)cdiv(N, 64)), dim3(64), 0, s, part, out, N, chunks);
+  int64_t rpc = colsum_rows_per_chunk(M);
+  int chunks = (int)cdiv(M, rpc);
+  bool vec = N % 4 == 0 && N / 4 <= 256 && 256 % (N / 4) == 0 && ldy % 4 == 0 && ((uintptr_t)Y & 15) == 0;
+  if (vec)
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3((unsigned)chunks), dim3(256), 0, s, Y, ldy, part, M, N, rpc);
+  else
+    hipLaunchKernelGGL(colsum_partial_slow_kernel, dim3((unsigned)chunks, (unsigned)cdiv(N, 64)), dim3(64), 0, s, Y, ldy, part, M, N, rpc);
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)N), dim3(256), 0, s, part, out, N, chunks);
 }
 }  // namespace svr
 
@@ -294,8 +344,7 @@ extern "C" int svr_linear_bwd_data(const float *dY, int64_t lddy, const float *W
 extern "C" int64_t svr_linear_bwd_weight_workspace(int64_t M, int64_t N, int64_t K) {
   int sps;
   int splits = tn_splits(M, N, K, &sps);
-  int64_t chunks = cdiv(M > 0 ? M : 1, COLSUM_CHUNK);
-  return ((int64_t)splits * N * K + chunks * N) * (int64_t)sizeof(float);
+  return ((int64_t)splits * N * K + colsum_workspace_floats(M, N)) * (int64_t)sizeof(float);
 }
 
 extern "C" int svr_linear_bwd_weight(const float *dY, int64_t lddy, const float *X, int64_t ldx, float *dW, int64_t lddw,
@@ -335,7 +384,7 @@ extern "C" int svr_fc_out_bwd(const float *H, int64_t ldh, const float *w, const
   int blocks = (int)cdiv(M, FCO_ROWS);
   float *part = (float *)workspace;
   hipLaunchKernelGGL(fc_out_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, s, H, ldh, w, dlogits, dH, lddh, part, M, K, FCO_ROWS);
-  hipLaunchKernelGGL(fc_out_bwd_final_kernel, dim3((unsigned)cdiv(K + 1, 256)), dim3(256), 0, s, part, dw, db, K, blocks);
+  hipLaunchKernelGGL(fc_out_bwd_final_kernel, dim3((unsigned)(K + 1)), dim3(256), 0, s, part, dw, db, K, blocks);
   return launch_status("fc_out_bwd");
 }
 

@@ -1,0 +1,70 @@
+"""Batch-sharded data parallelism for the IF-Net training step: one process per GPU, parameters
+replicated, every rank runs the hot path on its own samples, and ONE sum all-reduce of a flat
+fp32 gradient bucket per step (RCCL over xGMI through torch.distributed's "nccl" backend; "gloo"
+on CPU for the tests).  The reference has no distributed code at all; this is the
+build's §8(e) row.  BatchNorm statistics stay per-GPU (what the reference computes at that batch
+size); running statistics are whatever the local rank saw.
+
+The bucket owns the memory: every parameter's .grad is a view into one flat tensor, so the
+all-reduce needs no gather/scatter copies and the (fused) optimizer reads the reduced gradients
+in place.  10.2 MB for IF-Net: a ring over 7 xGMI links moves it in ~120 us, far below the step
+time, so a single un-overlapped collective is the right size.
+"""
+import torch
+import torch.distributed as dist
+
+
+class GradBucket:
+    def __init__(self, params, device=None, dtype=torch.float32):
+        self.params = [p for p in params if p.requires_grad]
+        dev = device if device is not None else self.params[0].device
+        self.numel = sum(p.numel() for p in self.params)
+        self.flat = torch.zeros(self.numel, device=dev, dtype=dtype)
+        off = 0
+        for p in self.params:
+            n = p.numel()
+            p.grad = self.flat[off:off + n].view_as(p)
+            off += n
+
+    def zero(self):
+        self.flat.zero_()
+
+    def all_reduce_mean(self, group=None):
+        """Sum over ranks then divide by the world size (mean of per-rank batch means = global
+        batch mean for equal shards, trainer/trainer_ifnet.py:46)."""
+        if dist.is_available() and dist.is_initialized():
+            world = dist.get_world_size(group)
+            if world > 1:
+                dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
+                self.flat.div_(world)
+        return self.flat
+
+
+def broadcast_parameters(module, src=0, group=None):
+    """Make every rank start from rank `src`'s parameters and buffers."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return
+    with torch.no_grad():
+        for t in list(module.parameters()) + list(module.buffers()):
+            dist.broadcast(t.data, src=src, group=group)
+
+
+class DataParallelTrainer:
+    """Drives ``trainer.training_step`` (the reference's LightningModule contract) data-parallel:
+    zero bucket -> training_step -> backward -> all-reduce(mean) -> optimizer step."""
+
+    def __init__(self, trainer, optimizer=None, group=None, sync_params=True):
+        self.trainer = trainer
+        self.group = group
+        if sync_params:
+            broadcast_parameters(trainer, 0, group)
+        self.bucket = GradBucket(list(trainer.parameters()))
+        self.optimizer = optimizer if optimizer is not None else trainer.configure_optimizers()[0][0]
+
+    def step(self, batch, batch_idx=0):
+        self.bucket.zero()
+        out = self.trainer.training_step(batch, batch_idx)
+        out["loss"].backward()
+        self.bucket.all_reduce_mean(self.group)
+        self.optimizer.step()
+        return out

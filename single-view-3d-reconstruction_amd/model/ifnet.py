@@ -73,8 +73,9 @@ class _EncoderGatherFn(torch.autograd.Function):
             levels.append(y)
             saved.append((inp, acts, packed, argmax, ss, mean))
             inp = pooled
-        feat = ops.gather_fwd(levels, pts, ext._layout, ext._disp, ext._align)
-        ctx.ext, ctx.saved, ctx.levels, ctx.pts = ext, saved, levels, pts
+        order = ops.morton_order(pts)          # processing order only; rows keep the caller's order
+        feat = ops.gather_fwd(levels, pts, ext._layout, ext._disp, ext._align, order=order)
+        ctx.ext, ctx.saved, ctx.levels, ctx.pts, ctx.order = ext, saved, levels, pts, order
         ctx.x_shape = x.shape
         ctx.training = training
         return feat
@@ -87,7 +88,8 @@ class _EncoderGatherFn(torch.autograd.Function):
         need_x, need_pts = ctx.needs_input_grad[1], ctx.needs_input_grad[2]
         gfeat = gfeat.contiguous()
         gvols = [torch.zeros_like(levels[0]) if need_x else None] + [torch.zeros_like(v) for v in levels[1:]]
-        gpts = ops.gather_bwd(levels, gvols, pts, gfeat, ext._layout, ext._disp, ext._align, want_gpoints=need_pts)
+        gpts = ops.gather_bwd(levels, gvols, pts, gfeat, ext._layout, ext._disp, ext._align, want_gpoints=need_pts,
+                              order=ctx.order)
         grads = {}
         dpooled = None
         gx = None

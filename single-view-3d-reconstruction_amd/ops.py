@@ -59,8 +59,20 @@ class FeatureLayout:
         return perm
 
 
-def make_gather_desc(vols, gvols, layout, B, N, displacement, align_corners):
+def morton_order(points):
+    """(B*N,) int32 processing order: points of one sample sorted by a 64^3 Morton code."""
+    _f32(points)
+    B, N, _ = points.shape
+    l = _lib.lib()
+    order = torch.empty(B * N, device=points.device, dtype=torch.int32)
+    ws = torch.empty(l.svr_points_morton_order_workspace(B, N), device=points.device, dtype=torch.uint8)
+    check(l.svr_points_morton_order(_p(points), _p(order), B, N, _p(ws), _stream()), "morton_order")
+    return order
+
+
+def make_gather_desc(vols, gvols, layout, B, N, displacement, align_corners, order=None):
     d = GatherDesc()
+    d.order = _p(order)
     d.n_levels = len(vols)
     d.B, d.N = B, N
     d.row_stride = layout.row_stride
@@ -79,19 +91,19 @@ def make_gather_desc(vols, gvols, layout, B, N, displacement, align_corners):
     return d
 
 
-def gather_fwd(vols, points, layout, displacement, align_corners, out=None):
+def gather_fwd(vols, points, layout, displacement, align_corners, out=None, order=None):
     B, N, _ = points.shape
     _f32(points)
-    d = make_gather_desc(vols, None, layout, B, N, displacement, align_corners)
+    d = make_gather_desc(vols, None, layout, B, N, displacement, align_corners, order)
     if out is None:
         out = torch.zeros(B * N, layout.row_stride, device=points.device, dtype=torch.float32)
     check(_lib.lib().svr_gather_trilinear_fwd(C.byref(d), _p(points), _p(out), _stream()), "gather_fwd")
     return out
 
 
-def gather_bwd(vols, gvols, points, gfeat, layout, displacement, align_corners, want_gpoints=False):
+def gather_bwd(vols, gvols, points, gfeat, layout, displacement, align_corners, want_gpoints=False, order=None):
     B, N, _ = points.shape
-    d = make_gather_desc(vols, gvols, layout, B, N, displacement, align_corners)
+    d = make_gather_desc(vols, gvols, layout, B, N, displacement, align_corners, order)
     gp = torch.empty_like(points) if want_gpoints else None
     check(_lib.lib().svr_gather_trilinear_bwd(C.byref(d), _p(points), _p(gfeat), _p(gp), _stream()), "gather_bwd")
     return gp

@@ -212,3 +212,40 @@ def test_bn_pool_fwd_bwd(B, dims, C, pool):
     ye_ref = F.batch_norm(x.detach(), rm, rv, gamma.detach(), beta.detach(), False, 0.1, 1e-5)
     ye = ops.bn_forward(_cl(x.detach()), gamma.detach().cuda(), beta.detach().cuda(), rm_g, rv_g, False, want_pool=False)[0]
     assert G.rel_err(_ncdhw(ye).numpy(), ye_ref.numpy()) < 2e-6
+
+
+def test_morton_order_is_a_permutation_and_gather_is_order_independent():
+    ops = _ops()
+    chans = [1, 16, 32, 64, 128, 128]
+    B, dims, N = 3, (16, 16, 16), 1000
+    vols = _rand_levels(B, dims, chans, 21)
+    g = torch.Generator().manual_seed(22)
+    pts = (torch.rand(B, N, 3, generator=g) - 0.5) * 1.2
+    pts[0, 0, 0] = float("nan")
+    order = ops.morton_order(pts.cuda())
+    o = order.cpu().long()
+    assert sorted(o.tolist()) == list(range(B * N))                 # a permutation
+    assert torch.equal(o // N, torch.arange(B).repeat_interleave(N))  # samples stay contiguous
+    # Morton keys non-decreasing inside a sample
+    q = ((pts.reshape(-1, 3)[o] + 0.5) * 64).clamp(0, 63).nan_to_num(0).long()
+    def spread(v):
+        out = torch.zeros_like(v)
+        for bit in range(6):
+            out |= ((v >> bit) & 1) << (3 * bit)
+        return out
+    key = spread(q[:, 2]) | (spread(q[:, 1]) << 1) | (spread(q[:, 0]) << 2)
+    key = key + (o // N) * (1 << 18)
+    assert bool((key[1:] >= key[:-1]).all())
+    layout = ops.FeatureLayout(chans)
+    vols_g = [_cl(v) for v in vols]
+    pts_g = pts.nan_to_num(0.1).cuda()
+    a = ops.gather_fwd(vols_g, pts_g, layout, float(np.float32(0.0722)), False)
+    b = ops.gather_fwd(vols_g, pts_g, layout, float(np.float32(0.0722)), False, order=order)
+    assert torch.equal(a, b)
+    gf = torch.randn(B * N, layout.row_stride, generator=g).cuda()
+    g1 = [torch.zeros_like(v) for v in vols_g]
+    g2 = [torch.zeros_like(v) for v in vols_g]
+    ops.gather_bwd(vols_g, g1, pts_g, gf, layout, float(np.float32(0.0722)), False)
+    ops.gather_bwd(vols_g, g2, pts_g, gf, layout, float(np.float32(0.0722)), False, order=order)
+    for x1, x2 in zip(g1, g2):
+        assert G.rel_err(x2.cpu().numpy(), x1.cpu().numpy()) < 1e-5
