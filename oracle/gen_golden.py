@@ -134,6 +134,54 @@ def project_case(project, tag, seed, B, dims, kernel, sigma, scale):
           f"sigma_grad={out['sigma_grad']} size={os.path.getsize(path)/1024:.0f} KiB")
 
 
+def scene_case(Unet, project, IFNet, tag, seed, B, scale, N):
+    """The reference modules composed exactly like SceneNetTrainer.forward / losses_and_logging
+    (trainer/trainer_scene_net.py:69-103,147-149; the LightningModule itself needs pytorch_lightning)."""
+    from oracle import scene_oracle as S
+    import torch.nn.functional as F
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    rgb = torch.rand(B, 3, 256, 256, generator=g) * 2 - 1
+    target = torch.rand(B, 240, 320, generator=g) * 5 + 0.5
+    pts = torch.rand(B, N, 3, generator=g) - 0.5
+    occ = (torch.rand(B, N, generator=g) < 0.5).float()
+    dims = (torch.tensor([139, 104, 112]) / scale).round().long()
+    min_z, max_z = 0.1953997164964676, 7.0
+    unet = Unet(channels_in=3, channels_out=1)
+    unet.load_state_dict(S.name_seeded_like(unet.state_dict(), 1.0, "unet."), strict=False)
+    proj = project(dims, [3, 3, 3], torch.tensor([1.5, 1.5, 1.5]))
+    ifnet = IFNet()
+    ifnet.load_state_dict(O.name_seeded_state(128, GAIN), strict=False)
+    unet.train(); ifnet.train()
+    raw = unet(rgb)
+    z = F.interpolate(raw, size=320, mode="bilinear")[:, :, 40:280, :].squeeze(1)
+    depth = torch.sigmoid(z) * (max_z - min_z) + min_z
+    pc = proj.depthmap_to_gridspace(depth, scale)
+    pc = proj.norm_grid_space(pc)
+    vox = proj(pc)
+    logits = ifnet(vox, pts)
+    ce = F.binary_cross_entropy_with_logits(logits, occ, reduction="mean")
+    mse = F.mse_loss(depth, target, reduction="mean")
+    loss = ce + mse
+    loss.backward()
+    out = {
+        "meta": np.array([seed, B, scale, N, int(dims[0]), int(dims[1]), int(dims[2])], dtype=np.int64),
+        "gain": np.float32(GAIN), "points": pts.numpy(), "occupancies": occ.numpy().astype(np.uint8),
+        "rgb_s": sample(rgb), "target_s": sample(target),
+        "depth_s": sample(depth, 8192), "pc_s": sample(pc, 8192), "vox_s": sample(vox, 16384),
+        "vox_sum": np.float64(vox.double().sum().item()),
+        "logits": logits.detach().numpy(), "ce": np.float64(ce.item()), "mse": np.float64(mse.item()),
+        "loss": np.float64(loss.item()), "sigma_grad": proj.sigma.grad.numpy().copy(),
+    }
+    for prefix, mod in (("unet.", unet), ("ifnet.", ifnet)):
+        for name, p in mod.named_parameters():
+            out["grad_norm/" + prefix + name] = np.float64(p.grad.double().norm().item())
+            out["grad/" + prefix + name] = sample(p.grad, 256)
+    path = os.path.join(OUT, f"scene_{tag}.npz")
+    np.savez_compressed(path, **out)
+    print(f"{path}: loss={loss.item():.6f} ce={ce.item():.6f} mse={mse.item():.6f} vox_sum={out['vox_sum']:.2f} "
+          f"sigma_grad={out['sigma_grad']} size={os.path.getsize(path)/1024:.0f} KiB")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--net_res", type=int, default=128)
@@ -157,6 +205,8 @@ def main():
         project_case(project, "full", 105, 2, (139, 104, 112), (3, 3, 3), (1.5, 1.5, 1.5), 1)
         project_case(project, "half", 106, 1, (70, 52, 56), (11, 9, 9), (2.0, 1.5, 1.0), 2)
         project_case(project, "cube", 107, 2, (48, 40, 56), (5, 3, 3), (0.8, 1.2, 1.7), 2)
+        from model.unet import Unet
+        scene_case(Unet, project, IFNet, "cfg5small", 131, 2, 4, 300)
     else:
         ifnet_case(IFNet, 32, "res32", 121, 2, (16, 12, 20), 512, spread=1.1)
 

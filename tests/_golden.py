@@ -50,3 +50,14 @@ def project_inputs(z):
 def state(net_res, gain=None, z=None):
     g = float(z["gain"]) if z is not None else (gain or 3.0)
     return O.name_seeded_state(net_res, g)
+
+
+def scene_inputs(z):
+    seed, B, scale, N, d0, d1, d2 = (int(v) for v in z["meta"])
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    rgb = torch.rand(B, 3, 256, 256, generator=g) * 2 - 1
+    target = torch.rand(B, 240, 320, generator=g) * 5 + 0.5
+    assert np.array_equal(sample(rgb), z["rgb_s"]) and np.array_equal(sample(target), z["target_s"])
+    batch = {"rgb": rgb, "depthmap_target": target, "points": torch.from_numpy(z["points"].copy()),
+             "occupancies": torch.from_numpy(z["occupancies"].astype(np.float32))}
+    return batch, (d0, d1, d2), scale
