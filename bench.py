@@ -39,13 +39,22 @@ def cpu_baseline(D, N, max_seconds=40.0):
     threads = torch.get_num_threads()
     b = synth_batch(103, 1, D, N, "cpu")
     st = O.make_leaf_state(O.name_seeded_state(128))
-    t0 = time.perf_counter()
-    out = O.training_step(st, b, 128)
-    out["loss"].backward()
-    dt = time.perf_counter() - t0
+    times = []
+    t_all = time.perf_counter()
+    for rep in range(3):                                  # first repetition doubles as the warm-up
+        for v in st.values():
+            v.grad = None
+        t0 = time.perf_counter()
+        out = O.training_step(st, b, 128)
+        out["loss"].backward()
+        times.append(time.perf_counter() - t0)
+        if time.perf_counter() - t_all > max_seconds:
+            break
+    dt = min(times)
     return {"value": N / dt, "unit": "query-points/s", "cores": threads, "kind": "port",
-            "sample": f"1 sample of the workload (B=1, {D}^3 grid, {N} points), fwd+bwd once, {dt:.1f} s, "
-                      f"torch CPU ops with {threads} threads (oracle/ifnet_oracle.py)"}
+            "sample": f"1 sample of the workload (B=1, {D}^3 grid, {N} points), fwd+bwd, best of {len(times)} "
+                      f"repetitions ({', '.join(f'{t:.1f}' for t in times)} s), torch CPU ops with {threads} threads "
+                      "(oracle/ifnet_oracle.py)"}
 
 
 def main():
@@ -142,7 +151,7 @@ def main():
                                    f"{a.batch}/GPU, full 3D conv encoder + 6-level trilinear gather + occupancy MLP, "
                                    "fwd+bwd+grad all-reduce+Adam",
                        "global_batch": world * a.batch, "parallelism": f"dp{world}", "loss": loss},
-            "roofline": {"kernel": "svr_gather_trilinear_fwd (6 levels)", "bound": "hbm", "achieved": achieved,
+            "roofline": {"kernel": "gather_fwd_fused_kernel (svr_gather_trilinear_fwd, all 6 levels in one launch)", "bound": "hbm", "achieved": achieved,
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                          "ms_per_launch": gather_ms, "algorithmic_bytes_per_launch": alg_bytes, "traffic": traffic},
         }

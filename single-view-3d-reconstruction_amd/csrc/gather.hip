@@ -75,12 +75,19 @@ __device__ __forceinline__ Weights corner_weights(const Corner &c) {
   return w;
 }
 
+// All levels run in ONE launch: the grid is the concatenation of the per-level block ranges.
+struct FusedArgs {
+  LevelArgs L[SVR_MAX_LEVELS];
+  unsigned block_start[SVR_MAX_LEVELS + 1];
+  int n;
+};
+
 template <int C>
-__global__ __launch_bounds__(256) void gather_fwd_kernel(LevelArgs L, const float *__restrict__ points,
-                                                         float *__restrict__ feat, const int32_t *__restrict__ order,
-                                                         int64_t total, int N, int row_stride, float disp, int ac) {
+__device__ __forceinline__ void gather_fwd_body(const LevelArgs &L, const float *__restrict__ points,
+                                                float *__restrict__ feat, const int32_t *__restrict__ order,
+                                                int64_t gid, int64_t total, int N, int row_stride, float disp,
+                                                int ac) {
   constexpr int V = (C >= 4) ? C / 4 : 1;
-  int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (gid >= total) return;
   int q = (int)(gid % V);
   int j = (int)((gid / V) % 7);
@@ -124,6 +131,25 @@ __global__ __launch_bounds__(256) void gather_fwd_kernel(LevelArgs L, const floa
           }
         }
     feat[pn * row_stride + L.col + j] = acc;
+  }
+}
+
+__global__ __launch_bounds__(256) void gather_fwd_fused_kernel(FusedArgs A, const float *__restrict__ points,
+                                                               float *__restrict__ feat,
+                                                               const int32_t *__restrict__ order, int64_t BN, int N,
+                                                               int row_stride, float disp, int ac) {
+  int l = 0;
+  while (l + 1 < A.n && blockIdx.x >= A.block_start[l + 1]) ++l;
+  const LevelArgs &L = A.L[l];
+  const int64_t gid = (int64_t)(blockIdx.x - A.block_start[l]) * 256 + threadIdx.x;
+  const int V = L.C >= 4 ? L.C / 4 : 1;
+  const int64_t total = BN * 7 * V;
+  switch (L.C) {
+    case 1: gather_fwd_body<1>(L, points, feat, order, gid, total, N, row_stride, disp, ac); break;
+    case 16: gather_fwd_body<16>(L, points, feat, order, gid, total, N, row_stride, disp, ac); break;
+    case 32: gather_fwd_body<32>(L, points, feat, order, gid, total, N, row_stride, disp, ac); break;
+    case 64: gather_fwd_body<64>(L, points, feat, order, gid, total, N, row_stride, disp, ac); break;
+    case 128: gather_fwd_body<128>(L, points, feat, order, gid, total, N, row_stride, disp, ac); break;
   }
 }
 
@@ -216,18 +242,18 @@ __device__ __forceinline__ float corner_w(const Weights &w, int k) {
 }
 
 template <int C>
-__global__ __launch_bounds__(256) void gather_bwd_runs_kernel(LevelArgs L, const float *__restrict__ points,
-                                                              const float *__restrict__ gfeat,
-                                                              const int32_t *__restrict__ order, int64_t BN, int N,
-                                                              int row_stride, float disp, int ac, int64_t waves) {
+__device__ __forceinline__ void gather_bwd_runs_body(const LevelArgs &L, const float *__restrict__ points,
+                                                     const float *__restrict__ gfeat,
+                                                     const int32_t *__restrict__ order, int64_t BN, int N,
+                                                     int row_stride, float disp, int ac, int64_t item,
+                                                     int64_t waves) {
   constexpr int CW = C < 64 ? C : 64;  // channels per lane group
   constexpr int G = 64 / CW;           // independent runs per wave
   constexpr int CG = C / CW;           // channel groups per sample
   constexpr int PG = 2 * CW;           // consecutive points per run group
   const int lane = threadIdx.x & 63;
   const int ch = lane % CW, grp = lane / CW;
-  const int64_t item = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;  // wave-uniform (chunk, j, cg)
-  if (item >= waves) return;
+  if (item >= waves) return;  // item: wave-uniform (chunk, j, cg)
   const int cg = (int)(item % CG);
   const int j = (int)((item / CG) % 7);
   const int64_t chunk = item / (7 * CG);
@@ -272,6 +298,29 @@ __global__ __launch_bounds__(256) void gather_bwd_runs_kernel(LevelArgs L, const
     for (int k = 0; k < 8; ++k) acc[k] += g * corner_w(w, k);
   }
   flush();
+}
+
+__host__ __device__ inline int64_t bwd_runs_waves(int C, int64_t BN) {
+  int cw = C < 64 ? C : 64;
+  int64_t chunks = (BN + (int64_t)(64 / cw) * 2 * cw - 1) / ((int64_t)(64 / cw) * 2 * cw);
+  return chunks * 7 * (C / cw);
+}
+
+__global__ __launch_bounds__(256) void gather_bwd_fused_kernel(FusedArgs A, const float *__restrict__ points,
+                                                               const float *__restrict__ gfeat,
+                                                               const int32_t *__restrict__ order, int64_t BN, int N,
+                                                               int row_stride, float disp, int ac) {
+  int l = 0;
+  while (l + 1 < A.n && blockIdx.x >= A.block_start[l + 1]) ++l;
+  const LevelArgs &L = A.L[l];
+  const int64_t item = ((int64_t)(blockIdx.x - A.block_start[l]) * 256 + threadIdx.x) >> 6;
+  const int64_t waves = bwd_runs_waves(L.C, BN);
+  switch (L.C) {
+    case 16: gather_bwd_runs_body<16>(L, points, gfeat, order, BN, N, row_stride, disp, ac, item, waves); break;
+    case 32: gather_bwd_runs_body<32>(L, points, gfeat, order, BN, N, row_stride, disp, ac, item, waves); break;
+    case 64: gather_bwd_runs_body<64>(L, points, gfeat, order, BN, N, row_stride, disp, ac, item, waves); break;
+    case 128: gather_bwd_runs_body<128>(L, points, gfeat, order, BN, N, row_stride, disp, ac, item, waves); break;
+  }
 }
 
 __global__ void corner_index_kernel(const float *__restrict__ points, int32_t *__restrict__ out,
@@ -328,14 +377,23 @@ extern "C" int svr_gather_trilinear_fwd(const svr_gather_desc *d, const float *p
   hipStream_t s = (hipStream_t)stream;
   int64_t BN = (int64_t)d->B * d->N;
   if (BN == 0) return SVR_OK;
-  for (int l = 0; l < d->n_levels; ++l) {
-    LevelArgs L = level_args(d->level[l]);
-    int V = L.C >= 4 ? L.C / 4 : 1;
-    int64_t total = BN * 7 * V;
-    unsigned grid = (unsigned)svr::cdiv(total, 256);
-    DISPATCH_C(L.C, hipLaunchKernelGGL(gather_fwd_kernel<CC>, dim3(grid), dim3(256), 0, s, L, points, features, d->order,
-                                       total, d->N, d->row_stride, d->displacement, d->align_corners));
-  }
+  // one launch; widest levels first so the long workgroups are scheduled early
+  FusedArgs A;
+  A.n = 0;
+  unsigned blocks = 0;
+  for (int pass = 0; pass < 2; ++pass)
+    for (int l = d->n_levels - 1; l >= 0; --l) {
+      if ((d->level[l].C >= 4) != (pass == 0)) continue;
+      LevelArgs L = level_args(d->level[l]);
+      int V = L.C >= 4 ? L.C / 4 : 1;
+      A.L[A.n] = L;
+      A.block_start[A.n] = blocks;
+      blocks += (unsigned)svr::cdiv(BN * 7 * V, 256);
+      ++A.n;
+    }
+  A.block_start[A.n] = blocks;
+  hipLaunchKernelGGL(gather_fwd_fused_kernel, dim3(blocks), dim3(256), 0, s, A, points, features, d->order, BN, d->N,
+                     d->row_stride, d->displacement, d->align_corners);
   return svr::launch_status("gather_fwd");
 }
 
@@ -350,7 +408,10 @@ extern "C" int svr_gather_trilinear_bwd(const svr_gather_desc *d, const float *p
     hipError_t e = hipMemsetAsync(gpoints, 0, (size_t)BN * 3 * sizeof(float), s);
     SVR_CHECK(e == hipSuccess, (int)e, "gather_bwd: memset failed: %s", hipGetErrorString(e));
   }
-  for (int l = 0; l < d->n_levels; ++l) {
+  FusedArgs FA;
+  FA.n = 0;
+  unsigned fblocks = 0;
+  for (int l = d->n_levels - 1; l >= 0; --l) {
     LevelArgs L = level_args(d->level[l]);
     bool gv = L.gvol != nullptr;
     if (!gv && !gpoints) continue;
@@ -370,19 +431,15 @@ extern "C" int svr_gather_trilinear_bwd(const svr_gather_desc *d, const float *p
                          points, gfeatures, gpoints, total, d->N, d->row_stride, d->displacement, d->align_corners);
       continue;
     }
-    {
-      int cw = L.C < 64 ? L.C : 64;
-      int g = 64 / cw, cgn = L.C / cw, pg = 2 * cw;
-      int64_t chunks = svr::cdiv(BN, (int64_t)g * pg);
-      int64_t waves = chunks * 7 * cgn;
-      unsigned grid = (unsigned)svr::cdiv(waves * 64, 256);
-      switch (L.C) {
-        case 16: hipLaunchKernelGGL(gather_bwd_runs_kernel<16>, dim3(grid), dim3(256), 0, s, L, points, gfeatures, d->order, BN, d->N, d->row_stride, d->displacement, d->align_corners, waves); break;
-        case 32: hipLaunchKernelGGL(gather_bwd_runs_kernel<32>, dim3(grid), dim3(256), 0, s, L, points, gfeatures, d->order, BN, d->N, d->row_stride, d->displacement, d->align_corners, waves); break;
-        case 64: hipLaunchKernelGGL(gather_bwd_runs_kernel<64>, dim3(grid), dim3(256), 0, s, L, points, gfeatures, d->order, BN, d->N, d->row_stride, d->displacement, d->align_corners, waves); break;
-        case 128: hipLaunchKernelGGL(gather_bwd_runs_kernel<128>, dim3(grid), dim3(256), 0, s, L, points, gfeatures, d->order, BN, d->N, d->row_stride, d->displacement, d->align_corners, waves); break;
-      }
-    }
+    FA.L[FA.n] = L;
+    FA.block_start[FA.n] = fblocks;
+    fblocks += (unsigned)svr::cdiv(bwd_runs_waves(L.C, BN) * 64, 256);
+    ++FA.n;
+  }
+  if (FA.n > 0) {
+    FA.block_start[FA.n] = fblocks;
+    hipLaunchKernelGGL(gather_bwd_fused_kernel, dim3(fblocks), dim3(256), 0, s, FA, points, gfeatures, d->order, BN, d->N,
+                       d->row_stride, d->displacement, d->align_corners);
   }
   return svr::launch_status("gather_bwd");
 }

@@ -163,6 +163,33 @@ class _ExtractorBase(nn.Module):
                 self._param_list += [c.weight, c.bias]
             self._param_list += [bn.weight, bn.bias]
 
+    @torch.no_grad()
+    def encode_levels(self, x):
+        """Inference only: the sampled pyramid [x, bn_1, ...] (channels-last), computed ONCE so dense-grid
+        evaluation does not redo the encoder per chunk (the reference recomputes it for every chunk,
+        model/ifnet.py:220-226).  Uses the module's current mode for BatchNorm (eval -> running stats)."""
+        if not x.is_cuda:
+            raise RuntimeError("IF-Net HIP path needs GPU tensors (no CPU fallback)")
+        B = x.shape[0]
+        D, H, W = x.shape[2:]
+        inp = x.float().contiguous().view(B, D, H, W, 1)
+        levels = [inp]
+        nst = len(self._stages)
+        for si, (convs, bn) in enumerate(self._stages):
+            cur = inp
+            for conv in convs:
+                wf, _ = ops.conv3d_pack_weight(conv.weight.detach(), want_bwd=False)
+                cur = ops.conv3d_k3(cur, wf, conv.bias.detach(), relu=True)
+            y, pooled, _, _, _ = ops.bn_forward(cur, bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var,
+                                                self.training, eps=bn.eps, momentum=bn.momentum, want_pool=(si + 1 < nst))
+            levels.append(y)
+            inp = pooled
+        return levels
+
+    @torch.no_grad()
+    def feature_rows_from_levels(self, levels, points, order=None):
+        return ops.gather_fwd(levels, points.float().contiguous(), self._layout, self._disp, self._align, order=order)
+
     def feature_rows(self, x, points):
         """(B*N, FS) rows in the internal column layout (what the point MLP consumes)."""
         if not x.is_cuda:
@@ -251,6 +278,21 @@ class IFNet(nn.Module):
         wz = torch.cat([w, w.new_zeros(w.shape[0], 1)], dim=1)
         return wz[:, torch.where(perm >= 0, perm, torch.full_like(perm, w.shape[1]))].contiguous()
 
+    @torch.no_grad()
+    def encode(self, x):
+        """Cache the feature pyramid of a grid for repeated queries (dense-grid inference)."""
+        return self.ifnet_feature_extractor.encode_levels(x)
+
+    @torch.no_grad()
+    def query(self, levels, points):
+        """Logits (B,N) for `points` against a pyramid from encode()."""
+        B, N = points.shape[0], points.shape[1]
+        rows = self.ifnet_feature_extractor.feature_rows_from_levels(levels, points)
+        h = ops.linear_fwd(rows, self._fc0_internal(), self.fc_0.bias, relu=True)
+        h = ops.linear_fwd(h, self.fc_1.weight.squeeze(2), self.fc_1.bias, relu=True)
+        h = ops.linear_fwd(h, self.fc_2.weight.squeeze(2), self.fc_2.bias, relu=True)
+        return ops.fc_out_fwd(h, self.fc_out.weight.reshape(-1).contiguous(), self.fc_out.bias).view(B, N)
+
     def forward(self, x, points):
         B, N = points.shape[0], points.shape[1]
         rows = self.ifnet_feature_extractor.feature_rows(x, points)
@@ -273,13 +315,20 @@ def make_3d_grid(bb_min, bb_max, shape, res_increase=1):
 
 
 def evaluate_network_on_grid(network, x, resolution, res_increase=1, points_batch_size=2048 * 16):
-    """Occupancy probabilities on the dense lattice (model/ifnet.py:215-229).  Results stay on the
-    device until the end (one D2H copy instead of one per chunk)."""
+    """Occupancy probabilities on the dense lattice (model/ifnet.py:215-229).
+
+    Same result as the reference loop, but the encoder pyramid is computed once (network.encode) instead of
+    once per chunk, the lattice is built on the device, and the values stay on the device until the single
+    D2H copy at the end (the reference does one per chunk, :226).  `network` in eval() mode reproduces the
+    reference's validation call; any module without encode()/query() falls back to network(x, chunk)."""
     pointsf = make_3d_grid((-0.5,) * 3, (0.5,) * 3, resolution, res_increase).to(x.device)
     values = []
     with torch.no_grad():
+        levels = network.encode(x) if hasattr(network, "encode") else None
         for pi in torch.split(pointsf, points_batch_size):
-            values.append(torch.sigmoid(network(x, pi.unsqueeze(0))).squeeze(0))
+            pi = pi.unsqueeze(0)
+            z = network.query(levels, pi) if levels is not None else network(x, pi)
+            values.append(torch.sigmoid(z).squeeze(0))
     value = torch.cat(values, dim=0).cpu().numpy()
     r = [int(s) * res_increase for s in resolution]
     return value.reshape(r[0], r[1], r[2])
