@@ -64,10 +64,11 @@ typedef struct svr_gather_desc {
  * (L2 locality, run-combining of atomics); outputs keep the caller's point order.
  * workspace: svr_points_morton_order_workspace() bytes.                                      */
 int64_t svr_points_morton_order_workspace(int32_t B, int32_t N);
-int svr_points_morton_order(const float *points, int32_t *order, int32_t B, int32_t N, void *workspace,
-                            void *stream);
+int svr_points_morton_order(const float *points, int32_t *order, float *sorted_points /* (B,N,3) or NULL */,
+                            int32_t B, int32_t N, void *workspace, void *stream);
 
-/* features[b*N+n][level.col + j*C + c] = trilinear sample j of channel c (zeros padding). */
+/* features[b*N+n][level.col + j*C + c] = trilinear sample j of channel c (zeros padding);
+ * columns past the last level (up to row_stride) are written as zeros.                      */
 int svr_gather_trilinear_fwd(const svr_gather_desc *d, const float *points /*(B,N,3)*/,
                              float *features, void *stream);
 /* gvol[level] += scatter of gfeatures (autograd of grid_sample wrt the volume);
@@ -103,15 +104,17 @@ int svr_linear_bwd_weight(const float *dY, int64_t lddy, const float *X, int64_t
                           int64_t lddw, float *db, int64_t M, int64_t N, int64_t K,
                           void *workspace, void *stream);
 
-/* fc_out (Conv1d(hidden,1,1), model/ifnet.py:35,58-59): logits[m] = H[m,:].w + b           */
+/* fc_out (Conv1d(hidden,1,1), model/ifnet.py:35,58-59): logits[r(m)] = H[m,:].w + b, where
+ * r(m) = row_map[m] if row_map != NULL (rows were processed in Morton order: scatter the logits back
+ * to the caller's point order) else m.                                                            */
 int svr_fc_out_fwd(const float *H, int64_t ldh, const float *w, const float *b, float *logits,
-                   int64_t M, int64_t K, void *stream);
-/* dH[m,k] = dlogits[m]*w[k]*(H[m,k]>0);  dw[k] = sum_m dlogits[m]*H[m,k];  db = sum dlogits.
- * workspace: svr_fc_out_bwd_workspace() bytes.                                            */
+                   const int32_t *row_map, int64_t M, int64_t K, void *stream);
+/* With g[m] = dlogits[r(m)]:  dH[m,k] = g[m]*w[k]*(H[m,k]>0);  dw[k] = sum_m g[m]*H[m,k];
+ * db = sum g.  workspace: svr_fc_out_bwd_workspace() bytes.                                 */
 int64_t svr_fc_out_bwd_workspace(int64_t M, int64_t K);
-int svr_fc_out_bwd(const float *H, int64_t ldh, const float *w, const float *dlogits, float *dH,
-                   int64_t lddh, float *dw, float *db, int64_t M, int64_t K, void *workspace,
-                   void *stream);
+int svr_fc_out_bwd(const float *H, int64_t ldh, const float *w, const float *dlogits,
+                   const int32_t *row_map, float *dH, int64_t lddh, float *dw, float *db, int64_t M,
+                   int64_t K, void *workspace, void *stream);
 
 /* BCE-with-logits, reduction 'none' -> sum over points -> mean over batch
  * (trainer/trainer_ifnet.py:46).  loss: 1 float; dlogits (B,N) = gscale*(sigmoid(z)-y)/B

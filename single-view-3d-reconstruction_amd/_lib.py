@@ -30,7 +30,7 @@ SIGNATURES = {
     "svr_version": (C.c_int, []),
     "svr_last_error": (C.c_char_p, []),
     "svr_points_morton_order_workspace": (I64, [I32, I32]),
-    "svr_points_morton_order": (C.c_int, [P, P, I32, I32, P, P]),
+    "svr_points_morton_order": (C.c_int, [P, P, P, I32, I32, P, P]),
     "svr_gather_trilinear_fwd": (C.c_int, [C.POINTER(GatherDesc), P, P, P]),
     "svr_gather_trilinear_bwd": (C.c_int, [C.POINTER(GatherDesc), P, P, P, P]),
     "svr_gather_corner_indices": (C.c_int, [C.POINTER(GatherDesc), I32, P, P, P]),
@@ -38,9 +38,9 @@ SIGNATURES = {
     "svr_linear_bwd_data": (C.c_int, [P, I64, P, I64, P, I64, I64, I64, I64, C.c_int, P, I64, P]),
     "svr_linear_bwd_weight_workspace": (I64, [I64, I64, I64]),
     "svr_linear_bwd_weight": (C.c_int, [P, I64, P, I64, P, I64, P, I64, I64, I64, P, P]),
-    "svr_fc_out_fwd": (C.c_int, [P, I64, P, P, P, I64, I64, P]),
+    "svr_fc_out_fwd": (C.c_int, [P, I64, P, P, P, P, I64, I64, P]),
     "svr_fc_out_bwd_workspace": (I64, [I64, I64]),
-    "svr_fc_out_bwd": (C.c_int, [P, I64, P, P, P, I64, P, P, I64, I64, P, P]),
+    "svr_fc_out_bwd": (C.c_int, [P, I64, P, P, P, P, I64, P, P, I64, I64, P, P]),
     "svr_bce_logits_sum_mean": (C.c_int, [P, P, P, P, I64, I64, F32, P, P]),
     "svr_conv3d_pack_weight": (C.c_int, [P, P, P, I32, I32, P]),
     "svr_conv3d_unpack_wgrad": (C.c_int, [P, P, I32, I32, P]),

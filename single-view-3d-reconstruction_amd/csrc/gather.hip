@@ -80,6 +80,7 @@ struct FusedArgs {
   LevelArgs L[SVR_MAX_LEVELS];
   unsigned block_start[SVR_MAX_LEVELS + 1];
   int n;
+  int pad_start;  // forward: columns [pad_start, row_stride) of every row are zero-filled by the last level
 };
 
 template <int C>
@@ -144,6 +145,10 @@ __global__ __launch_bounds__(256) void gather_fwd_fused_kernel(FusedArgs A, cons
   const int64_t gid = (int64_t)(blockIdx.x - A.block_start[l]) * 256 + threadIdx.x;
   const int V = L.C >= 4 ? L.C / 4 : 1;
   const int64_t total = BN * 7 * V;
+  if (l == A.n - 1 && gid < total && gid % (7 * V) == 0) {  // padding columns: written once per row
+    float *row = feat + (gid / (7 * V)) * row_stride;
+    for (int c = A.pad_start; c < row_stride; ++c) row[c] = 0.f;
+  }
   switch (L.C) {
     case 1: gather_fwd_body<1>(L, points, feat, order, gid, total, N, row_stride, disp, ac); break;
     case 16: gather_fwd_body<16>(L, points, feat, order, gid, total, N, row_stride, disp, ac); break;
@@ -254,9 +259,14 @@ __device__ __forceinline__ void gather_bwd_runs_body(const LevelArgs &L, const f
   const int lane = threadIdx.x & 63;
   const int ch = lane % CW, grp = lane / CW;
   if (item >= waves) return;  // item: wave-uniform (chunk, j, cg)
+  // item -> (j, chunk, cg) with j OUTERMOST and the chunks visited through a multiplicative permutation:
+  // waves that run at the same time then work on one displacement and on spatially distant runs, so their
+  // flushes do not pile onto the same voxel rows (same-address float atomics serialise at the memory side).
+  const int64_t nchunks = waves / (7 * CG);
   const int cg = (int)(item % CG);
-  const int j = (int)((item / CG) % 7);
-  const int64_t chunk = item / (7 * CG);
+  const int64_t cidx = (item / CG) % nchunks;
+  const int j = (int)(item / (CG * nchunks));
+  const int64_t chunk = (cidx * 1000003LL) % nchunks;
   const int64_t i0 = (chunk * G + grp) * PG;
   const int64_t i1 = min(BN, i0 + PG);
   const int coff = L.col + j * C + cg * CW + ch;
@@ -278,24 +288,51 @@ __device__ __forceinline__ void gather_bwd_runs_body(const LevelArgs &L, const f
     }
   };
 
-  int64_t pn_next = (i0 < i1) ? (order ? (int64_t)order[i0] : i0) : 0;
-  for (int64_t i = i0; i < i1; ++i) {
-    const int64_t pn = pn_next;
-    if (i + 1 < i1) pn_next = order ? (int64_t)order[i + 1] : i + 1;
-    const float g = gfeat[pn * row_stride + coff];
-    const float p3[3] = {points[pn * 3], points[pn * 3 + 1], points[pn * 3 + 2]};
-    Corner c = sample_corner(p3, j, disp, L.D, L.H, L.W, ac);
-    Weights w = corner_weights(c);
-    const bool touches = w.z0 >= -1 && w.z0 < L.D && w.y0 >= -1 && w.y0 < L.H && w.x0 >= -1 && w.x0 < L.W;
-    const int64_t nb = touches ? (pn / N) * ((int64_t)L.D * L.H * L.W) : -1;
-    if (nb != cb || w.z0 != cz || w.y0 != cy || w.x0 != cx) {
-      flush();
-      cb = nb; cz = w.z0; cy = w.y0; cx = w.x0;
+  // Software pipeline: the loads of the NEXT group of UNR samples are issued before the current group is
+  // processed, so they neither wait on each other (one dependent round trip per group, not per sample)
+  // nor on the atomics of the current group's flushes (vmcnt retires in issue order).
+  constexpr int UNR = 4;
+  float gq[UNR], pq[UNR][3];
+  int64_t nq[UNR];
+  auto fetch = [&](int64_t base) {
 #pragma unroll
-      for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+    for (int u = 0; u < UNR; ++u) {
+      const int64_t i = base + u;
+      const int64_t pn = (i < i1) ? (order ? (int64_t)order[i] : i) : (i0 < i1 ? (order ? (int64_t)order[i0] : i0) : 0);
+      nq[u] = pn;
+      gq[u] = gfeat[pn * row_stride + coff];
+      pq[u][0] = points[pn * 3];
+      pq[u][1] = points[pn * 3 + 1];
+      pq[u][2] = points[pn * 3 + 2];
     }
+  };
+  if (i0 < i1) fetch(i0);
+  for (int64_t ib = i0; ib < i1; ib += UNR) {
+    float gc[UNR], pc[UNR][3];
+    int64_t nc[UNR];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) acc[k] += g * corner_w(w, k);
+    for (int u = 0; u < UNR; ++u) {
+      gc[u] = gq[u]; nc[u] = nq[u];
+      pc[u][0] = pq[u][0]; pc[u][1] = pq[u][1]; pc[u][2] = pq[u][2];
+    }
+    if (ib + UNR < i1) fetch(ib + UNR);
+#pragma unroll
+    for (int u = 0; u < UNR; ++u) {
+      if (ib + u < i1) {
+        Corner c = sample_corner(pc[u], j, disp, L.D, L.H, L.W, ac);
+        Weights w = corner_weights(c);
+        const bool touches = w.z0 >= -1 && w.z0 < L.D && w.y0 >= -1 && w.y0 < L.H && w.x0 >= -1 && w.x0 < L.W;
+        const int64_t nb = touches ? (nc[u] / N) * ((int64_t)L.D * L.H * L.W) : -1;
+        if (nb != cb || w.z0 != cz || w.y0 != cy || w.x0 != cx) {
+          flush();
+          cb = nb; cz = w.z0; cy = w.y0; cx = w.x0;
+#pragma unroll
+          for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] += gc[u] * corner_w(w, k);
+      }
+    }
   }
   flush();
 }
@@ -392,6 +429,11 @@ extern "C" int svr_gather_trilinear_fwd(const svr_gather_desc *d, const float *p
       ++A.n;
     }
   A.block_start[A.n] = blocks;
+  A.pad_start = 0;
+  for (int l = 0; l < d->n_levels; ++l) {
+    int end = d->level[l].col + 7 * d->level[l].C;
+    if (end > A.pad_start) A.pad_start = end;
+  }
   hipLaunchKernelGGL(gather_fwd_fused_kernel, dim3(blocks), dim3(256), 0, s, A, points, features, d->order, BN, d->N,
                      d->row_stride, d->displacement, d->align_corners);
   return svr::launch_status("gather_fwd");

@@ -181,7 +181,8 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(const float *__restri
 // fc_out forward: 16 lanes per row, float4 loads.
 __global__ __launch_bounds__(256) void fc_out_fwd_kernel(const float *__restrict__ H, int64_t ldh,
                                                          const float *__restrict__ w, const float *__restrict__ b,
-                                                         float *__restrict__ logits, int64_t M, int64_t K) {
+                                                         float *__restrict__ logits,
+                                                         const int32_t *__restrict__ row_map, int64_t M, int64_t K) {
   int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
   int sub = threadIdx.x & 15;
   float s = 0.f;
@@ -195,13 +196,14 @@ __global__ __launch_bounds__(256) void fc_out_fwd_kernel(const float *__restrict
   }
 #pragma unroll
   for (int o = 8; o >= 1; o >>= 1) s += __shfl_xor(s, o);
-  if (row < M && sub == 0) logits[row] = s + b[0];
+  if (row < M && sub == 0) logits[row_map ? (int64_t)row_map[row] : row] = s + b[0];
 }
 
 // fc_out backward: dH = dlogit*w*(H>0); per-block partial of dw[k] = sum_m dlogit[m]*H[m][k].
 __global__ __launch_bounds__(256) void fc_out_bwd_kernel(const float *__restrict__ H, int64_t ldh,
                                                          const float *__restrict__ w,
-                                                         const float *__restrict__ dlogits, float *__restrict__ dH,
+                                                         const float *__restrict__ dlogits,
+                                                         const int32_t *__restrict__ row_map, float *__restrict__ dH,
                                                          int64_t lddh, float *__restrict__ part, int64_t M, int64_t K,
                                                          int64_t rows_per_block) {
   // thread t owns columns t, t+256, ... ; rows looped (coalesced across the wave per row)
@@ -209,7 +211,7 @@ __global__ __launch_bounds__(256) void fc_out_bwd_kernel(const float *__restrict
   for (int64_t k = threadIdx.x; k < K; k += blockDim.x) {
     float wk = w[k], s = 0.f;
     for (int64_t m = r0; m < r1; ++m) {
-      float h = H[m * ldh + k], g = dlogits[m];
+      float h = H[m * ldh + k], g = dlogits[row_map ? (int64_t)row_map[m] : m];
       s += g * h;
       dH[m * lddh + k] = h > 0.f ? g * wk : 0.f;
     }
@@ -217,7 +219,7 @@ __global__ __launch_bounds__(256) void fc_out_bwd_kernel(const float *__restrict
   }
   if (threadIdx.x == 0) {
     float s = 0.f;
-    for (int64_t m = r0; m < r1; ++m) s += dlogits[m];
+    for (int64_t m = r0; m < r1; ++m) s += dlogits[row_map ? (int64_t)row_map[m] : m];
     part[(int64_t)blockIdx.x * (K + 1) + K] = s;
   }
 }
@@ -363,12 +365,12 @@ extern "C" int svr_linear_bwd_weight(const float *dY, int64_t lddy, const float 
   return launch_status("linear_bwd_weight");
 }
 
-extern "C" int svr_fc_out_fwd(const float *H, int64_t ldh, const float *w, const float *b, float *logits, int64_t M,
-                              int64_t K, void *stream) {
+extern "C" int svr_fc_out_fwd(const float *H, int64_t ldh, const float *w, const float *b, float *logits,
+                              const int32_t *row_map, int64_t M, int64_t K, void *stream) {
   SVR_CHECK(H && w && b && logits, SVR_E_BADARG, "fc_out_fwd: null pointer");
   SVR_CHECK(K > 0 && K % 4 == 0 && ldh % 4 == 0, SVR_E_BADSHAPE, "fc_out_fwd: K=%ld ldh=%ld", (long)K, (long)ldh);
   if (M <= 0) return SVR_OK;
-  hipLaunchKernelGGL(fc_out_fwd_kernel, dim3((unsigned)cdiv(M * 16, 256)), dim3(256), 0, (hipStream_t)stream, H, ldh, w, b, logits, M, K);
+  hipLaunchKernelGGL(fc_out_fwd_kernel, dim3((unsigned)cdiv(M * 16, 256)), dim3(256), 0, (hipStream_t)stream, H, ldh, w, b, logits, row_map, M, K);
   return launch_status("fc_out_fwd");
 }
 
@@ -376,14 +378,15 @@ namespace { constexpr int64_t FCO_ROWS = 512; }
 
 extern "C" int64_t svr_fc_out_bwd_workspace(int64_t M, int64_t K) { return cdiv(M > 0 ? M : 1, FCO_ROWS) * (K + 1) * (int64_t)sizeof(float); }
 
-extern "C" int svr_fc_out_bwd(const float *H, int64_t ldh, const float *w, const float *dlogits, float *dH, int64_t lddh,
-                              float *dw, float *db, int64_t M, int64_t K, void *workspace, void *stream) {
+extern "C" int svr_fc_out_bwd(const float *H, int64_t ldh, const float *w, const float *dlogits, const int32_t *row_map,
+                              float *dH, int64_t lddh, float *dw, float *db, int64_t M, int64_t K, void *workspace,
+                              void *stream) {
   SVR_CHECK(H && w && dlogits && dH && dw && workspace, SVR_E_BADARG, "fc_out_bwd: null pointer");
   SVR_CHECK(M > 0 && K > 0, SVR_E_BADSHAPE, "fc_out_bwd: M=%ld K=%ld", (long)M, (long)K);
   hipStream_t s = (hipStream_t)stream;
   int blocks = (int)cdiv(M, FCO_ROWS);
   float *part = (float *)workspace;
-  hipLaunchKernelGGL(fc_out_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, s, H, ldh, w, dlogits, dH, lddh, part, M, K, FCO_ROWS);
+  hipLaunchKernelGGL(fc_out_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, s, H, ldh, w, dlogits, row_map, dH, lddh, part, M, K, FCO_ROWS);
   hipLaunchKernelGGL(fc_out_bwd_final_kernel, dim3((unsigned)(K + 1)), dim3(256), 0, s, part, dw, db, K, blocks);
   return launch_status("fc_out_bwd");
 }

@@ -44,6 +44,16 @@ __global__ void morton_key_kernel(const float *__restrict__ points, uint32_t *__
   vals[i] = (int32_t)i;
 }
 
+__global__ void permute_points_kernel(const float *__restrict__ points, const int32_t *__restrict__ order,
+                                      float *__restrict__ out, int64_t total) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  int64_t src = order[i];
+  out[i * 3] = points[src * 3];
+  out[i * 3 + 1] = points[src * 3 + 1];
+  out[i * 3 + 2] = points[src * 3 + 2];
+}
+
 int key_bits(int B) {
   int bb = 0;
   while ((1 << bb) < B) ++bb;
@@ -67,8 +77,8 @@ extern "C" int64_t svr_points_morton_order_workspace(int32_t B, int32_t N) {
   return 3 * align256(total * 4) + align256((int64_t)rocprim_temp_bytes(total, key_bits(B))) + 256;
 }
 
-extern "C" int svr_points_morton_order(const float *points, int32_t *order, int32_t B, int32_t N, void *workspace,
-                                       void *stream) {
+extern "C" int svr_points_morton_order(const float *points, int32_t *order, float *sorted_points, int32_t B, int32_t N,
+                                       void *workspace, void *stream) {
   int64_t total = (int64_t)B * N;
   if (total <= 0) return SVR_OK;
   SVR_CHECK(points && order && workspace, SVR_E_BADARG, "morton_order: null pointer");
@@ -86,5 +96,7 @@ extern "C" int svr_points_morton_order(const float *points, int32_t *order, int3
   hipLaunchKernelGGL(morton_key_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, s, points, keys_in, vals_in, total, N);
   hipError_t e = rocprim::radix_sort_pairs((void *)w, tmp, keys_in, keys_out, vals_in, order, (size_t)total, 0, bits, s);
   SVR_CHECK(e == hipSuccess, (int)e, "morton_order: radix sort failed: %s", hipGetErrorString(e));
+  if (sorted_points)
+    hipLaunchKernelGGL(permute_points_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, s, points, order, sorted_points, total);
   return launch_status("morton_order");
 }

@@ -73,9 +73,8 @@ class _EncoderGatherFn(torch.autograd.Function):
             levels.append(y)
             saved.append((inp, acts, packed, argmax, ss, mean))
             inp = pooled
-        order = ops.morton_order(pts)          # processing order only; rows keep the caller's order
-        feat = ops.gather_fwd(levels, pts, ext._layout, ext._disp, ext._align, order=order)
-        ctx.ext, ctx.saved, ctx.levels, ctx.pts, ctx.order = ext, saved, levels, pts, order
+        feat = ops.gather_fwd(levels, pts, ext._layout, ext._disp, ext._align)
+        ctx.ext, ctx.saved, ctx.levels, ctx.pts = ext, saved, levels, pts
         ctx.x_shape = x.shape
         ctx.training = training
         return feat
@@ -88,8 +87,7 @@ class _EncoderGatherFn(torch.autograd.Function):
         need_x, need_pts = ctx.needs_input_grad[1], ctx.needs_input_grad[2]
         gfeat = gfeat.contiguous()
         gvols = [torch.zeros_like(levels[0]) if need_x else None] + [torch.zeros_like(v) for v in levels[1:]]
-        gpts = ops.gather_bwd(levels, gvols, pts, gfeat, ext._layout, ext._disp, ext._align, want_gpoints=need_pts,
-                              order=ctx.order)
+        gpts = ops.gather_bwd(levels, gvols, pts, gfeat, ext._layout, ext._disp, ext._align, want_gpoints=need_pts)
         grads = {}
         dpooled = None
         gx = None
@@ -125,25 +123,28 @@ class _PointMLPFn(torch.autograd.Function):
     (reference model/ifnet.py:55-59) on the f32 matrix cores."""
 
     @staticmethod
-    def forward(ctx, feat, w0p, b0, w1, b1, w2, b2, wo, bo):
+    def forward(ctx, feat, row_map, w0p, b0, w1, b1, w2, b2, wo, bo):
+        """row_map (int32, or None): feature row m belongs to caller point row_map[m]; the logits are
+        scattered back to the caller's order by the fc_out kernel."""
         h0 = ops.linear_fwd(feat, w0p, b0, relu=True)
         h1 = ops.linear_fwd(h0, w1, b1, relu=True)
         h2 = ops.linear_fwd(h1, w2, b2, relu=True)
-        logits = ops.fc_out_fwd(h2, wo, bo)
+        logits = ops.fc_out_fwd(h2, wo, bo, row_map)
         ctx.save_for_backward(feat, w0p, w1, w2, wo, h0, h1, h2)
+        ctx.row_map = row_map
         return logits
 
     @staticmethod
     def backward(ctx, dlogits):
         feat, w0p, w1, w2, wo, h0, h1, h2 = ctx.saved_tensors
-        dh2, dwo, dbo = ops.fc_out_bwd(h2, wo, dlogits.contiguous())          # dh2 already masked by h2 > 0
+        dh2, dwo, dbo = ops.fc_out_bwd(h2, wo, dlogits.contiguous(), ctx.row_map)   # dh2 already masked by h2 > 0
         dw2, db2 = ops.linear_bwd_weight(dh2, h1)
         dh1 = ops.linear_bwd_data(dh2, w2, mask=h1)
         dw1, db1 = ops.linear_bwd_weight(dh1, h0)
         dh0 = ops.linear_bwd_data(dh1, w1, mask=h0)
         dw0, db0 = ops.linear_bwd_weight(dh0, feat)
         dfeat = ops.linear_bwd_data(dh0, w0p) if ctx.needs_input_grad[0] else None
-        return dfeat, dw0, db0, dw1, db1, dw2, db2, dwo, dbo
+        return dfeat, None, dw0, db0, dw1, db1, dw2, db2, dwo, dbo
 
 
 class _ExtractorBase(nn.Module):
@@ -293,10 +294,24 @@ class IFNet(nn.Module):
         h = ops.linear_fwd(h, self.fc_2.weight.squeeze(2), self.fc_2.bias, relu=True)
         return ops.fc_out_fwd(h, self.fc_out.weight.reshape(-1).contiguous(), self.fc_out.bias).view(B, N)
 
-    def forward(self, x, points):
+    def forward(self, x, points, spatial_sort=True):
+        """logits (B,N).  With spatial_sort the points of every sample are visited in Morton order: the whole
+        gather -> MLP -> scatter chain runs on the permuted point set (rows are independent), and only the
+        (B,N) logits are permuted back.  That makes the gather's reads L2-local and lets the backward scatter
+        combine runs of samples that share corners (gather.hip); results do not depend on the order."""
         B, N = points.shape[0], points.shape[1]
+        if not x.is_cuda:
+            raise RuntimeError("IF-Net HIP path needs GPU tensors (no CPU fallback)")
+        row_map = None
+        if spatial_sort and N > 1:
+            pts = points.detach().float().contiguous()
+            row_map, sorted_pts = ops.morton_order(pts, want_sorted=True)     # samples stay contiguous
+            if points.requires_grad:       # rare (subsample_points > 0): keep the permutation differentiable
+                points = points.reshape(B * N, 3)[row_map.long()].view(B, N, 3)
+            else:
+                points = sorted_pts
         rows = self.ifnet_feature_extractor.feature_rows(x, points)
-        logits = _PointMLPFn.apply(rows, self._fc0_internal(), self.fc_0.bias,
+        logits = _PointMLPFn.apply(rows, row_map, self._fc0_internal(), self.fc_0.bias,
                                    self.fc_1.weight.squeeze(2), self.fc_1.bias,
                                    self.fc_2.weight.squeeze(2), self.fc_2.bias,
                                    self.fc_out.weight.reshape(-1), self.fc_out.bias)

@@ -59,15 +59,17 @@ class FeatureLayout:
         return perm
 
 
-def morton_order(points):
-    """(B*N,) int32 processing order: points of one sample sorted by a 64^3 Morton code."""
+def morton_order(points, want_sorted=False):
+    """(B*N,) int32 processing order: points of one sample sorted by a 64^3 Morton code
+    (and, optionally, the points gathered into that order)."""
     _f32(points)
     B, N, _ = points.shape
     l = _lib.lib()
     order = torch.empty(B * N, device=points.device, dtype=torch.int32)
+    spts = torch.empty_like(points) if want_sorted else None
     ws = torch.empty(l.svr_points_morton_order_workspace(B, N), device=points.device, dtype=torch.uint8)
-    check(l.svr_points_morton_order(_p(points), _p(order), B, N, _p(ws), _stream()), "morton_order")
-    return order
+    check(l.svr_points_morton_order(_p(points), _p(order), _p(spts), B, N, _p(ws), _stream()), "morton_order")
+    return (order, spts) if want_sorted else order
 
 
 def make_gather_desc(vols, gvols, layout, B, N, displacement, align_corners, order=None):
@@ -95,8 +97,8 @@ def gather_fwd(vols, points, layout, displacement, align_corners, out=None, orde
     B, N, _ = points.shape
     _f32(points)
     d = make_gather_desc(vols, None, layout, B, N, displacement, align_corners, order)
-    if out is None:
-        out = torch.zeros(B * N, layout.row_stride, device=points.device, dtype=torch.float32)
+    if out is None:   # the kernel writes every column (padding columns as zeros): no memset of the 4 GB buffer
+        out = torch.empty(B * N, layout.row_stride, device=points.device, dtype=torch.float32)
     check(_lib.lib().svr_gather_trilinear_fwd(C.byref(d), _p(points), _p(out), _stream()), "gather_fwd")
     return out
 
@@ -164,15 +166,16 @@ def linear_bwd_weight(dy, x, want_bias=True):
     return dw, db
 
 
-def fc_out_fwd(h, w, b):
+def fc_out_fwd(h, w, b, row_map=None):
+    """logits[row_map[m]] (or [m]) = h[m] . w + b"""
     _f32(h, w, b)
     M, K = h.shape
     out = torch.empty(M, device=h.device, dtype=torch.float32)
-    check(_lib.lib().svr_fc_out_fwd(_p(h), h.stride(0), _p(w), _p(b), _p(out), M, K, _stream()), "fc_out_fwd")
+    check(_lib.lib().svr_fc_out_fwd(_p(h), h.stride(0), _p(w), _p(b), _p(out), _p(row_map), M, K, _stream()), "fc_out_fwd")
     return out
 
 
-def fc_out_bwd(h, w, dlogits):
+def fc_out_bwd(h, w, dlogits, row_map=None):
     _f32(h, w, dlogits)
     M, K = h.shape
     l = _lib.lib()
@@ -180,8 +183,8 @@ def fc_out_bwd(h, w, dlogits):
     dh = torch.empty(M, K, device=h.device, dtype=torch.float32)
     dw = torch.empty(K, device=h.device, dtype=torch.float32)
     db = torch.empty(1, device=h.device, dtype=torch.float32)
-    check(l.svr_fc_out_bwd(_p(h), h.stride(0), _p(w), _p(dlogits), _p(dh), dh.stride(0), _p(dw), _p(db), M, K, _p(ws),
-                           _stream()), "fc_out_bwd")
+    check(l.svr_fc_out_bwd(_p(h), h.stride(0), _p(w), _p(dlogits), _p(row_map), _p(dh), dh.stride(0), _p(dw), _p(db), M, K,
+                           _p(ws), _stream()), "fc_out_bwd")
     return dh, dw, db
 
 

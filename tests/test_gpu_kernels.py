@@ -141,6 +141,14 @@ def test_fc_out_and_bce():
     assert G.rel_err(dh.cpu().numpy(), (dz[:, None] * w[None, :] * (h > 0)).numpy()) < 1e-6
     assert G.rel_err(dw.cpu().numpy(), (dz.double() @ h.double()).numpy()) < 1e-6
     assert abs(db.item() - dz.double().sum().item()) < 1e-4
+    # row_map: rows were processed in a permuted order, logits / dlogits live in the caller's order
+    perm = torch.randperm(M, generator=g).to(torch.int32)
+    zp = ops.fc_out_fwd(h.cuda(), w.cuda(), b.cuda(), perm.cuda())
+    assert torch.equal(zp.cpu()[perm.long()], z.cpu())
+    dh2, dw2, db2 = ops.fc_out_bwd(h.cuda(), w.cuda(), dz.cuda(), perm.cuda())
+    gperm = dz[perm.long()]
+    assert G.rel_err(dh2.cpu().numpy(), (gperm[:, None] * w[None, :] * (h > 0)).numpy()) < 1e-6
+    assert G.rel_err(dw2.cpu().numpy(), (gperm.double() @ h.double()).numpy()) < 1e-6
     logits = z_ref.float().view(B, M // B)
     t = (torch.rand(B, M // B, generator=g) < 0.5).float()
     lz = logits.clone().requires_grad_(True)
@@ -222,8 +230,9 @@ def test_morton_order_is_a_permutation_and_gather_is_order_independent():
     g = torch.Generator().manual_seed(22)
     pts = (torch.rand(B, N, 3, generator=g) - 0.5) * 1.2
     pts[0, 0, 0] = float("nan")
-    order = ops.morton_order(pts.cuda())
+    order, spts = ops.morton_order(pts.cuda(), want_sorted=True)
     o = order.cpu().long()
+    assert torch.equal(spts.cpu().reshape(-1, 3).nan_to_num(7.0), pts.reshape(-1, 3)[o].nan_to_num(7.0))
     assert sorted(o.tolist()) == list(range(B * N))                 # a permutation
     assert torch.equal(o // N, torch.arange(B).repeat_interleave(N))  # samples stay contiguous
     # Morton keys non-decreasing inside a sample

@@ -1,0 +1,44 @@
+"""Micro-benchmark of the gather forward / backward per level at the config-3 shape (B=8, 128^3, N=50k)."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import svr_amd
+from svr_amd import ops
+
+B, D, N = 8, 128, 50000
+chans = [1, 16, 32, 64, 128, 128]
+dev = "cuda"
+torch.manual_seed(0)
+vols, d = [], D
+for i, c in enumerate(chans):
+    vols.append(torch.randn(B, d, d, d, c, device=dev))
+    if i >= 1:
+        d //= 2
+pts = torch.rand(B, N, 3, device=dev) - 0.5
+order = ops.morton_order(pts).long()
+pts_sorted = pts.reshape(-1, 3)[order].view(B, N, 3).contiguous()
+layout = ops.FeatureLayout(chans)
+disp = 0.0722
+
+
+def timeit(fn, n=5):
+    fn(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+
+
+feat = torch.empty(B * N, layout.row_stride, device=dev)
+gfeat = torch.randn(B * N, layout.row_stride, device=dev)
+for name, p in (("random", pts), ("sorted", pts_sorted)):
+    print(name, "fwd all levels: %.3f ms" % timeit(lambda: ops.gather_fwd(vols, p, layout, disp, False, out=feat)))
+    for l in range(1, 6):
+        gv = [None] * 6
+        gv[l] = torch.zeros_like(vols[l])
+        t = timeit(lambda: ops.gather_bwd(vols, gv, p, gfeat, layout, disp, False))
+        print(f"  bwd level {l} (C={chans[l]}, S={vols[l].shape[1]}): {t:.3f} ms")
+    gv = [None] + [torch.zeros_like(v) for v in vols[1:]]
+    print("  bwd levels 1-5 fused: %.3f ms" % timeit(lambda: ops.gather_bwd(vols, gv, p, gfeat, layout, disp, False)))
