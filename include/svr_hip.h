@@ -47,6 +47,8 @@ typedef struct svr_level {
   float *gvol;      /* backward only: gradient volume, same shape, accumulated into   */
   int32_t C, D, H, W;
   int32_t col;      /* first column of this level inside a feature row                */
+  const int32_t *order; /* backward only, optional: (B*N) visiting order for THIS level from
+                           svr_points_voxel_order (overrides svr_gather_desc.order)   */
 } svr_level;
 
 typedef struct svr_gather_desc {
@@ -63,6 +65,13 @@ typedef struct svr_gather_desc {
  * reference op: it only changes the order in which the gather / scatter kernels visit points
  * (L2 locality, run-combining of atomics); outputs keep the caller's point order.
  * workspace: svr_points_morton_order_workspace() bytes.                                      */
+/* order[i] = index of the i-th point in (sample, Morton code of the BASE VOXEL of its undisplaced
+ * trilinear sample in a D x H x W volume) order: points that scatter into the same 8 corners of that
+ * level become consecutive, which is what the backward run-combining needs (the base-voxel lattice is
+ * shifted by half a voxel, differently at every level, so one global order cannot serve all levels).
+ * Same workspace size as svr_points_morton_order.                                               */
+int svr_points_voxel_order(const float *points, int32_t *order, int32_t B, int32_t N, int32_t D, int32_t H,
+                           int32_t W, int32_t align_corners, void *workspace, void *stream);
 int64_t svr_points_morton_order_workspace(int32_t B, int32_t N);
 int svr_points_morton_order(const float *points, int32_t *order, float *sorted_points /* (B,N,3) or NULL */,
                             int32_t B, int32_t N, void *workspace, void *stream);

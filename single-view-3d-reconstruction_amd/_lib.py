@@ -17,7 +17,7 @@ I32, I64, F32 = C.c_int32, C.c_int64, C.c_float
 
 
 class Level(C.Structure):
-    _fields_ = [("vol", P), ("gvol", P), ("C", I32), ("D", I32), ("H", I32), ("W", I32), ("col", I32)]
+    _fields_ = [("vol", P), ("gvol", P), ("C", I32), ("D", I32), ("H", I32), ("W", I32), ("col", I32), ("order", P)]
 
 
 class GatherDesc(C.Structure):
@@ -31,6 +31,7 @@ SIGNATURES = {
     "svr_last_error": (C.c_char_p, []),
     "svr_points_morton_order_workspace": (I64, [I32, I32]),
     "svr_points_morton_order": (C.c_int, [P, P, P, I32, I32, P, P]),
+    "svr_points_voxel_order": (C.c_int, [P, P, I32, I32, I32, I32, I32, I32, P, P]),
     "svr_gather_trilinear_fwd": (C.c_int, [C.POINTER(GatherDesc), P, P, P]),
     "svr_gather_trilinear_bwd": (C.c_int, [C.POINTER(GatherDesc), P, P, P, P]),
     "svr_gather_corner_indices": (C.c_int, [C.POINTER(GatherDesc), I32, P, P, P]),

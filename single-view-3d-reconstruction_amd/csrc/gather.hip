@@ -20,6 +20,7 @@ struct LevelArgs {
   const float *vol;
   float *gvol;
   int C, D, H, W, col;
+  const int32_t *order;  // backward: visiting order of this level (or null = natural order)
 };
 
 struct Corner {
@@ -84,7 +85,7 @@ struct FusedArgs {
 };
 
 template <int C>
-__device__ __forceinline__ void gather_fwd_body(const LevelArgs &L, const float *__restrict__ points,
+__device__ __forceinline__ void gather_fwd_body(const LevelArgs L, const float *__restrict__ points,
                                                 float *__restrict__ feat, const int32_t *__restrict__ order,
                                                 int64_t gid, int64_t total, int N, int row_stride, float disp,
                                                 int ac) {
@@ -141,7 +142,7 @@ __global__ __launch_bounds__(256) void gather_fwd_fused_kernel(FusedArgs A, cons
                                                                int row_stride, float disp, int ac) {
   int l = 0;
   while (l + 1 < A.n && blockIdx.x >= A.block_start[l + 1]) ++l;
-  const LevelArgs &L = A.L[l];
+  const LevelArgs L = A.L[l];  // by value: read from the kernel arguments once, then lives in SGPRs
   const int64_t gid = (int64_t)(blockIdx.x - A.block_start[l]) * 256 + threadIdx.x;
   const int V = L.C >= 4 ? L.C / 4 : 1;
   const int64_t total = BN * 7 * V;
@@ -246,117 +247,160 @@ __device__ __forceinline__ float corner_w(const Weights &w, int k) {
   return (w.wx[k & 1] * w.wy[(k >> 1) & 1]) * w.wz[k >> 2];
 }
 
+// Work item (one wave) = (sample b, displacement j, chunk of G*PG consecutive points, 64-channel group).
+// The PG = 2*CW samples of a lane group are evaluated ONCE, two per lane (source index, base voxel,
+// fractional weights), and broadcast to the group with wave shuffles while it walks them in order;
+// the only per-iteration memory access is the lane's own gradient element (prefetched 4 ahead).
 template <int C>
-__device__ __forceinline__ void gather_bwd_runs_body(const LevelArgs &L, const float *__restrict__ points,
+__device__ __forceinline__ void gather_bwd_runs_body(const LevelArgs L, const float *__restrict__ points,
                                                      const float *__restrict__ gfeat,
-                                                     const int32_t *__restrict__ order, int64_t BN, int N,
+                                                     const int32_t *__restrict__ order, int B, int N,
                                                      int row_stride, float disp, int ac, int64_t item,
                                                      int64_t waves) {
   constexpr int CW = C < 64 ? C : 64;  // channels per lane group
   constexpr int G = 64 / CW;           // independent runs per wave
   constexpr int CG = C / CW;           // channel groups per sample
   constexpr int PG = 2 * CW;           // consecutive points per run group
+  if (item >= waves) return;
   const int lane = threadIdx.x & 63;
   const int ch = lane % CW, grp = lane / CW;
-  if (item >= waves) return;  // item: wave-uniform (chunk, j, cg)
-  // item -> (j, chunk, cg) with j OUTERMOST and the chunks visited through a multiplicative permutation:
-  // waves that run at the same time then work on one displacement and on spatially distant runs, so their
-  // flushes do not pile onto the same voxel rows (same-address float atomics serialise at the memory side).
-  const int64_t nchunks = waves / (7 * CG);
+  // item -> (j, b, chunk, cg): j outermost, chunks through a multiplicative permutation so that waves running
+  // at the same time flush to distant voxel rows (same-address float atomics serialise at the memory side)
+  const int64_t cps = (N + G * PG - 1) / (G * PG);  // chunks per sample
+  const int64_t nchunks = cps * B;
   const int cg = (int)(item % CG);
   const int64_t cidx = (item / CG) % nchunks;
   const int j = (int)(item / (CG * nchunks));
-  const int64_t chunk = (cidx * 1000003LL) % nchunks;
-  const int64_t i0 = (chunk * G + grp) * PG;
-  const int64_t i1 = min(BN, i0 + PG);
+  const int64_t cperm = (cidx * 1000003LL) % nchunks;
+  const int b = (int)(cperm / cps);
+  const int n0 = (int)(cperm % cps) * (G * PG) + grp * PG;
+  const int cnt = min(PG, N - n0);  // samples of this group (<= 0: none)
   const int coff = L.col + j * C + cg * CW + ch;
-  float acc[8];
-#pragma unroll
-  for (int k = 0; k < 8; ++k) acc[k] = 0.f;
-  int cz = 0, cy = 0, cx = 0;
-  int64_t cb = -1;  // batch*volume offset of the current run, -1 = no run open
+  const int64_t vol = (int64_t)L.D * L.H * L.W;
+  float *gb = L.gvol + ((size_t)b * vol) * C + cg * CW + ch;
 
-  auto flush = [&]() {
-    if (cb >= 0) {
-      float *gb = L.gvol + (size_t)cb * C + cg * CW + ch;
+  // ---- stage 1: two samples per lane
+  int key[2];
+  float fx[2], fy[2], fz[2];
+  int64_t pnv[2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const int n = n0 + s * CW + ch;
+    key[s] = -1;
+    fx[s] = fy[s] = fz[s] = 0.f;
+    pnv[s] = 0;
+    if (s * CW + ch < cnt) {
+      int64_t pn = (int64_t)b * N + n;
+      if (order) pn = order[pn];
+      pnv[s] = pn;
+      const float p3[3] = {points[pn * 3], points[pn * 3 + 1], points[pn * 3 + 2]};
+      Corner c = sample_corner(p3, j, disp, L.D, L.H, L.W, ac);
+      const int x0 = clamp_int(c.x0f), y0 = clamp_int(c.y0f), z0 = clamp_int(c.z0f);
+      if (z0 >= -1 && z0 < L.D && y0 >= -1 && y0 < L.H && x0 >= -1 && x0 < L.W) {
+        key[s] = (x0 + 1) | ((y0 + 1) << 10) | ((z0 + 1) << 20);
+        fx[s] = c.ix - c.x0f;
+        fy[s] = c.iy - c.y0f;
+        fz[s] = c.iz - c.z0f;
+      }
+    }
+  }
+
+  // ---- stage 2: walk the samples with TWO open runs (slot 0 = most recent base voxel, slot 1 = the one
+  // before).  A displaced sample's base alternates between two neighbouring voxels while the points stay
+  // inside one voxel of the visiting order, so a single open run would be cut every other sample.
+  float acc0[8], acc1[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) acc0[k] = acc1[k] = 0.f;
+  int cur0 = -1, cur1 = -1;
+  auto flush = [&](int cur, const float (&acc)[8]) {
+    if (cur >= 0) {
+      const int x0 = (cur & 1023) - 1, y0 = ((cur >> 10) & 1023) - 1, z0 = (cur >> 20) - 1;
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
-        const int z = cz + (k >> 2), y = cy + ((k >> 1) & 1), x = cx + (k & 1);
+        const int z = z0 + (k >> 2), y = y0 + ((k >> 1) & 1), x = x0 + (k & 1);
         if (z >= 0 && z < L.D && y >= 0 && y < L.H && x >= 0 && x < L.W)
           atomicAdd(gb + (((size_t)z * L.H + y) * L.W + x) * C, acc[k]);
       }
     }
   };
-
-  // Software pipeline: the loads of the NEXT group of UNR samples are issued before the current group is
-  // processed, so they neither wait on each other (one dependent round trip per group, not per sample)
-  // nor on the atomics of the current group's flushes (vmcnt retires in issue order).
   constexpr int UNR = 4;
-  float gq[UNR], pq[UNR][3];
-  int64_t nq[UNR];
-  auto fetch = [&](int64_t base) {
 #pragma unroll
-    for (int u = 0; u < UNR; ++u) {
-      const int64_t i = base + u;
-      const int64_t pn = (i < i1) ? (order ? (int64_t)order[i] : i) : (i0 < i1 ? (order ? (int64_t)order[i0] : i0) : 0);
-      nq[u] = pn;
-      gq[u] = gfeat[pn * row_stride + coff];
-      pq[u][0] = points[pn * 3];
-      pq[u][1] = points[pn * 3 + 1];
-      pq[u][2] = points[pn * 3 + 2];
-    }
-  };
-  if (i0 < i1) fetch(i0);
-  for (int64_t ib = i0; ib < i1; ib += UNR) {
-    float gc[UNR], pc[UNR][3];
-    int64_t nc[UNR];
+  for (int s = 0; s < 2; ++s) {
+    for (int tb = 0; tb < CW; tb += UNR) {
+      if (s * CW + tb >= cnt) break;  // uniform within the group; other groups keep going
+      float gq[UNR];
+      int kq[UNR];
+      float xq[UNR], yq[UNR], zq[UNR];
 #pragma unroll
-    for (int u = 0; u < UNR; ++u) {
-      gc[u] = gq[u]; nc[u] = nq[u];
-      pc[u][0] = pq[u][0]; pc[u][1] = pq[u][1]; pc[u][2] = pq[u][2];
-    }
-    if (ib + UNR < i1) fetch(ib + UNR);
-#pragma unroll
-    for (int u = 0; u < UNR; ++u) {
-      if (ib + u < i1) {
-        Corner c = sample_corner(pc[u], j, disp, L.D, L.H, L.W, ac);
-        Weights w = corner_weights(c);
-        const bool touches = w.z0 >= -1 && w.z0 < L.D && w.y0 >= -1 && w.y0 < L.H && w.x0 >= -1 && w.x0 < L.W;
-        const int64_t nb = touches ? (nc[u] / N) * ((int64_t)L.D * L.H * L.W) : -1;
-        if (nb != cb || w.z0 != cz || w.y0 != cy || w.x0 != cx) {
-          flush();
-          cb = nb; cz = w.z0; cy = w.y0; cx = w.x0;
-#pragma unroll
-          for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+      for (int u = 0; u < UNR; ++u) {
+        const int src = grp * CW + tb + u;
+        kq[u] = __shfl(key[s], src);
+        xq[u] = __shfl(fx[s], src);
+        yq[u] = __shfl(fy[s], src);
+        zq[u] = __shfl(fz[s], src);
+        int64_t pn;
+        if (order) {  // wave-uniform
+          pn = __shfl((int)pnv[s], src);
+        } else {
+          pn = (int64_t)b * N + n0 + s * CW + tb + u;
         }
+        const bool live = s * CW + tb + u < cnt;
+        gq[u] = live ? gfeat[pn * row_stride + coff] : 0.f;
+        if (!live) kq[u] = -1;
+      }
 #pragma unroll
-        for (int k = 0; k < 8; ++k) acc[k] += gc[u] * corner_w(w, k);
+      for (int u = 0; u < UNR; ++u) {
+        const int kk = kq[u];
+        if (kk < 0) continue;  // sample touches no voxel (or padding slot)
+        if (kk != cur0) {
+          if (kk == cur1) {  // hit on the older run: make it the most recent
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { const float t = acc0[k]; acc0[k] = acc1[k]; acc1[k] = t; }
+            cur1 = cur0;
+          } else {           // miss: retire the older run, age the recent one, open a new one
+            flush(cur1, acc1);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { acc1[k] = acc0[k]; acc0[k] = 0.f; }
+            cur1 = cur0;
+          }
+          cur0 = kk;
+        }
+        const float wx1 = xq[u], wx0 = 1.f - wx1, wy1 = yq[u], wy0 = 1.f - wy1, wz1 = zq[u], wz0 = 1.f - wz1;
+        const float g = gq[u];
+        const float a00 = wy0 * wz0 * g, a10 = wy1 * wz0 * g, a01 = wy0 * wz1 * g, a11 = wy1 * wz1 * g;
+        acc0[0] += wx0 * a00; acc0[1] += wx1 * a00;
+        acc0[2] += wx0 * a10; acc0[3] += wx1 * a10;
+        acc0[4] += wx0 * a01; acc0[5] += wx1 * a01;
+        acc0[6] += wx0 * a11; acc0[7] += wx1 * a11;
       }
     }
   }
-  flush();
+  flush(cur1, acc1);
+  flush(cur0, acc0);
 }
 
-__host__ __device__ inline int64_t bwd_runs_waves(int C, int64_t BN) {
+__host__ __device__ inline int64_t bwd_runs_waves(int C, int B, int N) {
   int cw = C < 64 ? C : 64;
-  int64_t chunks = (BN + (int64_t)(64 / cw) * 2 * cw - 1) / ((int64_t)(64 / cw) * 2 * cw);
-  return chunks * 7 * (C / cw);
+  int64_t per = (int64_t)(64 / cw) * 2 * cw;  // points per wave
+  int64_t cps = (N + per - 1) / per;
+  return cps * B * 7 * (C / cw);
 }
 
 __global__ __launch_bounds__(256) void gather_bwd_fused_kernel(FusedArgs A, const float *__restrict__ points,
                                                                const float *__restrict__ gfeat,
-                                                               const int32_t *__restrict__ order, int64_t BN, int N,
+                                                               const int32_t *__restrict__ default_order, int B, int N,
                                                                int row_stride, float disp, int ac) {
   int l = 0;
   while (l + 1 < A.n && blockIdx.x >= A.block_start[l + 1]) ++l;
-  const LevelArgs &L = A.L[l];
+  const LevelArgs L = A.L[l];  // by value: read from the kernel arguments once, then lives in SGPRs
   const int64_t item = ((int64_t)(blockIdx.x - A.block_start[l]) * 256 + threadIdx.x) >> 6;
-  const int64_t waves = bwd_runs_waves(L.C, BN);
+  const int64_t waves = bwd_runs_waves(L.C, B, N);
+  const int32_t *order = L.order ? L.order : default_order;
   switch (L.C) {
-    case 16: gather_bwd_runs_body<16>(L, points, gfeat, order, BN, N, row_stride, disp, ac, item, waves); break;
-    case 32: gather_bwd_runs_body<32>(L, points, gfeat, order, BN, N, row_stride, disp, ac, item, waves); break;
-    case 64: gather_bwd_runs_body<64>(L, points, gfeat, order, BN, N, row_stride, disp, ac, item, waves); break;
-    case 128: gather_bwd_runs_body<128>(L, points, gfeat, order, BN, N, row_stride, disp, ac, item, waves); break;
+    case 16: gather_bwd_runs_body<16>(L, points, gfeat, order, B, N, row_stride, disp, ac, item, waves); break;
+    case 32: gather_bwd_runs_body<32>(L, points, gfeat, order, B, N, row_stride, disp, ac, item, waves); break;
+    case 64: gather_bwd_runs_body<64>(L, points, gfeat, order, B, N, row_stride, disp, ac, item, waves); break;
+    case 128: gather_bwd_runs_body<128>(L, points, gfeat, order, B, N, row_stride, disp, ac, item, waves); break;
   }
 }
 
@@ -393,7 +437,7 @@ int check_desc(const svr_gather_desc *d, bool bwd) {
   return SVR_OK;
 }
 
-LevelArgs level_args(const svr_level &L) { return LevelArgs{L.vol, L.gvol, L.C, L.D, L.H, L.W, L.col}; }
+LevelArgs level_args(const svr_level &L) { return LevelArgs{L.vol, L.gvol, L.C, L.D, L.H, L.W, L.col, L.order}; }
 
 }  // namespace
 
@@ -475,12 +519,13 @@ extern "C" int svr_gather_trilinear_bwd(const svr_gather_desc *d, const float *p
     }
     FA.L[FA.n] = L;
     FA.block_start[FA.n] = fblocks;
-    fblocks += (unsigned)svr::cdiv(bwd_runs_waves(L.C, BN) * 64, 256);
+    SVR_CHECK(L.D < 1022 && L.H < 1022 && L.W < 1022, SVR_E_UNSUPPORTED, "gather_bwd: level %d: dims above 1021", l);
+    fblocks += (unsigned)svr::cdiv(bwd_runs_waves(L.C, d->B, d->N) * 64, 256);
     ++FA.n;
   }
   if (FA.n > 0) {
     FA.block_start[FA.n] = fblocks;
-    hipLaunchKernelGGL(gather_bwd_fused_kernel, dim3(fblocks), dim3(256), 0, s, FA, points, gfeatures, d->order, BN, d->N,
+    hipLaunchKernelGGL(gather_bwd_fused_kernel, dim3(fblocks), dim3(256), 0, s, FA, points, gfeatures, d->order, d->B, d->N,
                        d->row_stride, d->displacement, d->align_corners);
   }
   return svr::launch_status("gather_bwd");

@@ -16,31 +16,46 @@ using namespace svr;
 
 namespace {
 
-constexpr int MORTON_BITS = 6;  // 64^3 cells
+constexpr int MORTON_BITS = 6;  // 64^3 cells for the global order
 
-__device__ __forceinline__ uint32_t spread3(uint32_t v) {  // 6 bits -> every third bit
-  v &= 0x3f;
-  v = (v | (v << 8)) & 0x300f;
-  v = (v | (v << 4)) & 0x30c3;
-  v = (v | (v << 2)) & 0x9249;
-  return v;
+__device__ __forceinline__ uint64_t spread3_10(uint32_t v) {  // 10 bits -> every third bit
+  uint64_t x = v & 0x3ff;
+  x = (x | (x << 16)) & 0x30000ffULL;
+  x = (x | (x << 8)) & 0x300f00fULL;
+  x = (x | (x << 4)) & 0x30c30c3ULL;
+  x = (x | (x << 2)) & 0x9249249ULL;
+  return x;
 }
 
-__global__ void morton_key_kernel(const float *__restrict__ points, uint32_t *__restrict__ keys,
-                                  int32_t *__restrict__ vals, int64_t total, int N) {
+// mode 0: Morton code of the position on a 64^3 lattice.  mode 1: Morton code of the base voxel
+// floor(source index)+1 of the undisplaced sample in a D x H x W volume (same arithmetic as gather.hip;
+// a last-bit difference would only cost a run split, never correctness).
+__global__ void sort_key_kernel(const float *__restrict__ points, uint64_t *__restrict__ keys, int32_t *__restrict__ vals,
+                                int64_t total, int N, int mode, int D, int H, int W, int ac) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
-  uint32_t q[3];
+  uint32_t q[3];  // z, y, x
+  const int S[3] = {D, H, W};
 #pragma unroll
   for (int a = 0; a < 3; ++a) {
     float p = points[i * 3 + a];
-    float f = (p + 0.5f) * (float)(1 << MORTON_BITS);
-    f = fminf(fmaxf(f, 0.f), (float)((1 << MORTON_BITS) - 1));
+    float f;
+    int hi;
+    if (mode == 0) {
+      f = (p + 0.5f) * (float)(1 << MORTON_BITS);
+      hi = (1 << MORTON_BITS) - 1;
+    } else {
+      float g = 2.0f * p;
+      float src = ac ? ((g + 1.0f) / 2.0f) * (float)(S[a] - 1) : ((g + 1.0f) * (float)S[a] - 1.0f) / 2.0f;
+      f = floorf(src) + 1.0f;
+      hi = S[a];
+    }
+    f = fminf(fmaxf(f, 0.f), (float)hi);
     q[a] = (p == p) ? (uint32_t)f : 0u;
   }
   // points[...,0] walks the slowest volume axis (z), [...,2] the fastest (x): x in the low bit
-  uint32_t m = spread3(q[2]) | (spread3(q[1]) << 1) | (spread3(q[0]) << 2);
-  keys[i] = ((uint32_t)(i / N) << (3 * MORTON_BITS)) | m;
+  uint64_t m = spread3_10(q[2]) | (spread3_10(q[1]) << 1) | (spread3_10(q[0]) << 2);
+  keys[i] = ((uint64_t)(i / N) << 30) | m;
   vals[i] = (int32_t)i;
 }
 
@@ -56,47 +71,59 @@ __global__ void permute_points_kernel(const float *__restrict__ points, const in
 
 int key_bits(int B) {
   int bb = 0;
-  while ((1 << bb) < B) ++bb;
-  return 3 * MORTON_BITS + bb;
+  while ((1LL << bb) < B) ++bb;
+  return 30 + bb;
 }
 
 size_t rocprim_temp_bytes(int64_t total, int bits) {
   size_t tmp = 0;
-  rocprim::radix_sort_pairs(nullptr, tmp, (uint32_t *)nullptr, (uint32_t *)nullptr, (int32_t *)nullptr,
+  rocprim::radix_sort_pairs(nullptr, tmp, (uint64_t *)nullptr, (uint64_t *)nullptr, (int32_t *)nullptr,
                             (int32_t *)nullptr, (size_t)total, 0, bits, (hipStream_t)0);
   return tmp;
 }
 
 int64_t align256(int64_t x) { return (x + 255) / 256 * 256; }
 
+int sort_points(const float *points, int32_t *order, float *sorted_points, int B, int N, int mode, int D, int H, int W,
+                int ac, void *workspace, hipStream_t s, const char *what) {
+  int64_t total = (int64_t)B * N;
+  if (total <= 0) return SVR_OK;
+  SVR_CHECK(points && order && workspace, SVR_E_BADARG, "%s: null pointer", what);
+  SVR_CHECK(mode == 0 || (D > 0 && H > 0 && W > 0 && D < 1023 && H < 1023 && W < 1023), SVR_E_UNSUPPORTED,
+            "%s: volume dims must be in [1, 1022]", what);
+  char *w = (char *)workspace;
+  uint64_t *keys_in = (uint64_t *)w;
+  w += align256(total * 8);
+  uint64_t *keys_out = (uint64_t *)w;
+  w += align256(total * 8);
+  int32_t *vals_in = (int32_t *)w;
+  w += align256(total * 4);
+  int bits = key_bits(B);
+  size_t tmp = rocprim_temp_bytes(total, bits);
+  hipLaunchKernelGGL(sort_key_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, s, points, keys_in, vals_in, total, N,
+                     mode, D, H, W, ac);
+  hipError_t e = rocprim::radix_sort_pairs((void *)w, tmp, keys_in, keys_out, vals_in, order, (size_t)total, 0, bits, s);
+  SVR_CHECK(e == hipSuccess, (int)e, "%s: radix sort failed: %s", what, hipGetErrorString(e));
+  if (sorted_points)
+    hipLaunchKernelGGL(permute_points_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, s, points, order,
+                       sorted_points, total);
+  return launch_status(what);
+}
+
 }  // namespace
 
 extern "C" int64_t svr_points_morton_order_workspace(int32_t B, int32_t N) {
   int64_t total = (int64_t)B * N;
   if (total <= 0) return 256;
-  return 3 * align256(total * 4) + align256((int64_t)rocprim_temp_bytes(total, key_bits(B))) + 256;
+  return 2 * align256(total * 8) + align256(total * 4) + align256((int64_t)rocprim_temp_bytes(total, key_bits(B))) + 256;
 }
 
 extern "C" int svr_points_morton_order(const float *points, int32_t *order, float *sorted_points, int32_t B, int32_t N,
                                        void *workspace, void *stream) {
-  int64_t total = (int64_t)B * N;
-  if (total <= 0) return SVR_OK;
-  SVR_CHECK(points && order && workspace, SVR_E_BADARG, "morton_order: null pointer");
-  SVR_CHECK(B < (1 << (32 - 3 * MORTON_BITS)), SVR_E_UNSUPPORTED, "morton_order: batch %d too large for 32-bit keys", B);
-  hipStream_t s = (hipStream_t)stream;
-  char *w = (char *)workspace;
-  uint32_t *keys_in = (uint32_t *)w;
-  w += align256(total * 4);
-  uint32_t *keys_out = (uint32_t *)w;
-  w += align256(total * 4);
-  int32_t *vals_in = (int32_t *)w;
-  w += align256(total * 4);
-  int bits = key_bits(B);
-  size_t tmp = rocprim_temp_bytes(total, bits);
-  hipLaunchKernelGGL(morton_key_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, s, points, keys_in, vals_in, total, N);
-  hipError_t e = rocprim::radix_sort_pairs((void *)w, tmp, keys_in, keys_out, vals_in, order, (size_t)total, 0, bits, s);
-  SVR_CHECK(e == hipSuccess, (int)e, "morton_order: radix sort failed: %s", hipGetErrorString(e));
-  if (sorted_points)
-    hipLaunchKernelGGL(permute_points_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, s, points, order, sorted_points, total);
-  return launch_status("morton_order");
+  return sort_points(points, order, sorted_points, B, N, 0, 0, 0, 0, 0, workspace, (hipStream_t)stream, "morton_order");
+}
+
+extern "C" int svr_points_voxel_order(const float *points, int32_t *order, int32_t B, int32_t N, int32_t D, int32_t H,
+                                      int32_t W, int32_t align_corners, void *workspace, void *stream) {
+  return sort_points(points, order, nullptr, B, N, 1, D, H, W, align_corners, workspace, (hipStream_t)stream, "voxel_order");
 }

@@ -87,7 +87,16 @@ class _EncoderGatherFn(torch.autograd.Function):
         need_x, need_pts = ctx.needs_input_grad[1], ctx.needs_input_grad[2]
         gfeat = gfeat.contiguous()
         gvols = [torch.zeros_like(levels[0]) if need_x else None] + [torch.zeros_like(v) for v in levels[1:]]
-        gpts = ops.gather_bwd(levels, gvols, pts, gfeat, ext._layout, ext._disp, ext._align, want_gpoints=need_pts)
+        # levels with >= ~1 point per voxel get their own visiting order (points sharing a base voxel become
+        # consecutive -> long register runs, few atomics); finer levels keep the natural (Morton) order
+        N = pts.shape[1]
+        level_orders = [None] * len(levels)
+        for l in range(1, len(levels)):
+            dhw = tuple(levels[l].shape[1:4])
+            if N >= 0.5 * dhw[0] * dhw[1] * dhw[2] and N > 64:
+                level_orders[l] = ops.voxel_order(pts, dhw, ext._align)
+        gpts = ops.gather_bwd(levels, gvols, pts, gfeat, ext._layout, ext._disp, ext._align, want_gpoints=need_pts,
+                              level_orders=level_orders)
         grads = {}
         dpooled = None
         gx = None

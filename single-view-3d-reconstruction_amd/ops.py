@@ -72,7 +72,19 @@ def morton_order(points, want_sorted=False):
     return (order, spts) if want_sorted else order
 
 
-def make_gather_desc(vols, gvols, layout, B, N, displacement, align_corners, order=None):
+def voxel_order(points, dims, align_corners=False):
+    """(B*N,) int32: points ordered by the Morton code of their base voxel in a volume of `dims` (D,H,W)."""
+    _f32(points)
+    B, N, _ = points.shape
+    l = _lib.lib()
+    order = torch.empty(B * N, device=points.device, dtype=torch.int32)
+    ws = torch.empty(l.svr_points_morton_order_workspace(B, N), device=points.device, dtype=torch.uint8)
+    check(l.svr_points_voxel_order(_p(points), _p(order), B, N, dims[0], dims[1], dims[2], int(align_corners), _p(ws),
+                                   _stream()), "voxel_order")
+    return order
+
+
+def make_gather_desc(vols, gvols, layout, B, N, displacement, align_corners, order=None, level_orders=None):
     d = GatherDesc()
     d.order = _p(order)
     d.n_levels = len(vols)
@@ -90,6 +102,7 @@ def make_gather_desc(vols, gvols, layout, B, N, displacement, align_corners, ord
         L.vol, L.gvol = _p(v), _p(g)
         L.C, L.D, L.H, L.W = ref.shape[4], ref.shape[1], ref.shape[2], ref.shape[3]
         L.col = layout.col[l]
+        L.order = _p(level_orders[l]) if level_orders is not None else C.c_void_p(0)
     return d
 
 
@@ -103,9 +116,10 @@ def gather_fwd(vols, points, layout, displacement, align_corners, out=None, orde
     return out
 
 
-def gather_bwd(vols, gvols, points, gfeat, layout, displacement, align_corners, want_gpoints=False, order=None):
+def gather_bwd(vols, gvols, points, gfeat, layout, displacement, align_corners, want_gpoints=False, order=None,
+               level_orders=None):
     B, N, _ = points.shape
-    d = make_gather_desc(vols, gvols, layout, B, N, displacement, align_corners, order)
+    d = make_gather_desc(vols, gvols, layout, B, N, displacement, align_corners, order, level_orders)
     gp = torch.empty_like(points) if want_gpoints else None
     check(_lib.lib().svr_gather_trilinear_bwd(C.byref(d), _p(points), _p(gfeat), _p(gp), _stream()), "gather_bwd")
     return gp

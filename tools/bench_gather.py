@@ -42,3 +42,12 @@ for name, p in (("random", pts), ("sorted", pts_sorted)):
         print(f"  bwd level {l} (C={chans[l]}, S={vols[l].shape[1]}): {t:.3f} ms")
     gv = [None] + [torch.zeros_like(v) for v in vols[1:]]
     print("  bwd levels 1-5 fused: %.3f ms" % timeit(lambda: ops.gather_bwd(vols, gv, p, gfeat, layout, disp, False)))
+    lo = [None] * 6
+    for l in (3, 4, 5):
+        lo[l] = ops.voxel_order(p, tuple(vols[l].shape[1:4]))
+    print("  voxel_order x3: %.3f ms" % timeit(lambda: [ops.voxel_order(p, tuple(vols[l].shape[1:4])) for l in (3, 4, 5)]))
+    for l in (3, 4, 5):
+        gv1 = [None] * 6
+        gv1[l] = torch.zeros_like(vols[l])
+        print(f"  bwd level {l} with its voxel order: %.3f ms" % timeit(lambda: ops.gather_bwd(vols, gv1, p, gfeat, layout, disp, False, level_orders=lo)))
+    print("  bwd levels 1-5 fused + level orders: %.3f ms" % timeit(lambda: ops.gather_bwd(vols, gv, p, gfeat, layout, disp, False, level_orders=lo)))
