@@ -113,6 +113,19 @@ int svr_linear_bwd_weight(const float *dY, int64_t lddy, const float *X, int64_t
                           int64_t lddw, float *db, int64_t M, int64_t N, int64_t K,
                           void *workspace, void *stream);
 
+/* The same two backward products on the bf16 matrix cores with a 3-term split (x = hi + mid, products
+ * hi*hi + hi*mid + mid*hi, f32 accumulation): ~1.5e-5 relative error per product, ~5x fewer matrix-core
+ * cycles than the exact-f32 MFMA.  Backward only -- the forward pass (logits, ReLU masks) stays exact f32.
+ * bwd_data workspace: svr_linear_bwd_data_bf16x3_workspace(N, K) bytes (split + transposed weight planes). */
+int64_t svr_linear_bwd_data_bf16x3_workspace(int64_t N, int64_t K);
+int svr_linear_bwd_data_bf16x3(const float *dY, int64_t lddy, const float *W, int64_t ldw, float *dX,
+                               int64_t lddx, int64_t M, int64_t N, int64_t K, int epilogue,
+                               const float *mask, int64_t ldmask, void *workspace, void *stream);
+int64_t svr_linear_bwd_weight_bf16x3_workspace(int64_t M, int64_t N, int64_t K);
+int svr_linear_bwd_weight_bf16x3(const float *dY, int64_t lddy, const float *X, int64_t ldx, float *dW,
+                                 int64_t lddw, float *db, int64_t M, int64_t N, int64_t K,
+                                 void *workspace, void *stream);
+
 /* fc_out (Conv1d(hidden,1,1), model/ifnet.py:35,58-59): logits[r(m)] = H[m,:].w + b, where
  * r(m) = row_map[m] if row_map != NULL (rows were processed in Morton order: scatter the logits back
  * to the caller's point order) else m.                                                            */

@@ -17,6 +17,7 @@ SOURCES = {
     "gather.hip": ["-ffp-contract=off"],
     "sort.hip": [],
     "gemm.hip": [],
+    "gemm_bf16x3.hip": [],
     "conv3d.hip": [],
     "bn_pool.hip": [],
     "projection.hip": ["-ffp-contract=off"],

@@ -1,0 +1,407 @@
+// Backward GEMMs of the point MLP on the bf16 matrix cores with a 3-term split ("bf16x3"), gfx950.
+//
+//   x = hi + mid (+ 2^-16 |x|),  hi = bf16_rne(x),  mid = bf16_rne(x - hi)
+//   a*b ~= a_hi*b_hi + a_hi*b_mid + a_mid*b_hi        (f32 accumulation inside the MFMA)
+//
+// Each product carries a relative error of ~2^-16 = 1.5e-5 with random sign (round-to-nearest splits), i.e.
+// two orders of magnitude below the 1e-3 gradient noise that ReLU-mask flips already put on ANY f32
+// implementation of this network (DESIGN.md "Gradient tolerance"), at ~1/5 of the matrix-core cycles of the
+// exact-f32 MFMA.  It is used ONLY for the two backward products of the MLP layers,
+//     dX = dY W        (svr_linear_bwd_data_bf16x3)
+//     dW = dY^T X      (svr_linear_bwd_weight_bf16x3)
+// never in the forward pass: logits, ReLU masks and everything the 1e-4 parity gate sees stay exact f32.
+//
+// Structure: 128x128 block tile, 4 waves x (2x2) tiles of v_mfma_f32_32x32x16_bf16, k-step 32, two LDS
+// stages.  LDS holds hi/mid planes as [row][k] bf16 with a 72-byte row stride: the transposing store of
+// the dW operands (two consecutive k packed per dword, lane <-> row) is then 2-way conflict at worst and
+// the fragment reads (ds_read_b64, lane <-> row) are conflict free.
+#include "common.h"
+
+using namespace svr;
+
+namespace svr {
+void colsum_launch(const float *Y, int64_t ldy, float *out, float *part, int64_t M, int64_t N, hipStream_t s);
+int64_t colsum_workspace_floats(int64_t M, int64_t N);
+}  // namespace svr
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int XK = 32;    // reduction elements per step
+constexpr int XLD = 36;   // bf16 per LDS row (72 B)
+constexpr int XLW = XLD / 2;  // ... in dwords
+
+// (x0, x1) -> packed bf16 pairs of the hi and mid parts
+__device__ __forceinline__ void split2(float x0, float x1, uint32_t &hi, uint32_t &mid) {
+  f32x2 v = {x0, x1};
+  bf16x2 h = __builtin_convertvector(v, bf16x2);
+  hi = __builtin_bit_cast(uint32_t, h);
+  f32x2 r = {x0 - __uint_as_float(hi << 16), x1 - __uint_as_float(hi & 0xffff0000u)};
+  bf16x2 m = __builtin_convertvector(r, bf16x2);
+  mid = __builtin_bit_cast(uint32_t, m);
+}
+
+// ---- operand loaders (ROWS tile rows, NT threads) -------------------------------------------------
+// A "plane pair" in LDS is uint32_t[2][ROWS * XLW]: hi plane then mid plane, [row][k] bf16.
+// Tile rows past the operand's extent are CLAMPED to the last valid row instead of being zero-filled:
+// they only feed output rows/columns that the guarded epilogue never stores, and clamping keeps the load
+// path free of per-element branches and 64-bit index arithmetic.  Only the reduction tail needs zeros.
+//
+// RowK: f32 source, tile row = operand row, k contiguous.  thread -> (row = t/8 + (NT/8) i, float4 t%8)
+template <int ROWS, int NT>
+struct RowKLoader {
+  static constexpr int R = ROWS * 8 / NT;
+  const float *rowp[R];
+  float4 v[R];
+  __device__ __forceinline__ RowKLoader(const float *src, int64_t ld, int64_t row0, int64_t nrows) {
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+      int64_t r = row0 + (t >> 3) + (NT / 8) * i;
+      r = r < nrows ? r : nrows - 1;
+      rowp[i] = src + r * ld + (t & 7) * 4;
+    }
+  }
+  __device__ __forceinline__ void load(int64_t k0, int64_t) {
+#pragma unroll
+    for (int i = 0; i < R; ++i) v[i] = *reinterpret_cast<const float4 *>(rowp[i] + k0);
+  }
+  __device__ __forceinline__ void store(uint32_t *planes) const {
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+      uint32_t h0, m0, h1, m1;
+      split2(v[i].x, v[i].y, h0, m0);
+      split2(v[i].z, v[i].w, h1, m1);
+      const int off = ((t >> 3) + (NT / 8) * i) * XLW + (t & 7) * 2;
+      *reinterpret_cast<uint2 *>(planes + off) = make_uint2(h0, h1);
+      *reinterpret_cast<uint2 *>(planes + ROWS * XLW + off) = make_uint2(m0, m1);
+    }
+  }
+};
+
+// Planes: pre-split bf16 planes [row][k] in global memory (k contiguous).  thread -> (row = t/4 + (NT/4) i, 16 B part t%4)
+// (8-byte pieces: a 16-byte vector here crashes hipcc 7.2's machine copy propagation)
+template <int ROWS, int NT>
+struct PlaneLoader {
+  static constexpr int R = ROWS * 4 / NT;
+  const uint16_t *ph[R], *pm[R];
+  uint2 vh[R][2], vm[R][2];
+  __device__ __forceinline__ PlaneLoader(const uint16_t *hi, const uint16_t *mid, int64_t ld, int64_t row0, int64_t nrows) {
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+      int64_t r = row0 + (t >> 2) + (NT / 4) * i;
+      r = r < nrows ? r : nrows - 1;
+      ph[i] = hi + r * ld + (t & 3) * 8;
+      pm[i] = mid + r * ld + (t & 3) * 8;
+    }
+  }
+  __device__ __forceinline__ void load(int64_t k0, int64_t) {
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+      const uint2 *qh = reinterpret_cast<const uint2 *>(ph[i] + k0);
+      const uint2 *qm = reinterpret_cast<const uint2 *>(pm[i] + k0);
+      vh[i][0] = qh[0]; vh[i][1] = qh[1];
+      vm[i][0] = qm[0]; vm[i][1] = qm[1];
+    }
+  }
+  __device__ __forceinline__ void store(uint32_t *planes) const {
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+      const int off = ((t >> 2) + (NT / 4) * i) * XLW + (t & 3) * 4;
+      *reinterpret_cast<uint2 *>(planes + off) = vh[i][0];
+      *reinterpret_cast<uint2 *>(planes + off + 2) = vh[i][1];
+      *reinterpret_cast<uint2 *>(planes + ROWS * XLW + off) = vm[i][0];
+      *reinterpret_cast<uint2 *>(planes + ROWS * XLW + off + 2) = vm[i][1];
+    }
+  }
+};
+
+// Transposed: f32 source S[k][col] (col contiguous); the tile row is a source COLUMN.
+// thread -> (col = t % ROWS, k-pair group t / ROWS): coalesced dword loads, one packed dword store per k pair.
+template <int ROWS, int NT>
+struct TransLoader {
+  static constexpr int KG = NT / ROWS;  // k-pair groups
+  static constexpr int P = 16 / KG;     // k pairs per thread
+  const float *colp;                    // &S[first k of this thread][col]
+  int64_t ld;
+  int kfirst;
+  float v[2 * P];
+  __device__ __forceinline__ TransLoader(const float *src, int64_t ld_, int64_t col0, int64_t ncols) : ld(ld_) {
+    const int t = threadIdx.x;
+    int64_t c = col0 + (t % ROWS);
+    c = c < ncols ? c : ncols - 1;
+    kfirst = 2 * (t / ROWS) * P;
+    colp = src + (int64_t)kfirst * ld + c;
+  }
+  // kend: end of the reduction range; a full step (k0 + 32 <= kend) takes the branch-free path
+  __device__ __forceinline__ void load(int64_t k0, int64_t kend) {
+    const float *q = colp + k0 * ld;
+    if (k0 + XK <= kend) {
+#pragma unroll
+      for (int p = 0; p < 2 * P; ++p) v[p] = q[p * ld];
+    } else {
+#pragma unroll
+      for (int p = 0; p < 2 * P; ++p) v[p] = (k0 + kfirst + p < kend) ? q[p * ld] : 0.f;
+    }
+  }
+  __device__ __forceinline__ void store(uint32_t *planes) const {
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      uint32_t h, m;
+      split2(v[2 * p], v[2 * p + 1], h, m);
+      const int off = (t % ROWS) * XLW + (t / ROWS) * P + p;
+      planes[off] = h;
+      planes[ROWS * XLW + off] = m;
+    }
+  }
+};
+
+__device__ __forceinline__ bf16x8 read_frag(const uint32_t *plane, int row, int kword) {
+  // 8 bf16 = 4 dwords at [row][kword .. kword+3]; 8-byte aligned
+  const uint2 lo = *reinterpret_cast<const uint2 *>(plane + row * XLW + kword);
+  const uint2 hi = *reinterpret_cast<const uint2 *>(plane + row * XLW + kword + 2);
+  union { uint4 q; bf16x8 v; } f;
+  f.q = make_uint4(lo.x, lo.y, hi.x, hi.y);
+  return f.v;
+}
+
+// Block tile (WR*64) x (WC*64), WR*WC waves, every wave a 64x64 tile = 2x2 MFMA tiles.
+// lds: [stage 2][ A planes 2*TM*XLW | B planes 2*TN*XLW ] dwords
+template <int WR, int WC>
+struct Geo {
+  static constexpr int NT = WR * WC * 64, TM = WR * 64, TN = WC * 64;
+  static constexpr int STAGE = 2 * (TM + TN) * XLW;  // dwords
+  static constexpr int LDS_DWORDS = 2 * STAGE;
+};
+
+template <int WR, int WC>
+__device__ __forceinline__ void compute_step(const uint32_t *pa, f32x16 (&acc)[2][2]) {
+  using G = Geo<WR, WC>;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wr = wave / WC, wc = wave % WC;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const uint32_t *pb = pa + 2 * G::TM * XLW;
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    bf16x8 ah[2], am[2], bh[2], bm[2];
+    const int kw = ks * 8 + lh * 4;  // dword offset of this lane's 8 k values
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int row = wr * 64 + i * 32 + l31;
+      ah[i] = read_frag(pa, row, kw);
+      am[i] = read_frag(pa + G::TM * XLW, row, kw);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int row = wc * 64 + j * 32 + l31;
+      bh[j] = read_frag(pb, row, kw);
+      bm[j] = read_frag(pb + G::TN * XLW, row, kw);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[i], bh[j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bm[j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+      }
+  }
+}
+
+// Pipeline: the global loads of step s+1 are issued before the MFMAs of step s and converted / written to the
+// other LDS stage after them; one barrier per k-step.  (Two register sets -- loads two steps ahead -- were
+// tried: 200..256 VGPRs, spills, 1.5-4x slower.)
+template <int WR, int WC, class AL, class BL>
+__device__ __forceinline__ void mainloop(AL &al, BL &bl, uint32_t *lds, int64_t kbeg, int64_t kend, f32x16 (&acc)[2][2]) {
+  using G = Geo<WR, WC>;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  if (kbeg >= kend) return;
+  al.load(kbeg, kend);
+  bl.load(kbeg, kend);
+  al.store(lds);
+  bl.store(lds + 2 * G::TM * XLW);
+  __syncthreads();
+  int st = 0;
+  for (int64_t k0 = kbeg; k0 < kend; k0 += XK) {
+    const bool more = k0 + XK < kend;
+    if (more) {
+      al.load(k0 + XK, kend);
+      bl.load(k0 + XK, kend);
+    }
+    compute_step<WR, WC>(lds + st * G::STAGE, acc);
+    if (more) {
+      uint32_t *na = lds + (st ^ 1) * G::STAGE;
+      al.store(na);
+      bl.store(na + 2 * G::TM * XLW);
+    }
+    __syncthreads();
+    st ^= 1;
+  }
+}
+
+template <int WR, int WC, class F>
+__device__ __forceinline__ void foreach_acc(f32x16 (&acc)[2][2], F f) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wr = wave / WC, wc = wave % WC;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = wc * 64 + j * 32 + (lane & 31);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) f(wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), col, acc[i][j][r]);
+    }
+}
+
+// W[n][k] f32 -> planes [k][n] bf16 (hi, mid): the B operand of dX = dY W wants the reduction index n contiguous
+__global__ void pack_planes_kernel(const float *__restrict__ W, int64_t ldw, uint16_t *__restrict__ hi,
+                                   uint16_t *__restrict__ mid, int64_t N, int64_t K) {
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // over (k, n/2)
+  if (idx >= K * (N / 2)) return;
+  int64_t k = idx / (N / 2), n = (idx % (N / 2)) * 2;
+  uint32_t h, m;
+  split2(W[n * ldw + k], W[(n + 1) * ldw + k], h, m);
+  *reinterpret_cast<uint32_t *>(hi + k * N + n) = h;
+  *reinterpret_cast<uint32_t *>(mid + k * N + n) = m;
+}
+
+// dX[M,K] = dY[M,N] W[N,K] (W given as planes [K][N]); optional ReLU mask epilogue.
+// Epilogue: the 128x128 f32 tile goes through LDS so that every wave-instruction writes (and reads the mask
+// as) whole 512-byte row pieces with 16 bytes per lane; the MFMA register layout would give 128-byte pieces
+// of 64 dword stores per lane.
+constexpr int NN_TM = 128, NN_TN = 128, NN_CLD = NN_TN + 4;
+__global__ __launch_bounds__(256) void linear_nn_x3_kernel(const float *__restrict__ dY, int64_t lddy,
+                                                           const uint16_t *__restrict__ Wh,
+                                                           const uint16_t *__restrict__ Wm, float *__restrict__ dX,
+                                                           int64_t lddx, const float *__restrict__ mask, int64_t ldmask,
+                                                           int64_t M, int64_t N, int64_t K) {
+  using G = Geo<2, 2>;
+  static_assert(G::LDS_DWORDS >= NN_TM * NN_CLD, "epilogue tile must fit the staging buffers");
+  __shared__ uint32_t lds[G::LDS_DWORDS];
+  const int64_t c0 = (int64_t)blockIdx.x * NN_TN, m0 = (int64_t)blockIdx.y * NN_TM;
+  RowKLoader<NN_TM, 256> al(dY, lddy, m0, M);
+  PlaneLoader<NN_TN, 256> bl(Wh, Wm, N, c0, K);
+  f32x16 acc[2][2];
+  mainloop<2, 2>(al, bl, lds, 0, N, acc);
+  __syncthreads();  // every wave is done reading operand fragments before the tile overwrites the buffers
+  float *ct = reinterpret_cast<float *>(lds);
+  foreach_acc<2, 2>(acc, [&](int row, int col, float v) { ct[row * NN_CLD + col] = v; });
+  __syncthreads();
+  const int t = threadIdx.x;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int row = (t >> 5) + 8 * i, c4 = (t & 31) * 4;
+    const int64_t m = m0 + row, c = c0 + c4;
+    if (m < M && c < K) {  // K % 4 == 0 (host-checked), so a float4 never straddles the edge
+      float4 v = *reinterpret_cast<const float4 *>(ct + row * NN_CLD + c4);
+      if (mask) {
+        const float4 k4 = *reinterpret_cast<const float4 *>(mask + m * ldmask + c);
+        v.x = k4.x > 0.f ? v.x : 0.f;
+        v.y = k4.y > 0.f ? v.y : 0.f;
+        v.z = k4.z > 0.f ? v.z : 0.f;
+        v.w = k4.w > 0.f ? v.w : 0.f;
+      }
+      *reinterpret_cast<float4 *>(dX + m * lddx + c) = v;
+    }
+  }
+}
+
+// slab[z][N,K] = dY[rows of split z]^T X[rows of split z].  256 x 128 tile (8 waves): with N = 256 every row of
+// X is read from HBM once per split instead of once per 128-row tile.
+constexpr int TN_TM = 256, TN_TN = 128;
+__global__ __launch_bounds__(512) void linear_tn_x3_kernel(const float *__restrict__ dY, int64_t lddy,
+                                                           const float *__restrict__ X, int64_t ldx,
+                                                           float *__restrict__ slab, int64_t M, int64_t N, int64_t K,
+                                                           int64_t rows_per_split) {
+  using G = Geo<4, 2>;
+  __shared__ uint32_t lds[G::LDS_DWORDS];
+  const int64_t j0 = (int64_t)blockIdx.x * TN_TN, i0 = (int64_t)blockIdx.y * TN_TM;
+  const int64_t kbeg = (int64_t)blockIdx.z * rows_per_split;
+  const int64_t kend = min(M, kbeg + rows_per_split);
+  TransLoader<TN_TM, 512> al(dY, lddy, i0, N);
+  TransLoader<TN_TN, 512> bl(X, ldx, j0, K);
+  f32x16 acc[2][2];
+  mainloop<4, 2>(al, bl, lds, kbeg, kend, acc);
+  float *out = slab + (int64_t)blockIdx.z * N * K;
+  foreach_acc<4, 2>(acc, [&](int row, int col, float v) {
+    int64_t i = i0 + row, j = j0 + col;
+    if (i < N && j < K) out[i * K + j] = v;
+  });
+}
+
+__global__ void slab_reduce_x3_kernel(const float *__restrict__ slab, float *__restrict__ out, int64_t rows, int64_t cols,
+                                      int64_t ldo, int splits) {
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= rows * cols) return;
+  float s = 0.f;
+  for (int z = 0; z < splits; ++z) s += slab[(int64_t)z * rows * cols + idx];
+  out[(idx / cols) * ldo + (idx % cols)] = s;
+}
+
+int tn_splits(int64_t M, int64_t N, int64_t K, int64_t *rows_per_split) {
+  int64_t tiles = cdiv(N, TN_TM) * cdiv(K, TN_TN);
+  int64_t want = cdiv(512, tiles);  // one 8-wave workgroup per CU, two rounds
+  if (want < 1) want = 1;
+  int64_t rps = cdiv(cdiv(M, want), XK) * XK;  // multiple of the k-step
+  if (rps < XK) rps = XK;
+  *rows_per_split = rps;
+  return (int)cdiv(M, rps);
+}
+
+}  // namespace
+
+extern "C" int64_t svr_linear_bwd_data_bf16x3_workspace(int64_t N, int64_t K) { return 2 * N * K * (int64_t)sizeof(uint16_t) + 256; }
+
+extern "C" int svr_linear_bwd_data_bf16x3(const float *dY, int64_t lddy, const float *W, int64_t ldw, float *dX, int64_t lddx,
+                                          int64_t M, int64_t N, int64_t K, int epilogue, const float *mask, int64_t ldmask,
+                                          void *workspace, void *stream) {
+  SVR_CHECK(dY && W && dX && workspace, SVR_E_BADARG, "linear_bwd_data_bf16x3: null pointer");
+  SVR_CHECK(M >= 0 && N > 0 && K > 0 && N % XK == 0 && K % 4 == 0 && lddx % 4 == 0 && ldmask % 4 == 0, SVR_E_BADSHAPE,
+            "linear_bwd_data_bf16x3: M=%ld N=%ld K=%ld (need N %% 32 == 0, K and leading dims %% 4 == 0)", (long)M, (long)N, (long)K);
+  SVR_CHECK(lddy % 4 == 0 && ((uintptr_t)dY & 15) == 0, SVR_E_ALIGN, "linear_bwd_data_bf16x3: dY must be 16-byte aligned");
+  SVR_CHECK(epilogue == SVR_EPI_NONE || (epilogue == SVR_EPI_MASK && mask), SVR_E_BADARG, "linear_bwd_data_bf16x3: epilogue %d", epilogue);
+  if (M == 0) return SVR_OK;
+  hipStream_t s = (hipStream_t)stream;
+  uint16_t *hi = (uint16_t *)(((uintptr_t)workspace + 15) & ~(uintptr_t)15);
+  uint16_t *mid = hi + N * K;
+  hipLaunchKernelGGL(pack_planes_kernel, dim3((unsigned)cdiv(K * (N / 2), 256)), dim3(256), 0, s, W, ldw, hi, mid, N, K);
+  dim3 grid((unsigned)cdiv(K, NN_TN), (unsigned)cdiv(M, NN_TM));
+  hipLaunchKernelGGL(linear_nn_x3_kernel, grid, dim3(256), 0, s, dY, lddy, hi, mid, dX, lddx,
+                     epilogue == SVR_EPI_MASK ? mask : nullptr, ldmask, M, N, K);
+  return launch_status("linear_bwd_data_bf16x3");
+}
+
+extern "C" int64_t svr_linear_bwd_weight_bf16x3_workspace(int64_t M, int64_t N, int64_t K) {
+  int64_t rps;
+  int splits = tn_splits(M, N, K, &rps);
+  return ((int64_t)splits * N * K + colsum_workspace_floats(M, N)) * (int64_t)sizeof(float);
+}
+
+extern "C" int svr_linear_bwd_weight_bf16x3(const float *dY, int64_t lddy, const float *X, int64_t ldx, float *dW,
+                                            int64_t lddw, float *db, int64_t M, int64_t N, int64_t K, void *workspace,
+                                            void *stream) {
+  SVR_CHECK(dY && X && dW && workspace, SVR_E_BADARG, "linear_bwd_weight_bf16x3: null pointer");
+  SVR_CHECK(M > 0 && N > 0 && K > 0, SVR_E_BADSHAPE, "linear_bwd_weight_bf16x3: M=%ld N=%ld K=%ld", (long)M, (long)N, (long)K);
+  hipStream_t s = (hipStream_t)stream;
+  int64_t rps;
+  int splits = tn_splits(M, N, K, &rps);
+  float *slab = (float *)workspace;
+  dim3 grid((unsigned)cdiv(K, TN_TN), (unsigned)cdiv(N, TN_TM), (unsigned)splits);
+  hipLaunchKernelGGL(linear_tn_x3_kernel, grid, dim3(512), 0, s, dY, lddy, X, ldx, slab, M, N, K, rps);
+  hipLaunchKernelGGL(slab_reduce_x3_kernel, dim3((unsigned)cdiv(N * K, 256)), dim3(256), 0, s, slab, dW, N, K, lddw, splits);
+  if (db) colsum_launch(dY, lddy, db, slab + (int64_t)splits * N * K, M, N, s);
+  return launch_status("linear_bwd_weight_bf16x3");
+}

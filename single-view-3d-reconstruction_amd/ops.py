@@ -151,7 +151,12 @@ def linear_fwd(x, w, bias, relu=True, out=None):
     return out
 
 
-def linear_bwd_data(dy, w, mask=None, out=None):
+# Arithmetic of the two backward GEMMs of the point MLP: "bf16x3" (3-term bf16 split on the bf16 matrix cores,
+# ~1.5e-5 relative per product, see gemm_bf16x3.hip) or "f32" (exact-f32 MFMA).  The forward is always exact f32.
+BACKWARD_GEMM = "bf16x3"
+
+
+def linear_bwd_data(dy, w, mask=None, out=None, mode=None):
     """dx = (dy @ w) [* (mask > 0)]; dy (M,N), w (N,K)."""
     _f32(dy, w, mask)
     M, N = dy.shape
@@ -159,6 +164,15 @@ def linear_bwd_data(dy, w, mask=None, out=None):
     if out is None:
         out = torch.empty(M, K, device=dy.device, dtype=torch.float32)
     epi = EPI_MASK if mask is not None else EPI_NONE
+    if (mode or BACKWARD_GEMM) == "bf16x3" and N % 32 == 0:
+        l = _lib.lib()
+        ws = torch.empty(l.svr_linear_bwd_data_bf16x3_workspace(N, K), device=dy.device, dtype=torch.uint8)
+        check(l.svr_linear_bwd_data_bf16x3(C.c_void_p(dy.data_ptr()), dy.stride(0), C.c_void_p(w.data_ptr()), w.stride(0),
+                                           C.c_void_p(out.data_ptr()), out.stride(0), M, N, K, epi,
+                                           C.c_void_p(mask.data_ptr()) if mask is not None else C.c_void_p(0),
+                                           mask.stride(0) if mask is not None else 0, _p(ws), _stream()),
+              "linear_bwd_data_bf16x3")
+        return out
     check(_lib.lib().svr_linear_bwd_data(C.c_void_p(dy.data_ptr()), dy.stride(0), C.c_void_p(w.data_ptr()), w.stride(0),
                                          C.c_void_p(out.data_ptr()), out.stride(0), M, N, K, epi,
                                          C.c_void_p(mask.data_ptr()) if mask is not None else C.c_void_p(0),
@@ -166,15 +180,21 @@ def linear_bwd_data(dy, w, mask=None, out=None):
     return out
 
 
-def linear_bwd_weight(dy, x, want_bias=True):
+def linear_bwd_weight(dy, x, want_bias=True, mode=None):
     """dW (N,K) = dy.T @ x, db (N) = dy.sum(0)."""
     _f32(dy, x)
     M, N = dy.shape
     K = x.shape[1]
     l = _lib.lib()
-    ws = torch.empty(l.svr_linear_bwd_weight_workspace(M, N, K), device=dy.device, dtype=torch.uint8)
     dw = torch.empty(N, K, device=dy.device, dtype=torch.float32)
     db = torch.empty(N, device=dy.device, dtype=torch.float32) if want_bias else None
+    if (mode or BACKWARD_GEMM) == "bf16x3":
+        ws = torch.empty(l.svr_linear_bwd_weight_bf16x3_workspace(M, N, K), device=dy.device, dtype=torch.uint8)
+        check(l.svr_linear_bwd_weight_bf16x3(C.c_void_p(dy.data_ptr()), dy.stride(0), C.c_void_p(x.data_ptr()), x.stride(0),
+                                             _p(dw), dw.stride(0), _p(db), M, N, K, _p(ws), _stream()),
+              "linear_bwd_weight_bf16x3")
+        return dw, db
+    ws = torch.empty(l.svr_linear_bwd_weight_workspace(M, N, K), device=dy.device, dtype=torch.uint8)
     check(l.svr_linear_bwd_weight(C.c_void_p(dy.data_ptr()), dy.stride(0), C.c_void_p(x.data_ptr()), x.stride(0),
                                   _p(dw), dw.stride(0), _p(db), M, N, K, _p(ws), _stream()), "linear_bwd_weight")
     return dw, db

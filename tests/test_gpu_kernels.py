@@ -119,11 +119,16 @@ def test_linear_fwd_bwd(M, N, K):
     assert G.rel_err(y.cpu().numpy(), y_ref.numpy()) < 2e-6
     dy = torch.randn(M, N, generator=g)
     dx_ref = (dy.double() @ w.double()) * (x.double() > 0)
-    dx = ops.linear_bwd_data(dy.cuda(), w.cuda(), mask=x.cuda())
-    assert G.rel_err(dx.cpu().numpy(), dx_ref.numpy()) < 2e-6
-    dw, db = ops.linear_bwd_weight(dy.cuda(), x.cuda())
-    assert G.rel_err(dw.cpu().numpy(), (dy.double().t() @ x.double()).numpy()) < 2e-6
-    assert G.rel_err(db.cpu().numpy(), dy.double().sum(0).numpy()) < 2e-6
+    dw_ref = dy.double().t() @ x.double()
+    # exact-f32 MFMA: 2e-6;  bf16x3 split (backward default): 2^-16 per product -> 5e-5
+    for mode, tol in (("f32", 2e-6), ("bf16x3", 5e-5)):
+        dx = ops.linear_bwd_data(dy.cuda(), w.cuda(), mask=x.cuda(), mode=mode)
+        assert G.rel_err(dx.cpu().numpy(), dx_ref.numpy()) < tol, mode
+        dxn = ops.linear_bwd_data(dy.cuda(), w.cuda(), mode=mode)
+        assert G.rel_err(dxn.cpu().numpy(), (dy.double() @ w.double()).numpy()) < tol, mode
+        dw, db = ops.linear_bwd_weight(dy.cuda(), x.cuda(), mode=mode)
+        assert G.rel_err(dw.cpu().numpy(), dw_ref.numpy()) < tol, mode
+        assert G.rel_err(db.cpu().numpy(), dy.double().sum(0).numpy()) < 2e-6
 
 
 def test_fc_out_and_bce():
