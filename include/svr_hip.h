@@ -113,6 +113,14 @@ int svr_linear_bwd_weight(const float *dY, int64_t lddy, const float *X, int64_t
                           int64_t lddw, float *db, int64_t M, int64_t N, int64_t K,
                           void *workspace, void *stream);
 
+/* Forward product at f32 accuracy on the bf16 matrix cores: x = hi + mid + lo (three bf16 terms = 24
+ * mantissa bits), six MFMA products, f32 accumulation; agrees with svr_linear_fwd to ~2e-7 relative.
+ * epilogue NONE / BIAS / BIAS_RELU.  workspace: svr_linear_fwd_bf16x6_workspace(N, K) bytes.          */
+int64_t svr_linear_fwd_bf16x6_workspace(int64_t N, int64_t K);
+int svr_linear_fwd_bf16x6(const float *X, int64_t ldx, const float *W, int64_t ldw, const float *bias,
+                          float *Y, int64_t ldy, int64_t M, int64_t N, int64_t K, int epilogue,
+                          void *workspace, void *stream);
+
 /* The same two backward products on the bf16 matrix cores with a 3-term split (x = hi + mid, products
  * hi*hi + hi*mid + mid*hi, f32 accumulation): ~1.5e-5 relative error per product, ~5x fewer matrix-core
  * cycles than the exact-f32 MFMA.  Backward only -- the forward pass (logits, ReLU masks) stays exact f32.

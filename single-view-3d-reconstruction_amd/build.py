@@ -18,6 +18,7 @@ SOURCES = {
     "sort.hip": [],
     "gemm.hip": [],
     "gemm_bf16x3.hip": [],
+    "gemm_bf16x6.hip": [],
     "conv3d.hip": [],
     "bn_pool.hip": [],
     "projection.hip": ["-ffp-contract=off"],

@@ -136,7 +136,12 @@ def corner_indices(vols, points, layout, level, displacement, align_corners):
 # ------------------------------------------------------------------------------------------
 # point MLP
 # ------------------------------------------------------------------------------------------
-def linear_fwd(x, w, bias, relu=True, out=None):
+# Arithmetic of the forward GEMMs of the point MLP: "bf16x6" (6-product bf16 split, f32-equivalent accuracy,
+# gemm_bf16x6.hip) or "f32" (exact-f32 MFMA).
+FORWARD_GEMM = "bf16x6"
+
+
+def linear_fwd(x, w, bias, relu=True, out=None, mode=None):
     """y = [relu](x @ w.T + bias); x (M,K) row stride may exceed K (padded feature rows)."""
     _f32(x, w, bias)
     M, K = x.shape
@@ -145,6 +150,12 @@ def linear_fwd(x, w, bias, relu=True, out=None):
     if out is None:
         out = torch.empty(M, N, device=x.device, dtype=torch.float32)
     epi = EPI_NONE if bias is None else (EPI_BIAS_RELU if relu else EPI_BIAS)
+    if (mode or FORWARD_GEMM) == "bf16x6" and K % 16 == 0:
+        l = _lib.lib()
+        ws = torch.empty(l.svr_linear_fwd_bf16x6_workspace(N, K), device=x.device, dtype=torch.uint8)
+        check(l.svr_linear_fwd_bf16x6(C.c_void_p(x.data_ptr()), x.stride(0), C.c_void_p(w.data_ptr()), w.stride(0), _p(bias),
+                                      _p(out), out.stride(0), M, N, K, epi, _p(ws), _stream()), "linear_fwd_bf16x6")
+        return out
     check(_lib.lib().svr_linear_fwd(C.c_void_p(x.data_ptr()), x.stride(0), C.c_void_p(w.data_ptr()), w.stride(0),
                                     _p(bias), _p(out), out.stride(0), M, N, K, epi, C.c_void_p(0), 0, _stream()),
           "linear_fwd")

@@ -115,8 +115,11 @@ def test_linear_fwd_bwd(M, N, K):
     w = torch.randn(N, K, generator=g) / K ** 0.5
     b = torch.randn(N, generator=g)
     y_ref = F.relu(x.double() @ w.double().t() + b.double())
-    y = ops.linear_fwd(x.cuda(), w.cuda(), b.cuda(), relu=True)
-    assert G.rel_err(y.cpu().numpy(), y_ref.numpy()) < 2e-6
+    for mode in ("f32", "bf16x6"):          # both forward paths are held to the same f32-level gate
+        y = ops.linear_fwd(x.cuda(), w.cuda(), b.cuda(), relu=True, mode=mode)
+        assert G.rel_err(y.cpu().numpy(), y_ref.numpy()) < 2e-6, mode
+        yl = ops.linear_fwd(x.cuda(), w.cuda(), b.cuda(), relu=False, mode=mode)
+        assert G.rel_err(yl.cpu().numpy(), (x.double() @ w.double().t() + b.double()).numpy()) < 2e-6, mode
     dy = torch.randn(M, N, generator=g)
     dx_ref = (dy.double() @ w.double()) * (x.double() > 0)
     dw_ref = dy.double().t() @ x.double()
