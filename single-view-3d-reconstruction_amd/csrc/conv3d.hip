@@ -261,6 +261,101 @@ __global__ __launch_bounds__(256) void conv3d_bwd_weight_kernel(const float *__r
   }
 }
 
+// ---- backward-weight, brick version (production): a workgroup walks 4x4x8-voxel bricks of the output.
+// Per brick it stages the 32-channel slice of the input WITH its one-voxel halo (6x6x10 voxels) and the
+// 32-channel slice of dout in LDS once, and all 27 taps are then served from LDS: the shifted input voxel
+// of a tap is a constant offset in the halo tile.  The voxels are the MFMA k (32x32x2, exact f32):
+//   A[i = ci][k = voxel] = in[voxel + tap][ci]   (32 consecutive channels of one voxel: conflict free)
+//   B[k = voxel][j = co] = dout[voxel][co]       (loaded once per k pair, reused by the wave's 7 taps)
+// Wave w owns taps w, w+4, ...; the 27 accumulator tiles stay in registers across ALL bricks of the
+// workgroup (persistent loop), so the partial sums leave the chip once per workgroup (slab + ordered sum).
+constexpr int BRZ = 4, BRY = 4, BRX = 8, BRV = BRZ * BRY * BRX;          // brick: 128 voxels
+constexpr int HLZ = BRZ + 2, HLY = BRY + 2, HLX = BRX + 2, HLV = HLZ * HLY * HLX;  // halo tile: 360 voxels
+constexpr int BCP = 33;                                                  // padded channel stride (floats)
+
+__global__ __launch_bounds__(256) void conv3d_bwd_weight_brick_kernel(const float *__restrict__ in,
+                                                                      const float *__restrict__ dout,
+                                                                      float *__restrict__ slab, ConvShape s, int nbz,
+                                                                      int nby, int nbx, int co_tiles) {
+  __shared__ float sin[HLV * BCP];
+  __shared__ float sdo[BRV * BCP];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int pair = blockIdx.y;
+  const int ci0 = (pair / co_tiles) * 32, co0 = (pair % co_tiles) * 32;
+  const int64_t bricks = (int64_t)s.B * nbz * nby * nbx;
+  int tapoff[7];
+#pragma unroll
+  for (int ti = 0; ti < 7; ++ti) {
+    const int tap = wave + 4 * ti;
+    tapoff[ti] = ((tap / 9 - 1) * HLY + ((tap / 3) % 3 - 1)) * HLX + (tap % 3 - 1);
+  }
+  f32x16 acc[7];
+#pragma unroll
+  for (int ti = 0; ti < 7; ++ti)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[ti][r] = 0.f;
+
+  for (int64_t brick = blockIdx.x; brick < bricks; brick += gridDim.x) {
+    int64_t q = brick;
+    const int bx = (int)(q % nbx); q /= nbx;
+    const int by = (int)(q % nby); q /= nby;
+    const int bz = (int)(q % nbz);
+    const int64_t b = q / nbz;
+    const int z0 = bz * BRZ, y0 = by * BRY, x0 = bx * BRX;
+    const float *inb = in + b * (int64_t)s.D * s.H * s.W * s.Ci;
+    const float *dob = dout + b * (int64_t)s.D * s.H * s.W * s.Co;
+    // stage the input halo tile: (voxel, float4 of 4 channels)
+    for (int idx = t; idx < HLV * 8; idx += 256) {
+      const int hv = idx >> 3, c4 = (idx & 7) * 4;
+      const int hx = hv % HLX, hy = (hv / HLX) % HLY, hz = hv / (HLX * HLY);
+      const int gz = z0 + hz - 1, gy = y0 + hy - 1, gx = x0 + hx - 1;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (gz >= 0 && gz < s.D && gy >= 0 && gy < s.H && gx >= 0 && gx < s.W && ci0 + c4 < s.Ci)
+        v = *reinterpret_cast<const float4 *>(inb + (((int64_t)gz * s.H + gy) * s.W + gx) * s.Ci + ci0 + c4);
+      float *d = sin + hv * BCP + c4;
+      d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    }
+    for (int idx = t; idx < BRV * 8; idx += 256) {
+      const int v_ = idx >> 3, c4 = (idx & 7) * 4;
+      const int vx = v_ % BRX, vy = (v_ / BRX) % BRY, vz = v_ / (BRX * BRY);
+      const int gz = z0 + vz, gy = y0 + vy, gx = x0 + vx;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (gz < s.D && gy < s.H && gx < s.W && co0 + c4 < s.Co)
+        v = *reinterpret_cast<const float4 *>(dob + (((int64_t)gz * s.H + gy) * s.W + gx) * s.Co + co0 + c4);
+      float *d = sdo + v_ * BCP + c4;
+      d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int kp = 0; kp < BRV / 2; ++kp) {
+      const int v_ = 2 * kp + lh;
+      const int vx = v_ % BRX, vy = (v_ / BRX) % BRY, vz = v_ / (BRX * BRY);
+      const int hbase = (((vz + 1) * HLY + vy + 1) * HLX + vx + 1) * BCP + l31;
+      const float bv = sdo[v_ * BCP + l31];
+#pragma unroll
+      for (int ti = 0; ti < 7; ++ti) {
+        if (wave + 4 * ti < 27) {  // wave-uniform
+          const float av = sin[hbase + tapoff[ti] * BCP];
+          acc[ti] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[ti], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();
+  }
+  // slab layout shared with the reduce kernel: [part][tap][pair][32 ci][32 co]
+  const int pairs = gridDim.y;
+#pragma unroll
+  for (int ti = 0; ti < 7; ++ti) {
+    const int tap = wave + 4 * ti;
+    if (tap < 27) {
+      float *o = slab + ((((int64_t)blockIdx.x) * 27 + tap) * pairs + pair) * 1024;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[((r & 3) + 8 * (r >> 2) + 4 * lh) * 32 + l31] = acc[ti][r];
+    }
+  }
+}
+
 __global__ void conv3d_bwd_weight_reduce_kernel(const float *__restrict__ slab, float *__restrict__ dWp, int Ci, int Co,
                                                 int ci_tiles, int co_tiles, int parts) {
   int idx = blockIdx.x * blockDim.x + threadIdx.x;  // over [tap][tile][32][32]
@@ -328,6 +423,15 @@ __global__ void conv3d_c1_bwd_weight_reduce_kernel(const float *__restrict__ sla
   double sum = 0.0;
   for (int p = 0; p < parts; ++p) sum += (double)slab[(int64_t)p * 1024 + idx];
   dWp[tap * Co + co] = (float)sum;
+}
+
+// workgroups (= partial slabs) per channel-tile pair of the brick backward-weight kernel: ~2 per CU in total
+int bw_brick_parts(int B, int D, int H, int W, int Ci, int Co) {
+  int64_t bricks = (int64_t)B * cdiv(D, BRZ) * cdiv(H, BRY) * cdiv(W, BRX);
+  int64_t pairs = cdiv(Ci, 32) * cdiv(Co, 32);
+  int64_t parts = cdiv(512, pairs);
+  if (parts > bricks) parts = bricks;
+  return (int)(parts < 1 ? 1 : parts);
 }
 
 int check_shape(int B, int D, int H, int W, int Ci, int Co) {
@@ -403,7 +507,7 @@ extern "C" int64_t svr_conv3d_k3_bwd_weight_workspace(int32_t B, int32_t D, int3
   int64_t cs = colsum_workspace_floats(M, Co);
   if (Ci == 1) return (chunks * 4 * 1024 + cs) * (int64_t)sizeof(float);
   int64_t tiles = cdiv(Ci, 32) * cdiv(Co, 32);
-  return (chunks * 4 * 27 * tiles * 1024 + cs) * (int64_t)sizeof(float);
+  return ((int64_t)bw_brick_parts(B, D, H, W, Ci, Co) * 27 * tiles * 1024 + cs) * (int64_t)sizeof(float);
 }
 
 extern "C" int svr_conv3d_k3_bwd_weight(const float *in, const float *dout, float *dWp, float *db, int32_t B, int32_t D,
@@ -422,12 +526,15 @@ extern "C" int svr_conv3d_k3_bwd_weight(const float *in, const float *dout, floa
     hipLaunchKernelGGL(conv3d_c1_bwd_weight_reduce_kernel, dim3(4), dim3(256), 0, s, slab, dWp, Co, chunks * 4);
     slab_floats = (int64_t)chunks * 4 * 1024;
   } else {
+    SVR_CHECK(Ci % 4 == 0 && Co % 4 == 0, SVR_E_UNSUPPORTED, "conv3d_bwd_weight: need Ci, Co %% 4 == 0 (Ci=%d Co=%d)", Ci, Co);
     int cit = (int)cdiv(Ci, 32), cot = (int)cdiv(Co, 32);
-    dim3 grid(27, (unsigned)(cit * cot), (unsigned)chunks);
-    hipLaunchKernelGGL(conv3d_bwd_weight_kernel, grid, dim3(256), 0, s, in, dout, slab, sh, cit, cot);
+    int nbz = (int)cdiv(D, BRZ), nby = (int)cdiv(H, BRY), nbx = (int)cdiv(W, BRX);
+    int parts = bw_brick_parts(B, D, H, W, Ci, Co);
+    dim3 grid((unsigned)parts, (unsigned)(cit * cot));
+    hipLaunchKernelGGL(conv3d_bwd_weight_brick_kernel, grid, dim3(256), 0, s, in, dout, slab, sh, nbz, nby, nbx, cot);
     int per = 27 * cit * cot * 1024;
-    hipLaunchKernelGGL(conv3d_bwd_weight_reduce_kernel, dim3(cdiv(per, 256)), dim3(256), 0, s, slab, dWp, Ci, Co, cit, cot, chunks * 4);
-    slab_floats = (int64_t)chunks * 4 * per;
+    hipLaunchKernelGGL(conv3d_bwd_weight_reduce_kernel, dim3(cdiv(per, 256)), dim3(256), 0, s, slab, dWp, Ci, Co, cit, cot, parts);
+    slab_floats = (int64_t)parts * per;
   }
   if (db) colsum_launch(dout, Co, db, slab + slab_floats, nrows * W, Co, s);
   return launch_status("conv3d_bwd_weight");
