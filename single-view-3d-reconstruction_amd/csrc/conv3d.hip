@@ -356,6 +356,111 @@ __global__ __launch_bounds__(256) void conv3d_bwd_weight_brick_kernel(const floa
   }
 }
 
+// ---- forward / backward-data, brick version (production): one workgroup = one 4x4x8 output brick, wave w
+// = z-slice w (32 voxels = one MFMA row tile), all Co columns.  Per CK-channel chunk of the input the halo
+// tile (6x6x10 voxels) is staged in LDS once and serves all 27 taps (the plain implicit GEMM re-reads every
+// input voxel 27 times from L2, which is what bounds the Co = 32 layers).  Exact f32 (32x32x2 MFMA):
+//   A[i = voxel][k = ci] from LDS (voxel stride CK+1 floats: conflict free), B[k = ci][j = co] = Wp rows
+//   straight from global memory (128-B rows, shared by every wave on the chip -> L1/L2 hits).
+template <int CK, int TNB>
+__global__ __launch_bounds__(256) void conv3d_brick_kernel(const float *__restrict__ in, const float *__restrict__ Wp,
+                                                           const float *__restrict__ bias, float *__restrict__ out,
+                                                           const float *__restrict__ mask, ConvShape s, int nbz, int nby,
+                                                           int nbx, int mode) {
+  constexpr int CP = CK + 1;
+  constexpr int NC = TNB * 32;                 // output columns of this workgroup
+  constexpr int WQ = CK * NC / 4;              // float4 per weight slice (one tap, CK input channels)
+  constexpr int WR_ = (WQ + 255) / 256;        // float4 per thread
+  __shared__ float sin[HLV * CP];
+  __shared__ float sw[2][CK * NC];             // weight slice of the current / next tap: [ci][co]
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int l31 = lane & 31, lh = lane >> 5;
+  int64_t q = blockIdx.x;
+  const int bx = (int)(q % nbx); q /= nbx;
+  const int by = (int)(q % nby); q /= nby;
+  const int bz = (int)(q % nbz);
+  const int64_t b = q / nbz;
+  const int z0 = bz * BRZ, y0 = by * BRY, x0 = bx * BRX;
+  const int co0 = blockIdx.y * NC;
+  const float *inb = in + b * (int64_t)s.D * s.H * s.W * s.Ci;
+  // this lane's A voxel inside the wave's z-slice
+  const int avy = l31 / BRX, avx = l31 % BRX;
+  const int hbase = (((wave + 1) * HLY + avy + 1) * HLX + avx + 1) * CP;
+  f32x16 acc[TNB];
+#pragma unroll
+  for (int j = 0; j < TNB; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+  float4 wreg[WR_];
+  auto wload = [&](int ci0, int tap) {
+#pragma unroll
+    for (int i = 0; i < WR_; ++i) {
+      const int idx = t + 256 * i;
+      const int k = idx / (NC / 4), c4 = (idx % (NC / 4)) * 4;
+      wreg[i] = (idx < WQ && co0 + c4 < s.Co)
+                    ? *reinterpret_cast<const float4 *>(Wp + ((int64_t)tap * s.Ci + ci0 + k) * s.Co + co0 + c4)
+                    : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto wstore = [&](float *dst) {
+#pragma unroll
+    for (int i = 0; i < WR_; ++i) {
+      const int idx = t + 256 * i;
+      if (idx < WQ) *reinterpret_cast<float4 *>(dst + idx * 4) = wreg[i];
+    }
+  };
+
+  for (int ci0 = 0; ci0 < s.Ci; ci0 += CK) {
+    wload(ci0, 0);
+    if (ci0 > 0) __syncthreads();  // every wave is done with the previous chunk's halo tile and weight slices
+    for (int idx = t; idx < HLV * (CK / 4); idx += 256) {
+      const int hv = idx / (CK / 4), c4 = (idx % (CK / 4)) * 4;
+      const int hx = hv % HLX, hy = (hv / HLX) % HLY, hz = hv / (HLX * HLY);
+      const int gz = z0 + hz - 1, gy = y0 + hy - 1, gx = x0 + hx - 1;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (gz >= 0 && gz < s.D && gy >= 0 && gy < s.H && gx >= 0 && gx < s.W)
+        v = *reinterpret_cast<const float4 *>(inb + (((int64_t)gz * s.H + gy) * s.W + gx) * s.Ci + ci0 + c4);
+      float *d = sin + hv * CP + c4;
+      d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    }
+    wstore(sw[0]);
+    __syncthreads();
+    for (int tap = 0; tap < 27; ++tap) {
+      if (tap + 1 < 27) wload(ci0, tap + 1);
+      const int toff = (((tap / 9 - 1) * HLY + ((tap / 3) % 3 - 1)) * HLX + (tap % 3 - 1)) * CP;
+      const float *wb = sw[tap & 1] + lh * NC + l31;
+#pragma unroll
+      for (int kp = 0; kp < CK / 2; ++kp) {
+        const float av = sin[hbase + toff + 2 * kp + lh];
+#pragma unroll
+        for (int j = 0; j < TNB; ++j)
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, wb[2 * kp * NC + j * 32], acc[j], 0, 0, 0);
+      }
+      if (tap + 1 < 27) wstore(sw[(tap + 1) & 1]);
+      __syncthreads();
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < TNB; ++j) {
+    const int co = co0 + j * 32 + l31;
+    if (co >= s.Co) continue;
+    const float bv = (mode == SVR_EPI_BIAS || mode == SVR_EPI_BIAS_RELU) ? bias[co] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int i = (r & 3) + 8 * (r >> 2) + 4 * lh;
+      const int gz = z0 + wave, gy = y0 + i / BRX, gx = x0 + i % BRX;
+      if (gz < s.D && gy < s.H && gx < s.W) {
+        const int64_t o = ((((int64_t)b * s.D + gz) * s.H + gy) * s.W + gx) * s.Co + co;
+        float v = acc[j][r] + bv;
+        if (mode == SVR_EPI_BIAS_RELU) v = fmaxf(v, 0.f);
+        if (mode == SVR_EPI_MASK) v = mask[o] > 0.f ? v : 0.f;
+        out[o] = v;
+      }
+    }
+  }
+}
+
 __global__ void conv3d_bwd_weight_reduce_kernel(const float *__restrict__ slab, float *__restrict__ dWp, int Ci, int Co,
                                                 int ci_tiles, int co_tiles, int parts) {
   int idx = blockIdx.x * blockDim.x + threadIdx.x;  // over [tap][tile][32][32]
@@ -484,18 +589,19 @@ extern "C" int svr_conv3d_k3(const float *in, const float *Wp, const float *bias
   }
   SVR_CHECK(Ci % 16 == 0 && Co % 4 == 0, SVR_E_UNSUPPORTED, "conv3d: need Ci %% 16 == 0 and Co %% 4 == 0 (Ci=%d Co=%d)", Ci, Co);
   SVR_CHECK((((uintptr_t)in | (uintptr_t)Wp) & 15) == 0, SVR_E_ALIGN, "conv3d: operands must be 16-byte aligned");
-  if (Co <= 32) {
-    typedef TileCfg<4, 1, 1, 1> Cfg;
-    dim3 grid((unsigned)cdiv(M, Cfg::BM), (unsigned)cdiv(Co, Cfg::BN));
-    hipLaunchKernelGGL(conv3d_igemm_kernel<Cfg>, grid, dim3(256), 0, s, in, Wp, bias, out, mask, sh, epilogue);
-  } else if (Co <= 64) {
-    typedef TileCfg<4, 1, 1, 2> Cfg;
-    dim3 grid((unsigned)cdiv(M, Cfg::BM), (unsigned)cdiv(Co, Cfg::BN));
-    hipLaunchKernelGGL(conv3d_igemm_kernel<Cfg>, grid, dim3(256), 0, s, in, Wp, bias, out, mask, sh, epilogue);
-  } else {
-    typedef TileCfg<2, 2, 2, 2> Cfg;
-    dim3 grid((unsigned)cdiv(M, Cfg::BM), (unsigned)cdiv(Co, Cfg::BN));
-    hipLaunchKernelGGL(conv3d_igemm_kernel<Cfg>, grid, dim3(256), 0, s, in, Wp, bias, out, mask, sh, epilogue);
+  {
+    const int nbz = (int)cdiv(D, BRZ), nby = (int)cdiv(H, BRY), nbx = (int)cdiv(W, BRX);
+    const unsigned bricks = (unsigned)((int64_t)B * nbz * nby * nbx);
+#define LAUNCH_BRICK(CKV, TNV)                                                                                      \
+  hipLaunchKernelGGL((conv3d_brick_kernel<CKV, TNV>), dim3(bricks, (unsigned)cdiv(Co, TNV * 32)), dim3(256), 0, s, in, \
+                     Wp, bias, out, mask, sh, nbz, nby, nbx, epilogue)
+    const int tn = Co <= 32 ? 1 : (Co <= 64 ? 2 : 4);
+    if (Ci % 32 == 0) {
+      if (tn == 1) LAUNCH_BRICK(32, 1); else if (tn == 2) LAUNCH_BRICK(32, 2); else LAUNCH_BRICK(32, 4);
+    } else {
+      if (tn == 1) LAUNCH_BRICK(16, 1); else if (tn == 2) LAUNCH_BRICK(16, 2); else LAUNCH_BRICK(16, 4);
+    }
+#undef LAUNCH_BRICK
   }
   return launch_status("conv3d_igemm");
 }
