@@ -178,6 +178,68 @@ __global__ __launch_bounds__(256) void conv3d_c1_fwd_kernel(const float *__restr
   }
 }
 
+// ---- Ci == 1 forward on the matrix core (production): out[voxel][co] = sum_tap in[voxel+tap] W[tap][co] is a
+// [voxels x 27] x [27 x CO] product.  One workgroup = one 8x8x8 brick whose scalar halo tile (10^3 floats)
+// sits in LDS; A[i = voxel][k = tap] is read from it, B[k = tap][j = co] lives in 14 registers per lane.
+// 14 MFMAs (32x32x2, exact f32) per 32 voxels replace 27*CO LDS-fed FMAs per voxel; the kernel is then bound
+// by its 64 B/voxel output stream.
+constexpr int C1B = 8, C1H = C1B + 2;
+template <int CO>
+__global__ __launch_bounds__(256) void conv3d_c1_mfma_kernel(const float *__restrict__ in, const float *__restrict__ Wp,
+                                                             const float *__restrict__ bias, float *__restrict__ out,
+                                                             ConvShape s, int nbz, int nby, int nbx, int mode) {
+  __shared__ float tile[C1H * C1H * C1H];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int l31 = lane & 31, lh = lane >> 5;
+  int64_t q = blockIdx.x;
+  const int bx = (int)(q % nbx); q /= nbx;
+  const int by = (int)(q % nby); q /= nby;
+  const int bz = (int)(q % nbz);
+  const int64_t b = q / nbz;
+  const int z0 = bz * C1B, y0 = by * C1B, x0 = bx * C1B;
+  const float *inb = in + b * (int64_t)s.D * s.H * s.W;
+  for (int idx = t; idx < C1H * C1H * C1H; idx += 256) {
+    const int hx = idx % C1H, hy = (idx / C1H) % C1H, hz = idx / (C1H * C1H);
+    const int gz = z0 + hz - 1, gy = y0 + hy - 1, gx = x0 + hx - 1;
+    tile[idx] = (gz >= 0 && gz < s.D && gy >= 0 && gy < s.H && gx >= 0 && gx < s.W)
+                    ? inb[((int64_t)gz * s.H + gy) * s.W + gx] : 0.f;
+  }
+  float bw[14];
+  int toff[14];
+#pragma unroll
+  for (int kp = 0; kp < 14; ++kp) {
+    const int tap = 2 * kp + lh;
+    bw[kp] = (tap < 27 && l31 < CO) ? Wp[tap * CO + l31] : 0.f;
+    const int tc = tap < 27 ? tap : 26;
+    toff[kp] = ((tc / 9 - 1) * C1H + ((tc / 3) % 3 - 1)) * C1H + (tc % 3 - 1);
+  }
+  const float bv = (mode != SVR_EPI_NONE && l31 < CO) ? bias[l31] : 0.f;
+  __syncthreads();
+#pragma unroll
+  for (int rt = 0; rt < 4; ++rt) {  // wave w: z-slices 2w, 2w+1, two 32-voxel row tiles each
+    const int vz = 2 * wave + (rt >> 1), yh = rt & 1;
+    const int hb = ((vz + 1) * C1H + (yh * 4 + l31 / C1B) + 1) * C1H + (l31 % C1B) + 1;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int kp = 0; kp < 14; ++kp) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(tile[hb + toff[kp]], bw[kp], acc, 0, 0, 0);
+    if (l31 < CO) {
+      const int gz = z0 + vz;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int i = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int gy = y0 + yh * 4 + i / C1B, gx = x0 + i % C1B;
+        if (gz < s.D && gy < s.H && gx < s.W) {
+          float v = acc[r] + bv;
+          if (mode == SVR_EPI_BIAS_RELU) v = fmaxf(v, 0.f);
+          out[((((int64_t)b * s.D + gz) * s.H + gy) * s.W + gx) * CO + l31] = v;
+        }
+      }
+    }
+  }
+}
+
 // ---- Co == 1 "forward" = backward-data of a Ci==1 conv: out[m] = sum_{tap,ci} in[m+tap][ci] Wp[tap][ci]
 template <int CI>
 __global__ __launch_bounds__(256) void conv3d_to1_kernel(const float *__restrict__ in, const float *__restrict__ Wp,
@@ -519,15 +581,20 @@ __global__ __launch_bounds__(256) void conv3d_c1_bwd_weight_kernel(const float *
   }
 }
 
-__global__ void conv3d_c1_bwd_weight_reduce_kernel(const float *__restrict__ slab, float *__restrict__ dWp, int Co,
-                                                   int parts) {
-  int idx = blockIdx.x * blockDim.x + threadIdx.x;  // [tap 32][co 32]
-  if (idx >= 1024) return;
-  int tap = idx >> 5, co = idx & 31;
-  if (tap >= 27 || co >= Co) return;
+// one workgroup per (tap, co): f64 tree over the per-wave partial slabs (fixed order)
+__global__ __launch_bounds__(256) void conv3d_c1_bwd_weight_reduce_kernel(const float *__restrict__ slab,
+                                                                          float *__restrict__ dWp, int Co, int parts) {
+  const int tap = blockIdx.x / Co, co = blockIdx.x % Co;
   double sum = 0.0;
-  for (int p = 0; p < parts; ++p) sum += (double)slab[(int64_t)p * 1024 + idx];
-  dWp[tap * Co + co] = (float)sum;
+  for (int p = threadIdx.x; p < parts; p += 256) sum += (double)slab[(int64_t)p * 1024 + tap * 32 + co];
+  __shared__ double red[256];
+  red[threadIdx.x] = sum;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) dWp[tap * Co + co] = (float)red[0];
 }
 
 // workgroups (= partial slabs) per channel-tile pair of the brick backward-weight kernel: ~2 per CU in total
@@ -573,9 +640,10 @@ extern "C" int svr_conv3d_k3(const float *in, const float *Wp, const float *bias
   const int64_t M = (int64_t)B * D * H * W;
   if (Ci == 1) {
     SVR_CHECK(epilogue != SVR_EPI_MASK, SVR_E_UNSUPPORTED, "conv3d: Ci=1 with mask epilogue");
-    unsigned grid = (unsigned)cdiv(M, 256);
-    if (Co == 16) hipLaunchKernelGGL(conv3d_c1_fwd_kernel<16>, dim3(grid), dim3(256), 0, s, in, Wp, bias, out, sh, epilogue);
-    else if (Co == 32) hipLaunchKernelGGL(conv3d_c1_fwd_kernel<32>, dim3(grid), dim3(256), 0, s, in, Wp, bias, out, sh, epilogue);
+    const int nbz = (int)cdiv(D, C1B), nby = (int)cdiv(H, C1B), nbx = (int)cdiv(W, C1B);
+    const unsigned grid = (unsigned)((int64_t)B * nbz * nby * nbx);
+    if (Co == 16) hipLaunchKernelGGL(conv3d_c1_mfma_kernel<16>, dim3(grid), dim3(256), 0, s, in, Wp, bias, out, sh, nbz, nby, nbx, epilogue);
+    else if (Co == 32) hipLaunchKernelGGL(conv3d_c1_mfma_kernel<32>, dim3(grid), dim3(256), 0, s, in, Wp, bias, out, sh, nbz, nby, nbx, epilogue);
     else SVR_CHECK(false, SVR_E_UNSUPPORTED, "conv3d: Ci=1 supports Co in {16,32}, got %d", Co);
     return launch_status("conv3d_c1_fwd");
   }
@@ -629,7 +697,7 @@ extern "C" int svr_conv3d_k3_bwd_weight(const float *in, const float *dout, floa
   if (Ci == 1) {
     SVR_CHECK(Co <= 32, SVR_E_UNSUPPORTED, "conv3d_bwd_weight: Ci=1 needs Co<=32 (got %d)", Co);
     hipLaunchKernelGGL(conv3d_c1_bwd_weight_kernel, dim3(chunks), dim3(256), 0, s, in, dout, slab, sh);
-    hipLaunchKernelGGL(conv3d_c1_bwd_weight_reduce_kernel, dim3(4), dim3(256), 0, s, slab, dWp, Co, chunks * 4);
+    hipLaunchKernelGGL(conv3d_c1_bwd_weight_reduce_kernel, dim3(27 * Co), dim3(256), 0, s, slab, dWp, Co, chunks * 4);
     slab_floats = (int64_t)chunks * 4 * 1024;
   } else {
     SVR_CHECK(Ci % 4 == 0 && Co % 4 == 0, SVR_E_UNSUPPORTED, "conv3d_bwd_weight: need Ci, Co %% 4 == 0 (Ci=%d Co=%d)", Ci, Co);
