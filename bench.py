@@ -79,10 +79,12 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     torch.cuda.set_device(local_rank)
+    launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ     # under torch.distributed.run
+    if launched:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     dev = torch.device("cuda", local_rank)
 
     trainer = ImplicitRefinementTrainer()
@@ -108,7 +110,7 @@ def main():
     ifnet_mod = importlib.import_module("single-view-3d-reconstruction_amd.model.ifnet")
 
     def sync():
-        if world > 1:
+        if launched:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -122,9 +124,9 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     ifnet_mod.ops.gather_fwd = orig_gather
-    loss = float(out["loss"])
+    loss = float(out["loss"].detach())
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
-    if world > 1:
+    if launched:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax)
     gather_ms = sum(e0.elapsed_time(e1) for e0, e1 in ev) / max(len(ev), 1)
@@ -150,7 +152,10 @@ def main():
             "config": {"workload": f"BASELINE configs[2] per GPU: {a.grid}^3 grid, {a.points} query points, batch "
                                    f"{a.batch}/GPU, full 3D conv encoder + 6-level trilinear gather + occupancy MLP, "
                                    "fwd+bwd+grad all-reduce+Adam",
-                       "global_batch": world * a.batch, "parallelism": f"dp{world}", "loss": loss},
+                       "global_batch": world * a.batch, "parallelism": f"dp{world}", "loss": loss,
+                       "arithmetic": "f32 storage everywhere; encoder convs + BN exact f32 (f32 MFMA); point-MLP forward "
+                                     "bf16x6 split on the bf16 MFMA (f32-equivalent, 2e-7), point-MLP backward GEMMs bf16x3 "
+                                     "split (1.5e-5 per product); gather/scatter f32"},
             "roofline": {"kernel": "gather_fwd_fused_kernel (svr_gather_trilinear_fwd, all 6 levels in one launch)", "bound": "hbm", "achieved": achieved,
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                          "ms_per_launch": gather_ms, "algorithmic_bytes_per_launch": alg_bytes, "traffic": traffic},
@@ -158,7 +163,7 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(a.grid, a.points)
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if launched:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -1,14 +1,16 @@
-// 3x3x3 / padding-1 convolution on channels-last volumes for gfx950, exact-f32 MFMA.
+// 3x3x3 / padding-1 convolution on channels-last volumes for gfx950, exact-f32 MFMA (v_mfma_f32_32x32x2_f32).
 //
 // Replaces nn.Conv3d(ci, co, 3, padding=1) (+ fused bias / ReLU) of the IF-Net encoder
-// (reference model/ifnet.py:126-135 and :164-191; 32-variant :69-74,100-113) and its autograd:
-//   forward / backward-data : implicit GEMM  out[m][co] = sum_{tap,ci} in[m+tap][ci] Wp[tap][ci][co]
-//                             (M = B*D*H*W voxels, K = 27*Ci), LDS-tiled, shared core gemm_core.h;
-//   backward-weight         : dWp[tap][ci][co] = sum_m in[m+tap][ci] dout[m][co]; the reduction
-//                             dimension (voxels) is the MFMA k, operands go straight from global
-//                             memory to the matrix core (a half wave reads 32 consecutive channels
-//                             of one voxel = one 128-B line), per-wave partial slabs + ordered sum;
-//   Ci == 1 (conv_in)       : direct stencil kernels (bandwidth bound, not GEMM shaped).
+// (reference model/ifnet.py:126-135 and :164-191; 32-variant :69-74,100-113) and its autograd.
+// Everything works on 4x4x8-voxel output BRICKS whose input halo tile (6x6x10 voxels) is staged in LDS once
+// and then serves all 27 taps (a tap = a constant offset in the tile); the plain implicit GEMM re-read every
+// input voxel 27 times from L2 and was bound by that (profiles/r01_step_v1 vs v4):
+//   conv3d_brick_kernel            forward and backward-data (flipped, transposed weights): A = voxels x ci from
+//                                  the LDS halo tile, B = the tap's [ci][co] weight slice, double buffered in LDS;
+//   conv3d_bwd_weight_brick_kernel dWp[tap][ci][co] = sum_voxels in[voxel+tap][ci] dout[voxel][co]: voxels are the
+//                                  MFMA k, 27 accumulator tiles stay in registers across a persistent brick loop;
+//   conv3d_c1_* / conv3d_to1       Ci == 1 (conv_in): forward as a [voxels x 27] x [27 x Co] MFMA product from a
+//                                  scalar halo tile, weight gradient as a 27 x Co outer product, data gradient direct.
 #include "common.h"
 #include "gemm_core.h"
 
@@ -42,141 +44,6 @@ __global__ void unpack_wgrad_kernel(const float *__restrict__ dWp, float *__rest
 struct ConvShape {
   int B, D, H, W, Ci, Co;
 };
-
-// A operand of the implicit GEMM: row = output voxel, 16 consecutive k = 16 channels of one tap.
-template <int ROWS>
-struct ConvALoader {
-  static constexpr int R = ROWS / 64;
-  static constexpr int LD = ROWS + 2;
-  const float *in;
-  int D, H, W, Ci;
-  int vz[R], vy[R], vx[R];
-  int64_t vbase[R];  // voxel index of (b,0,0,0), or -1 for rows past M
-  float4 v[R];
-  __device__ __forceinline__ void init(const float *in_, const ConvShape &s, int64_t m0, int64_t M) {
-    in = in_;
-    D = s.D; H = s.H; W = s.W; Ci = s.Ci;
-    const int t = threadIdx.x;
-#pragma unroll
-    for (int i = 0; i < R; ++i) {
-      int64_t m = m0 + (t >> 2) + 64 * i;
-      if (m < M) {
-        int x = (int)(m % W);
-        int64_t r = m / W;
-        int y = (int)(r % H);
-        r /= H;
-        int z = (int)(r % D);
-        int64_t b = r / D;
-        vx[i] = x; vy[i] = y; vz[i] = z;
-        vbase[i] = b * D * H * W;
-      } else {
-        vx[i] = vy[i] = vz[i] = 0;
-        vbase[i] = -1;
-      }
-    }
-  }
-  __device__ __forceinline__ void load(int kt) {
-    const int t = threadIdx.x;
-    const int k0 = kt * BK;
-    const int tap = k0 / Ci, ci0 = k0 - tap * Ci;
-    const int dz = tap / 9 - 1, dy = (tap / 3) % 3 - 1, dx = tap % 3 - 1;
-#pragma unroll
-    for (int i = 0; i < R; ++i) {
-      int z = vz[i] + dz, y = vy[i] + dy, x = vx[i] + dx;
-      bool ok = vbase[i] >= 0 && z >= 0 && z < D && y >= 0 && y < H && x >= 0 && x < W;
-      if (ok) {
-        const float *p = in + (vbase[i] + ((int64_t)z * H + y) * W + x) * Ci + ci0 + (t & 3) * 4;
-        v[i] = *reinterpret_cast<const float4 *>(p);
-      } else {
-        v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-      }
-    }
-  }
-  __device__ __forceinline__ void store(float *tile) const {
-    const int t = threadIdx.x;
-#pragma unroll
-    for (int i = 0; i < R; ++i) {
-      float *d = tile + ((t & 3) * 4) * LD + (t >> 2) + 64 * i;
-      d[0] = v[i].x;
-      d[LD] = v[i].y;
-      d[2 * LD] = v[i].z;
-      d[3 * LD] = v[i].w;
-    }
-  }
-};
-
-template <class Cfg>
-__global__ __launch_bounds__(256) void conv3d_igemm_kernel(const float *__restrict__ in, const float *__restrict__ Wp,
-                                                           const float *__restrict__ bias, float *__restrict__ out,
-                                                           const float *__restrict__ mask, ConvShape s, int mode) {
-  const int64_t M = (int64_t)s.B * s.D * s.H * s.W;
-  const int64_t m0 = (int64_t)blockIdx.x * Cfg::BM;
-  const int n0 = blockIdx.y * Cfg::BN;
-  const int Co = s.Co;
-  auto bfn = [=](int k, int col4, int kt) -> const float * {
-    int c = n0 + col4;
-    return c < Co ? Wp + ((int64_t)kt * BK + k) * Co + c : nullptr;
-  };
-  typedef ConvALoader<Cfg::BM> AL;
-  typedef KRowLoader<Cfg::BN, decltype(bfn)> BL;
-  __shared__ GemmSmem<Cfg, AL, BL> sm;
-  AL al;
-  al.init(in, s, m0, M);
-  BL bl{bfn};
-  f32x16 acc[Cfg::TM][Cfg::TN];
-  gemm_mainloop<Cfg>(al, bl, sm, 0, 27 * s.Ci / BK, acc);
-  gemm_foreach<Cfg>(acc, [&](int row, int col, float v) {
-    int64_t m = m0 + row;
-    int n = n0 + col;
-    if (m < M && n < Co) {
-      if (mode == SVR_EPI_BIAS || mode == SVR_EPI_BIAS_RELU) v += bias[n];
-      if (mode == SVR_EPI_BIAS_RELU) v = fmaxf(v, 0.f);
-      if (mode == SVR_EPI_MASK) v = (mask[m * Co + n] > 0.f) ? v : 0.f;
-      out[m * Co + n] = v;
-    }
-  });
-}
-
-// ---- Ci == 1 forward: one thread per output voxel, CO outputs each (conv_in 1->16, 32-variant 1->32)
-template <int CO>
-__global__ __launch_bounds__(256) void conv3d_c1_fwd_kernel(const float *__restrict__ in, const float *__restrict__ Wp,
-                                                            const float *__restrict__ bias, float *__restrict__ out,
-                                                            ConvShape s, int mode) {
-  __shared__ float w[27 * CO + CO];
-  for (int i = threadIdx.x; i < 27 * CO; i += blockDim.x) w[i] = Wp[i];
-  for (int i = threadIdx.x; i < CO; i += blockDim.x) w[27 * CO + i] = (mode == SVR_EPI_NONE) ? 0.f : bias[i];
-  __syncthreads();
-  const int64_t M = (int64_t)s.B * s.D * s.H * s.W;
-  int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (m >= M) return;
-  int x = (int)(m % s.W);
-  int64_t r = m / s.W;
-  int y = (int)(r % s.H);
-  r /= s.H;
-  int z = (int)(r % s.D);
-  int64_t b = r / s.D;
-  const float *ib = in + b * s.D * s.H * s.W;
-  float acc[CO];
-#pragma unroll
-  for (int c = 0; c < CO; ++c) acc[c] = w[27 * CO + c];
-#pragma unroll
-  for (int tap = 0; tap < 27; ++tap) {
-    int zz = z + tap / 9 - 1, yy = y + (tap / 3) % 3 - 1, xx = x + tap % 3 - 1;
-    float v = 0.f;
-    if (zz >= 0 && zz < s.D && yy >= 0 && yy < s.H && xx >= 0 && xx < s.W) v = ib[((int64_t)zz * s.H + yy) * s.W + xx];
-#pragma unroll
-    for (int c = 0; c < CO; ++c) acc[c] += v * w[tap * CO + c];
-  }
-  float *o = out + m * CO;
-#pragma unroll
-  for (int c = 0; c < CO; c += 4) {
-    float4 t = make_float4(acc[c], acc[c + 1], acc[c + 2], acc[c + 3]);
-    if (mode == SVR_EPI_BIAS_RELU) {
-      t.x = fmaxf(t.x, 0.f); t.y = fmaxf(t.y, 0.f); t.z = fmaxf(t.z, 0.f); t.w = fmaxf(t.w, 0.f);
-    }
-    *reinterpret_cast<float4 *>(o + c) = t;
-  }
-}
 
 // ---- Ci == 1 forward on the matrix core (production): out[voxel][co] = sum_tap in[voxel+tap] W[tap][co] is a
 // [voxels x 27] x [27 x CO] product.  One workgroup = one 8x8x8 brick whose scalar halo tile (10^3 floats)
@@ -272,56 +139,7 @@ __global__ __launch_bounds__(256) void conv3d_to1_kernel(const float *__restrict
   out[m] = acc;
 }
 
-// ---- backward-weight: one tap and one (32 ci x 32 co) tile per workgroup, waves split the x-rows.
-//      slab[(chunk*4 + wave)][tap][ci][co] partials.
-constexpr int BW_ROWS = 256;  // (b,z,y) rows per workgroup
-
-__global__ __launch_bounds__(256) void conv3d_bwd_weight_kernel(const float *__restrict__ in,
-                                                                const float *__restrict__ dout,
-                                                                float *__restrict__ slab, ConvShape s, int ci_tiles,
-                                                                int co_tiles) {
-  const int tap = blockIdx.x;
-  const int tile = blockIdx.y;
-  const int ci0 = (tile / co_tiles) * 32, co0 = (tile % co_tiles) * 32;
-  const int chunk = blockIdx.z;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int l31 = lane & 31, lh = lane >> 5;
-  const int dz = tap / 9 - 1, dy = (tap / 3) % 3 - 1, dx = tap % 3 - 1;
-  const int64_t nrows = (int64_t)s.B * s.D * s.H;
-  const int64_t r0 = (int64_t)chunk * BW_ROWS;
-  const bool ci_ok = ci0 + l31 < s.Ci, co_ok = co0 + l31 < s.Co;
-  f32x16 acc;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  for (int64_t row = r0 + wave; row < r0 + BW_ROWS && row < nrows; row += 4) {
-    int y = (int)(row % s.H);
-    int64_t t = row / s.H;
-    int z = (int)(t % s.D);
-    int64_t b = t / s.D;
-    int zz = z + dz, yy = y + dy;
-    if (zz < 0 || zz >= s.D || yy < 0 || yy >= s.H) continue;
-    const float *arow = in + ((b * s.D + zz) * s.H + yy) * (int64_t)s.W * s.Ci + ci0 + l31;
-    const float *brow = dout + row * (int64_t)s.W * s.Co + co0 + l31;
-    for (int x0 = 0; x0 < s.W; x0 += 8) {
-      float av[4], bv[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        int x = x0 + 2 * u + lh, xs = x + dx;
-        av[u] = (ci_ok && x < s.W && xs >= 0 && xs < s.W) ? arow[(int64_t)xs * s.Ci] : 0.f;
-        bv[u] = (co_ok && x < s.W) ? brow[(int64_t)x * s.Co] : 0.f;
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u], acc, 0, 0, 0);
-    }
-  }
-  // slab layout: [chunk*4+wave][tap][tile][32][32]
-  float *o = slab + ((((int64_t)chunk * 4 + wave) * 27 + tap) * (ci_tiles * co_tiles) + tile) * 1024;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    int i = (r & 3) + 8 * (r >> 2) + 4 * lh;
-    o[i * 32 + l31] = acc[r];
-  }
-}
+constexpr int BW_ROWS = 256;  // (b,z,y) rows per workgroup of the Ci == 1 weight-gradient kernel
 
 // ---- backward-weight, brick version (production): a workgroup walks 4x4x8-voxel bricks of the output.
 // Per brick it stages the 32-channel slice of the input WITH its one-voxel halo (6x6x10 voxels) and the
@@ -671,7 +489,7 @@ extern "C" int svr_conv3d_k3(const float *in, const float *Wp, const float *bias
     }
 #undef LAUNCH_BRICK
   }
-  return launch_status("conv3d_igemm");
+  return launch_status("conv3d_brick");
 }
 
 extern "C" int64_t svr_conv3d_k3_bwd_weight_workspace(int32_t B, int32_t D, int32_t H, int32_t W, int32_t Ci, int32_t Co) {

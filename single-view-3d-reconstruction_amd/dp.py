@@ -34,8 +34,8 @@ class GradBucket:
         batch mean for equal shards, trainer/trainer_ifnet.py:46)."""
         if dist.is_available() and dist.is_initialized():
             world = dist.get_world_size(group)
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)     # RCCL over xGMI ("nccl" backend)
             if world > 1:
-                dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
                 self.flat.div_(world)
         return self.flat
 
