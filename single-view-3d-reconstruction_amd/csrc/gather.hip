@@ -453,6 +453,7 @@ LevelArgs level_args(const svr_level &L) { return LevelArgs{L.vol, L.gvol, L.C, 
 extern "C" int svr_gather_trilinear_fwd(const svr_gather_desc *d, const float *points, float *features,
                                         void *stream) {
   if (int rc = check_desc(d, false)) return rc;
+  if ((int64_t)d->B * d->N == 0) return SVR_OK;  // empty point set
   SVR_CHECK(points && features, SVR_E_BADARG, "gather_fwd: null points/features");
   SVR_CHECK(((uintptr_t)features & 15) == 0, SVR_E_ALIGN, "gather_fwd: features not 16-byte aligned");
   hipStream_t s = (hipStream_t)stream;
@@ -486,6 +487,7 @@ extern "C" int svr_gather_trilinear_fwd(const svr_gather_desc *d, const float *p
 extern "C" int svr_gather_trilinear_bwd(const svr_gather_desc *d, const float *points, const float *gfeatures,
                                         float *gpoints, void *stream) {
   if (int rc = check_desc(d, true)) return rc;
+  if ((int64_t)d->B * d->N == 0) return SVR_OK;  // empty point set: nothing to scatter
   SVR_CHECK(points && gfeatures, SVR_E_BADARG, "gather_bwd: null points/gfeatures");
   hipStream_t s = (hipStream_t)stream;
   int64_t BN = (int64_t)d->B * d->N;

@@ -317,6 +317,7 @@ void colsum_launch(const float *Y, int64_t ldy, float *out, float *part, int64_t
 extern "C" int svr_linear_fwd(const float *X, int64_t ldx, const float *W, int64_t ldw, const float *bias, float *Y,
                               int64_t ldy, int64_t M, int64_t N, int64_t K, int epilogue, const float *mask,
                               int64_t ldmask, void *stream) {
+  if (M == 0) return SVR_OK;  // empty point set
   SVR_CHECK(X && W && Y, SVR_E_BADARG, "linear_fwd: null pointer");
   SVR_CHECK(M >= 0 && N > 0 && K > 0 && K % BK == 0, SVR_E_BADSHAPE, "linear_fwd: M=%ld N=%ld K=%ld (K %% 16)", (long)M, (long)N, (long)K);
   SVR_CHECK(ldx % 4 == 0 && ldw % 4 == 0 && (((uintptr_t)X | (uintptr_t)W) & 15) == 0, SVR_E_ALIGN, "linear_fwd: operands must be 16-byte aligned");
@@ -331,6 +332,7 @@ extern "C" int svr_linear_fwd(const float *X, int64_t ldx, const float *W, int64
 extern "C" int svr_linear_bwd_data(const float *dY, int64_t lddy, const float *W, int64_t ldw, float *dX, int64_t lddx,
                                    int64_t M, int64_t N, int64_t K, int epilogue, const float *mask, int64_t ldmask,
                                    void *stream) {
+  if (M == 0) return SVR_OK;
   SVR_CHECK(dY && W && dX, SVR_E_BADARG, "linear_bwd_data: null pointer");
   SVR_CHECK(M >= 0 && N > 0 && K > 0 && N % BK == 0 && K % 4 == 0, SVR_E_BADSHAPE, "linear_bwd_data: M=%ld N=%ld K=%ld", (long)M, (long)N, (long)K);
   SVR_CHECK(lddy % 4 == 0 && ldw % 4 == 0 && (((uintptr_t)dY | (uintptr_t)W) & 15) == 0, SVR_E_ALIGN, "linear_bwd_data: operands must be 16-byte aligned");
@@ -367,6 +369,7 @@ extern "C" int svr_linear_bwd_weight(const float *dY, int64_t lddy, const float 
 
 extern "C" int svr_fc_out_fwd(const float *H, int64_t ldh, const float *w, const float *b, float *logits,
                               const int32_t *row_map, int64_t M, int64_t K, void *stream) {
+  if (M <= 0) return SVR_OK;
   SVR_CHECK(H && w && b && logits, SVR_E_BADARG, "fc_out_fwd: null pointer");
   SVR_CHECK(K > 0 && K % 4 == 0 && ldh % 4 == 0, SVR_E_BADSHAPE, "fc_out_fwd: K=%ld ldh=%ld", (long)K, (long)ldh);
   if (M <= 0) return SVR_OK;

@@ -368,6 +368,7 @@ extern "C" int64_t svr_linear_bwd_data_bf16x3_workspace(int64_t N, int64_t K) { 
 extern "C" int svr_linear_bwd_data_bf16x3(const float *dY, int64_t lddy, const float *W, int64_t ldw, float *dX, int64_t lddx,
                                           int64_t M, int64_t N, int64_t K, int epilogue, const float *mask, int64_t ldmask,
                                           void *workspace, void *stream) {
+  if (M == 0) return SVR_OK;
   SVR_CHECK(dY && W && dX && workspace, SVR_E_BADARG, "linear_bwd_data_bf16x3: null pointer");
   SVR_CHECK(M >= 0 && N > 0 && K > 0 && N % XK == 0 && K % 4 == 0 && lddx % 4 == 0 && ldmask % 4 == 0, SVR_E_BADSHAPE,
             "linear_bwd_data_bf16x3: M=%ld N=%ld K=%ld (need N %% 32 == 0, K and leading dims %% 4 == 0)", (long)M, (long)N, (long)K);

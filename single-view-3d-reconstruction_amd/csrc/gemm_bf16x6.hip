@@ -185,6 +185,7 @@ extern "C" int64_t svr_linear_fwd_bf16x6_workspace(int64_t N, int64_t K) { retur
 extern "C" int svr_linear_fwd_bf16x6(const float *X, int64_t ldx, const float *W, int64_t ldw, const float *bias, float *Y,
                                      int64_t ldy, int64_t M, int64_t N, int64_t K, int epilogue, void *workspace,
                                      void *stream) {
+  if (M == 0) return SVR_OK;  // empty point set
   SVR_CHECK(X && W && Y && workspace, SVR_E_BADARG, "linear_fwd_bf16x6: null pointer");
   SVR_CHECK(M >= 0 && N > 0 && K > 0 && K % YK == 0, SVR_E_BADSHAPE, "linear_fwd_bf16x6: M=%ld N=%ld K=%ld (K %% 16)", (long)M, (long)N, (long)K);
   SVR_CHECK(ldx % 4 == 0 && ((uintptr_t)X & 15) == 0, SVR_E_ALIGN, "linear_fwd_bf16x6: X must be 16-byte aligned");

@@ -299,6 +299,10 @@ def bn_forward(x, gamma, beta, running_mean, running_var, training, eps=1e-5, mo
     _f32(x, gamma, beta, running_mean, running_var)
     B, D, H, W, Cc = x.shape
     rows = B * D * H * W
+    if training and rows <= 1:
+        # same error as torch.nn.functional.batch_norm (the reference raises here too)
+        raise ValueError(f"Expected more than 1 value per channel when training, got input size "
+                         f"torch.Size([{B}, {Cc}, {D}, {H}, {W}])")
     l = _lib.lib()
     dev = x.device
     stats = None
