@@ -249,10 +249,11 @@ __global__ __launch_bounds__(256) void conv3d_brick_kernel(const float *__restri
                                                            int nbx, int mode) {
   constexpr int CP = CK + 1;
   constexpr int NC = TNB * 32;                 // output columns of this workgroup
-  constexpr int WQ = CK * NC / 4;              // float4 per weight slice (one tap, CK input channels)
+  constexpr int TG = TNB == 1 ? 3 : 1;         // taps per barrier (narrow tiles: 16 MFMAs per tap are too few)
+  constexpr int WQ = TG * CK * NC / 4;         // float4 per weight group (TG taps, CK input channels)
   constexpr int WR_ = (WQ + 255) / 256;        // float4 per thread
   __shared__ float sin[HLV * CP];
-  __shared__ float sw[2][CK * NC];             // weight slice of the current / next tap: [ci][co]
+  __shared__ float sw[2][TG * CK * NC];        // weight slices of the current / next tap group: [tap][ci][co]
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int l31 = lane & 31, lh = lane >> 5;
   int64_t q = blockIdx.x;
@@ -273,13 +274,14 @@ __global__ __launch_bounds__(256) void conv3d_brick_kernel(const float *__restri
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
   float4 wreg[WR_];
-  auto wload = [&](int ci0, int tap) {
+  auto wload = [&](int ci0, int tap0) {   // taps tap0 .. tap0+TG-1
 #pragma unroll
     for (int i = 0; i < WR_; ++i) {
       const int idx = t + 256 * i;
-      const int k = idx / (NC / 4), c4 = (idx % (NC / 4)) * 4;
+      const int tg = idx / (CK * NC / 4), rem = idx % (CK * NC / 4);
+      const int k = rem / (NC / 4), c4 = (rem % (NC / 4)) * 4;
       wreg[i] = (idx < WQ && co0 + c4 < s.Co)
-                    ? *reinterpret_cast<const float4 *>(Wp + ((int64_t)tap * s.Ci + ci0 + k) * s.Co + co0 + c4)
+                    ? *reinterpret_cast<const float4 *>(Wp + ((int64_t)(tap0 + tg) * s.Ci + ci0 + k) * s.Co + co0 + c4)
                     : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   };
@@ -306,18 +308,23 @@ __global__ __launch_bounds__(256) void conv3d_brick_kernel(const float *__restri
     }
     wstore(sw[0]);
     __syncthreads();
-    for (int tap = 0; tap < 27; ++tap) {
-      if (tap + 1 < 27) wload(ci0, tap + 1);
-      const int toff = (((tap / 9 - 1) * HLY + ((tap / 3) % 3 - 1)) * HLX + (tap % 3 - 1)) * CP;
-      const float *wb = sw[tap & 1] + lh * NC + l31;
+    for (int tap0 = 0; tap0 < 27; tap0 += TG) {
+      if (tap0 + TG < 27) wload(ci0, tap0 + TG);
+      const float *wg = sw[(tap0 / TG) & 1] + lh * NC + l31;
 #pragma unroll
-      for (int kp = 0; kp < CK / 2; ++kp) {
-        const float av = sin[hbase + toff + 2 * kp + lh];
+      for (int tg = 0; tg < TG; ++tg) {
+        const int tap = tap0 + tg;
+        const int toff = (((tap / 9 - 1) * HLY + ((tap / 3) % 3 - 1)) * HLX + (tap % 3 - 1)) * CP;
+        const float *wb = wg + tg * CK * NC;
 #pragma unroll
-        for (int j = 0; j < TNB; ++j)
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, wb[2 * kp * NC + j * 32], acc[j], 0, 0, 0);
+        for (int kp = 0; kp < CK / 2; ++kp) {
+          const float av = sin[hbase + toff + 2 * kp + lh];
+#pragma unroll
+          for (int j = 0; j < TNB; ++j)
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, wb[2 * kp * NC + j * 32], acc[j], 0, 0, 0);
+        }
       }
-      if (tap + 1 < 27) wstore(sw[(tap + 1) & 1]);
+      if (tap0 + TG < 27) wstore(sw[((tap0 / TG) + 1) & 1]);
       __syncthreads();
     }
   }
@@ -341,18 +348,26 @@ __global__ __launch_bounds__(256) void conv3d_brick_kernel(const float *__restri
   }
 }
 
-__global__ void conv3d_bwd_weight_reduce_kernel(const float *__restrict__ slab, float *__restrict__ dWp, int Ci, int Co,
-                                                int ci_tiles, int co_tiles, int parts) {
-  int idx = blockIdx.x * blockDim.x + threadIdx.x;  // over [tap][tile][32][32]
-  int per = 27 * ci_tiles * co_tiles * 1024;
-  if (idx >= per) return;
-  int j = idx & 31, i = (idx >> 5) & 31;
-  int tile = (idx >> 10) % (ci_tiles * co_tiles), tap = idx / (1024 * ci_tiles * co_tiles);
-  int ci = (tile / co_tiles) * 32 + i, co = (tile % co_tiles) * 32 + j;
-  if (ci >= Ci || co >= Co) return;
+// dWp = ordered f64 sum of the workgroup slabs: 64 outputs x 4 part lanes per workgroup
+__global__ __launch_bounds__(256) void conv3d_bwd_weight_reduce_kernel(const float *__restrict__ slab,
+                                                                       float *__restrict__ dWp, int Ci, int Co,
+                                                                       int ci_tiles, int co_tiles, int parts) {
+  const int per = 27 * ci_tiles * co_tiles * 1024;  // [tap][tile][32][32]
+  const int idx = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int pl = threadIdx.x >> 6;
   double sum = 0.0;
-  for (int p = 0; p < parts; ++p) sum += (double)slab[(int64_t)p * per + idx];
-  dWp[((size_t)tap * Ci + ci) * Co + co] = (float)sum;
+  if (idx < per)
+    for (int p = pl; p < parts; p += 4) sum += (double)slab[(int64_t)p * per + idx];
+  __shared__ double red[256];
+  red[threadIdx.x] = sum;
+  __syncthreads();
+  if (pl == 0 && idx < per) {
+    const double tot = red[threadIdx.x] + red[threadIdx.x + 64] + red[threadIdx.x + 128] + red[threadIdx.x + 192];
+    const int j = idx & 31, i = (idx >> 5) & 31;
+    const int tile = (idx >> 10) % (ci_tiles * co_tiles), tap = idx / (1024 * ci_tiles * co_tiles);
+    const int ci = (tile / co_tiles) * 32 + i, co = (tile % co_tiles) * 32 + j;
+    if (ci < Ci && co < Co) dWp[((size_t)tap * Ci + ci) * Co + co] = (float)tot;
+  }
 }
 
 // ---- Ci == 1 backward-weight: A[i = tap][k = voxel] = in[voxel + tap], B[k = voxel][j = co] = dout
@@ -525,7 +540,7 @@ extern "C" int svr_conv3d_k3_bwd_weight(const float *in, const float *dout, floa
     dim3 grid((unsigned)parts, (unsigned)(cit * cot));
     hipLaunchKernelGGL(conv3d_bwd_weight_brick_kernel, grid, dim3(256), 0, s, in, dout, slab, sh, nbz, nby, nbx, cot);
     int per = 27 * cit * cot * 1024;
-    hipLaunchKernelGGL(conv3d_bwd_weight_reduce_kernel, dim3(cdiv(per, 256)), dim3(256), 0, s, slab, dWp, Ci, Co, cit, cot, parts);
+    hipLaunchKernelGGL(conv3d_bwd_weight_reduce_kernel, dim3(cdiv(per, 64)), dim3(256), 0, s, slab, dWp, Ci, Co, cit, cot, parts);
     slab_floats = (int64_t)parts * per;
   }
   if (db) colsum_launch(dout, Co, db, slab + slab_floats, nrows * W, Co, s);

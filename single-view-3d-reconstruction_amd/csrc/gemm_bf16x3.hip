@@ -179,7 +179,7 @@ template <int WR, int WC>
 struct Geo {
   static constexpr int NT = WR * WC * 64, TM = WR * 64, TN = WC * 64;
   static constexpr int STAGE = 2 * (TM + TN) * XLW;  // dwords
-  static constexpr int LDS_DWORDS = 2 * STAGE;
+  static constexpr int LDS_DWORDS = STAGE;           // ONE stage: see mainloop
 };
 
 template <int WR, int WC>
@@ -216,9 +216,11 @@ __device__ __forceinline__ void compute_step(const uint32_t *pa, f32x16 (&acc)[2
   }
 }
 
-// Pipeline: the global loads of step s+1 are issued before the MFMAs of step s and converted / written to the
-// other LDS stage after them; one barrier per k-step.  (Two register sets -- loads two steps ahead -- were
-// tried: 200..256 VGPRs, spills, 1.5-4x slower.)
+// Pipeline: the global loads of step s+1 are issued before the MFMAs of step s and converted / written to LDS
+// after them.  ONE LDS stage and two barriers per k-step: SQ counters showed these kernels parked on memory
+// (SQ_WAIT_ANY 0.55-0.67 of the wave cycles, matrix pipe ~20 % busy), and halving the LDS footprint doubles the
+// workgroups per CU, i.e. the loads in flight; the extra barrier is covered by the other workgroups.
+// (Two register sets -- loads two steps ahead -- were tried: 200..256 VGPRs, spills, 1.5-4x slower.)
 template <int WR, int WC, class AL, class BL>
 __device__ __forceinline__ void mainloop(AL &al, BL &bl, uint32_t *lds, int64_t kbeg, int64_t kend, f32x16 (&acc)[2][2]) {
   using G = Geo<WR, WC>;
@@ -234,21 +236,19 @@ __device__ __forceinline__ void mainloop(AL &al, BL &bl, uint32_t *lds, int64_t 
   al.store(lds);
   bl.store(lds + 2 * G::TM * XLW);
   __syncthreads();
-  int st = 0;
   for (int64_t k0 = kbeg; k0 < kend; k0 += XK) {
     const bool more = k0 + XK < kend;
     if (more) {
       al.load(k0 + XK, kend);
       bl.load(k0 + XK, kend);
     }
-    compute_step<WR, WC>(lds + st * G::STAGE, acc);
+    compute_step<WR, WC>(lds, acc);
+    __syncthreads();  // every wave has read its fragments
     if (more) {
-      uint32_t *na = lds + (st ^ 1) * G::STAGE;
-      al.store(na);
-      bl.store(na + 2 * G::TM * XLW);
+      al.store(lds);
+      bl.store(lds + 2 * G::TM * XLW);
     }
     __syncthreads();
-    st ^= 1;
   }
 }
 
@@ -289,54 +289,60 @@ __global__ __launch_bounds__(256) void linear_nn_x3_kernel(const float *__restri
                                                            int64_t lddx, const float *__restrict__ mask, int64_t ldmask,
                                                            int64_t M, int64_t N, int64_t K) {
   using G = Geo<2, 2>;
-  static_assert(G::LDS_DWORDS >= NN_TM * NN_CLD, "epilogue tile must fit the staging buffers");
+  static_assert(G::LDS_DWORDS >= (NN_TM / 2) * NN_CLD, "half the epilogue tile must fit the staging buffer");
   __shared__ uint32_t lds[G::LDS_DWORDS];
   const int64_t c0 = (int64_t)blockIdx.x * NN_TN, m0 = (int64_t)blockIdx.y * NN_TM;
   RowKLoader<NN_TM, 256> al(dY, lddy, m0, M);
   PlaneLoader<NN_TN, 256> bl(Wh, Wm, N, c0, K);
   f32x16 acc[2][2];
-  mainloop<2, 2>(al, bl, lds, 0, N, acc);
-  __syncthreads();  // every wave is done reading operand fragments before the tile overwrites the buffers
+  mainloop<2, 2>(al, bl, lds, 0, N, acc);   // ends with a barrier: the operand buffers are free
   float *ct = reinterpret_cast<float *>(lds);
-  foreach_acc<2, 2>(acc, [&](int row, int col, float v) { ct[row * NN_CLD + col] = v; });
-  __syncthreads();
   const int t = threadIdx.x;
+  const int wave = t >> 6;
 #pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    const int row = (t >> 5) + 8 * i, c4 = (t & 31) * 4;
-    const int64_t m = m0 + row, c = c0 + c4;
-    if (m < M && c < K) {  // K % 4 == 0 (host-checked), so a float4 never straddles the edge
-      float4 v = *reinterpret_cast<const float4 *>(ct + row * NN_CLD + c4);
-      if (mask) {
-        const float4 k4 = *reinterpret_cast<const float4 *>(mask + m * ldmask + c);
-        v.x = k4.x > 0.f ? v.x : 0.f;
-        v.y = k4.y > 0.f ? v.y : 0.f;
-        v.z = k4.z > 0.f ? v.z : 0.f;
-        v.w = k4.w > 0.f ? v.w : 0.f;
+  for (int pass = 0; pass < 2; ++pass) {  // 64 rows per pass (the waves with wr == pass own them)
+    if ((wave >> 1) == pass)
+      foreach_acc<2, 2>(acc, [&](int row, int col, float v) { ct[(row - 64 * pass) * NN_CLD + col] = v; });
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int row = (t >> 5) + 8 * i, c4 = (t & 31) * 4;
+      const int64_t m = m0 + 64 * pass + row, c = c0 + c4;
+      if (m < M && c < K) {  // K % 4 == 0 (host-checked), so a float4 never straddles the edge
+        float4 v = *reinterpret_cast<const float4 *>(ct + row * NN_CLD + c4);
+        if (mask) {
+          const float4 k4 = *reinterpret_cast<const float4 *>(mask + m * ldmask + c);
+          v.x = k4.x > 0.f ? v.x : 0.f;
+          v.y = k4.y > 0.f ? v.y : 0.f;
+          v.z = k4.z > 0.f ? v.z : 0.f;
+          v.w = k4.w > 0.f ? v.w : 0.f;
+        }
+        *reinterpret_cast<float4 *>(dX + m * lddx + c) = v;
       }
-      *reinterpret_cast<float4 *>(dX + m * lddx + c) = v;
     }
+    __syncthreads();
   }
 }
 
-// slab[z][N,K] = dY[rows of split z]^T X[rows of split z].  256 x 128 tile (8 waves): with N = 256 every row of
-// X is read from HBM once per split instead of once per 128-row tile.
-constexpr int TN_TM = 256, TN_TN = 128;
-__global__ __launch_bounds__(512) void linear_tn_x3_kernel(const float *__restrict__ dY, int64_t lddy,
+// slab[z][N,K] = dY[rows of split z]^T X[rows of split z].  128 x 128 tile, 4 waves, 36 KB of LDS: three
+// workgroups per CU keep enough loads in flight (the 256 x 128 / 8-wave variant read X only once but ran one
+// workgroup per CU and was parked on memory 55 % of the time).
+constexpr int TN_TM = 128, TN_TN = 128;
+__global__ __launch_bounds__(256) void linear_tn_x3_kernel(const float *__restrict__ dY, int64_t lddy,
                                                            const float *__restrict__ X, int64_t ldx,
                                                            float *__restrict__ slab, int64_t M, int64_t N, int64_t K,
                                                            int64_t rows_per_split) {
-  using G = Geo<4, 2>;
+  using G = Geo<2, 2>;
   __shared__ uint32_t lds[G::LDS_DWORDS];
   const int64_t j0 = (int64_t)blockIdx.x * TN_TN, i0 = (int64_t)blockIdx.y * TN_TM;
   const int64_t kbeg = (int64_t)blockIdx.z * rows_per_split;
   const int64_t kend = min(M, kbeg + rows_per_split);
-  TransLoader<TN_TM, 512> al(dY, lddy, i0, N);
-  TransLoader<TN_TN, 512> bl(X, ldx, j0, K);
+  TransLoader<TN_TM, 256> al(dY, lddy, i0, N);
+  TransLoader<TN_TN, 256> bl(X, ldx, j0, K);
   f32x16 acc[2][2];
-  mainloop<4, 2>(al, bl, lds, kbeg, kend, acc);
+  mainloop<2, 2>(al, bl, lds, kbeg, kend, acc);
   float *out = slab + (int64_t)blockIdx.z * N * K;
-  foreach_acc<4, 2>(acc, [&](int row, int col, float v) {
+  foreach_acc<2, 2>(acc, [&](int row, int col, float v) {
     int64_t i = i0 + row, j = j0 + col;
     if (i < N && j < K) out[i * K + j] = v;
   });
@@ -353,7 +359,7 @@ __global__ void slab_reduce_x3_kernel(const float *__restrict__ slab, float *__r
 
 int tn_splits(int64_t M, int64_t N, int64_t K, int64_t *rows_per_split) {
   int64_t tiles = cdiv(N, TN_TM) * cdiv(K, TN_TN);
-  int64_t want = cdiv(512, tiles);  // one 8-wave workgroup per CU, two rounds
+  int64_t want = cdiv(1536, tiles);  // three 4-wave workgroups per CU, two rounds
   if (want < 1) want = 1;
   int64_t rps = cdiv(cdiv(M, want), XK) * XK;  // multiple of the k-step
   if (rps < XK) rps = XK;
@@ -401,7 +407,7 @@ extern "C" int svr_linear_bwd_weight_bf16x3(const float *dY, int64_t lddy, const
   int splits = tn_splits(M, N, K, &rps);
   float *slab = (float *)workspace;
   dim3 grid((unsigned)cdiv(K, TN_TN), (unsigned)cdiv(N, TN_TM), (unsigned)splits);
-  hipLaunchKernelGGL(linear_tn_x3_kernel, grid, dim3(512), 0, s, dY, lddy, X, ldx, slab, M, N, K, rps);
+  hipLaunchKernelGGL(linear_tn_x3_kernel, grid, dim3(256), 0, s, dY, lddy, X, ldx, slab, M, N, K, rps);
   hipLaunchKernelGGL(slab_reduce_x3_kernel, dim3((unsigned)cdiv(N * K, 256)), dim3(256), 0, s, slab, dW, N, K, lddw, splits);
   if (db) colsum_launch(dY, lddy, db, slab + (int64_t)splits * N * K, M, N, s);
   return launch_status("linear_bwd_weight_bf16x3");

@@ -11,7 +11,7 @@
 //   Y[M,N] = epi( X[M,K] W[N,K]^T )     X split on the fly, W pre-split once per call into 3 planes.
 //
 // 128x128 tile, 4 waves x (2x2) v_mfma_f32_32x32x16_bf16 tiles, k-step 16, LDS planes [row][k] with a 40-byte
-// row stride (ds_read_b64 fragment reads conflict free), two LDS stages (61 KB -> 2 workgroups per CU).
+// row stride (ds_read_b64 fragment reads conflict free), one 30 KB LDS stage (4 workgroups per CU).
 #include "common.h"
 
 using namespace svr;
@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256) void linear_nt_x6_kernel(const float *__restri
                                                            const uint16_t *__restrict__ W2, const float *__restrict__ bias,
                                                            float *__restrict__ Y, int64_t ldy, int64_t M, int64_t N,
                                                            int64_t K, int relu) {
-  __shared__ uint32_t lds[2 * STAGE];
+  __shared__ uint32_t lds[STAGE];  // one stage, two barriers per k-step: more workgroups (= loads in flight) per CU
   const int t = threadIdx.x;
   const int lane = t & 63, wave = t >> 6;
   const int wr = wave >> 1, wc = wave & 1;
@@ -131,11 +131,10 @@ __global__ __launch_bounds__(256) void linear_nt_x6_kernel(const float *__restri
   load(0);
   store(lds);
   __syncthreads();
-  int stg = 0;
   for (int64_t k0 = 0; k0 < K; k0 += YK) {
     const bool more = k0 + YK < K;
     if (more) load(k0 + YK);
-    const uint32_t *pa = lds + stg * STAGE, *pb = pa + 3 * PLANE;
+    const uint32_t *pa = lds, *pb = pa + 3 * PLANE;
     bf16x8 a[3][2], b[3][2];
 #pragma unroll
     for (int p = 0; p < 3; ++p)
@@ -155,9 +154,9 @@ __global__ __launch_bounds__(256) void linear_nt_x6_kernel(const float *__restri
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[1][j], acc[i][j], 0, 0, 0);
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][i], b[0][j], acc[i][j], 0, 0, 0);
       }
-    if (more) store(lds + (stg ^ 1) * STAGE);
+    __syncthreads();  // every wave has read its fragments
+    if (more) store(lds);
     __syncthreads();
-    stg ^= 1;
   }
 
 #pragma unroll
