@@ -166,6 +166,13 @@ int svr_conv3d_unpack_wgrad(const float *dWp /*[tap][ci][co]*/, float *dW /*(Co,
 int svr_conv3d_k3(const float *in, const float *Wp, const float *bias, float *out, int32_t B,
                   int32_t D, int32_t H, int32_t W, int32_t Ci, int32_t Co, int epilogue,
                   const float *mask, void *stream);
+/* Backward-data on the bf16 matrix cores with the 3-term split (see svr_linear_bwd_data_bf16x3):
+ * din(B,D,H,W,Ci) = epi( conv^T(dout(B,D,H,W,Co), W(Co,Ci,3,3,3)) ), epilogue NONE or MASK (mask like din).
+ * Takes the UNPACKED weights; workspace: svr_conv3d_bwd_data_bf16x3_workspace(Ci, Co) bytes.  Ci even.   */
+int64_t svr_conv3d_bwd_data_bf16x3_workspace(int32_t Ci, int32_t Co);
+int svr_conv3d_k3_bwd_data_bf16x3(const float *dout, const float *W, float *din, int32_t B, int32_t D,
+                                  int32_t H, int32_t Wd, int32_t Ci, int32_t Co, int epilogue,
+                                  const float *mask, void *workspace, void *stream);
 /* dWp[tap][ci][co] = sum_m in[m+tap][ci]*dout[m][co]; db[co] = sum_m dout[m][co] (may be NULL). */
 int64_t svr_conv3d_k3_bwd_weight_workspace(int32_t B, int32_t D, int32_t H, int32_t W, int32_t Ci,
                                            int32_t Co);

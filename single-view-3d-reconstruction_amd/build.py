@@ -20,6 +20,7 @@ SOURCES = {
     "gemm_bf16x3.hip": [],
     "gemm_bf16x6.hip": [],
     "conv3d.hip": [],
+    "conv3d_bf16.hip": [],
     "bn_pool.hip": [],
     "projection.hip": ["-ffp-contract=off"],
 }

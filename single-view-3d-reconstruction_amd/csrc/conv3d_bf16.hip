@@ -1,0 +1,214 @@
+// 3x3x3 convolution, backward-data, on the bf16 matrix cores with the 3-term split ("bf16x3"), gfx950.
+//
+// Same brick structure as conv3d_brick_kernel (conv3d.hip): one workgroup = one 4x4x8 output brick, wave w =
+// z-slice w (32 voxels = one MFMA row tile); per 32-channel chunk the input halo tile (6x6x10 voxels) is staged
+// in LDS once -- here split on the way in into hi/mid bf16 planes [voxel][ci] -- and serves all 27 taps; the
+// tap's weight slice [co][ci] (pre-split planes, packed once per step) is double buffered in LDS.
+//   x = hi + mid, products hi*hi + hi*mid + mid*hi, f32 accumulation in v_mfma_f32_32x32x16_bf16:
+//   ~1.5e-5 relative per product (see gemm_bf16x3.hip for why that is harmless in the BACKWARD pass), at a
+//   fraction of the exact-f32 MFMA cycles (6 x 32 cycles per 32x32x32 block instead of 16 x 64).
+// Used only for dIn = conv^T(dOut); the forward convolutions stay exact f32.
+#include "common.h"
+
+using namespace svr;
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct ConvShape {
+  int B, D, H, W, Ci, Co;
+};
+
+constexpr int BRZ = 4, BRY = 4, BRX = 8;
+constexpr int HLZ = BRZ + 2, HLY = BRY + 2, HLX = BRX + 2, HLV = HLZ * HLY * HLX;
+
+__device__ __forceinline__ void split2(float x0, float x1, uint32_t &hi, uint32_t &mid) {
+  f32x2 v = {x0, x1};
+  bf16x2 h = __builtin_convertvector(v, bf16x2);
+  hi = __builtin_bit_cast(uint32_t, h);
+  f32x2 r = {x0 - __uint_as_float(hi << 16), x1 - __uint_as_float(hi & 0xffff0000u)};
+  bf16x2 m = __builtin_convertvector(r, bf16x2);
+  mid = __builtin_bit_cast(uint32_t, m);
+}
+
+__device__ __forceinline__ bf16x8 read_frag(const uint32_t *p) {  // 8 bf16 at an 8-byte aligned address
+  const uint2 a = *reinterpret_cast<const uint2 *>(p);
+  const uint2 b = *reinterpret_cast<const uint2 *>(p + 2);
+  union { uint4 q; bf16x8 v; } f;
+  f.q = make_uint4(a.x, a.y, b.x, b.y);
+  return f.v;
+}
+
+// W (Co,Ci,3,3,3) f32 -> backward-data planes [2][27][Ci][Co] bf16: row = ORIGINAL input channel (the output
+// channel of the transposed conv), k = original output channel, taps flipped.
+__global__ void pack_bwd_planes_kernel(const float *__restrict__ W, uint16_t *__restrict__ hi, uint16_t *__restrict__ mid,
+                                       int Ci, int Co) {
+  int idx = blockIdx.x * blockDim.x + threadIdx.x;  // over (tap', ci, co/2)
+  if (idx >= 27 * Ci * (Co / 2)) return;
+  const int co = (idx % (Co / 2)) * 2;
+  const int ci = (idx / (Co / 2)) % Ci;
+  const int tp = idx / ((Co / 2) * Ci);
+  uint32_t h, m;
+  split2(W[((size_t)co * Ci + ci) * 27 + (26 - tp)], W[((size_t)(co + 1) * Ci + ci) * 27 + (26 - tp)], h, m);
+  const size_t o = ((size_t)tp * Ci + ci) * Co + co;
+  *reinterpret_cast<uint32_t *>(hi + o) = h;
+  *reinterpret_cast<uint32_t *>(mid + o) = m;
+}
+
+// out(B,D,H,W,NOUT) = epi( sum_{tap,k} in[voxel+tap][k] * P[tap][n][k] ), K = s.Ci input channels of THIS call,
+// NOUT = s.Co.  planes: hi then mid, each [27][NOUT][K] bf16.
+template <int CK, int TNB>
+__global__ __launch_bounds__(256) void conv3d_brick_x3_kernel(const float *__restrict__ in,
+                                                              const uint16_t *__restrict__ Ph,
+                                                              const uint16_t *__restrict__ Pm, float *__restrict__ out,
+                                                              const float *__restrict__ mask, ConvShape s, int nbz, int nby,
+                                                              int nbx, int mode) {
+  constexpr int XW = (CK + 4) / 2;           // dwords per LDS row (CK bf16 + 8 B pad)
+  constexpr int NC = TNB * 32;               // output columns of this workgroup
+  constexpr int TG = TNB == 1 ? 3 : 1;       // taps per barrier
+  constexpr int KS = CK / 16;                // MFMA k sub-steps per chunk
+  constexpr int PIECES = TG * 2 * NC * (CK / 8);  // 16-byte pieces per weight group
+  constexpr int WPT = (PIECES + 255) / 256;
+  __shared__ uint32_t sh[2][HLV * XW];       // halo tile, hi / mid planes: [voxel][k]
+  __shared__ uint32_t sw[2][TG][2][NC * XW]; // weight slices: [buffer][tap][plane][n][k]
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int l31 = lane & 31, lh = lane >> 5;
+  int64_t q = blockIdx.x;
+  const int bx = (int)(q % nbx); q /= nbx;
+  const int by = (int)(q % nby); q /= nby;
+  const int bz = (int)(q % nbz);
+  const int64_t b = q / nbz;
+  const int z0 = bz * BRZ, y0 = by * BRY, x0 = bx * BRX;
+  const int n0 = blockIdx.y * NC;
+  const float *inb = in + b * (int64_t)s.D * s.H * s.W * s.Ci;
+  const int hrow = ((wave + 1) * HLY + l31 / BRX + 1) * HLX + l31 % BRX + 1;  // this lane's voxel in the halo tile
+  f32x16 acc[TNB];
+#pragma unroll
+  for (int j = 0; j < TNB; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+  uint2 wreg[WPT][2];
+  auto wload = [&](int k0, int tap0) {
+#pragma unroll
+    for (int i = 0; i < WPT; ++i) {
+      const int idx = t + 256 * i;
+      const int part = idx % (CK / 8), row = (idx / (CK / 8)) % NC, pl = (idx / (CK / 8 * NC)) % 2, tg = idx / (CK / 8 * NC * 2);
+      const bool ok = idx < PIECES && n0 + row < s.Co;
+      const uint16_t *base = pl ? Pm : Ph;
+      const uint2 *p = reinterpret_cast<const uint2 *>(base + ((size_t)(tap0 + (ok ? tg : 0)) * s.Co + (ok ? n0 + row : 0)) * s.Ci + k0 + part * 8);
+      wreg[i][0] = ok ? p[0] : make_uint2(0, 0);
+      wreg[i][1] = ok ? p[1] : make_uint2(0, 0);
+    }
+  };
+  auto wstore = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < WPT; ++i) {
+      const int idx = t + 256 * i;
+      if (idx < PIECES) {
+        const int part = idx % (CK / 8), row = (idx / (CK / 8)) % NC, pl = (idx / (CK / 8 * NC)) % 2, tg = idx / (CK / 8 * NC * 2);
+        uint32_t *d = &sw[buf][tg][pl][row * XW + part * 4];
+        *reinterpret_cast<uint2 *>(d) = wreg[i][0];
+        *reinterpret_cast<uint2 *>(d + 2) = wreg[i][1];
+      }
+    }
+  };
+
+  for (int k0 = 0; k0 < s.Ci; k0 += CK) {
+    wload(k0, 0);
+    if (k0 > 0) __syncthreads();  // previous chunk's tiles are no longer read
+    for (int idx = t; idx < HLV * (CK / 4); idx += 256) {
+      const int hv = idx / (CK / 4), c4 = (idx % (CK / 4)) * 4;
+      const int hx = hv % HLX, hy = (hv / HLX) % HLY, hz = hv / (HLX * HLY);
+      const int gz = z0 + hz - 1, gy = y0 + hy - 1, gx = x0 + hx - 1;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (gz >= 0 && gz < s.D && gy >= 0 && gy < s.H && gx >= 0 && gx < s.W)
+        v = *reinterpret_cast<const float4 *>(inb + (((int64_t)gz * s.H + gy) * s.W + gx) * s.Ci + k0 + c4);
+      uint32_t h0, m0, h1, m1;
+      split2(v.x, v.y, h0, m0);
+      split2(v.z, v.w, h1, m1);
+      *reinterpret_cast<uint2 *>(&sh[0][hv * XW + c4 / 2]) = make_uint2(h0, h1);
+      *reinterpret_cast<uint2 *>(&sh[1][hv * XW + c4 / 2]) = make_uint2(m0, m1);
+    }
+    wstore(0);
+    __syncthreads();
+    for (int tap0 = 0; tap0 < 27; tap0 += TG) {
+      const int buf = (tap0 / TG) & 1;
+      if (tap0 + TG < 27) wload(k0, tap0 + TG);
+#pragma unroll
+      for (int tg = 0; tg < TG; ++tg) {
+        const int tap = tap0 + tg;
+        const int arow = hrow + ((tap / 9 - 1) * HLY + ((tap / 3) % 3 - 1)) * HLX + (tap % 3 - 1);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          const int kw = ks * 8 + lh * 4;
+          const bf16x8 ah = read_frag(&sh[0][arow * XW + kw]);
+          const bf16x8 am = read_frag(&sh[1][arow * XW + kw]);
+#pragma unroll
+          for (int j = 0; j < TNB; ++j) {
+            const bf16x8 bh = read_frag(&sw[buf][tg][0][(j * 32 + l31) * XW + kw]);
+            const bf16x8 bm = read_frag(&sw[buf][tg][1][(j * 32 + l31) * XW + kw]);
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc[j], 0, 0, 0);
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc[j], 0, 0, 0);
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[j], 0, 0, 0);
+          }
+        }
+      }
+      if (tap0 + TG < 27) wstore(buf ^ 1);
+      __syncthreads();
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < TNB; ++j) {
+    const int n = n0 + j * 32 + l31;
+    if (n >= s.Co) continue;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int i = (r & 3) + 8 * (r >> 2) + 4 * lh;
+      const int gz = z0 + wave, gy = y0 + i / BRX, gx = x0 + i % BRX;
+      if (gz < s.D && gy < s.H && gx < s.W) {
+        const int64_t o = ((((int64_t)b * s.D + gz) * s.H + gy) * s.W + gx) * s.Co + n;
+        float v = acc[j][r];
+        if (mode == SVR_EPI_MASK) v = mask[o] > 0.f ? v : 0.f;
+        out[o] = v;
+      }
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int64_t svr_conv3d_bwd_data_bf16x3_workspace(int32_t Ci, int32_t Co) { return 2LL * 27 * Ci * Co * (int64_t)sizeof(uint16_t) + 256; }
+
+// dIn(B,D,H,W,Ci) = epi( conv^T(dOut(B,D,H,W,Co), W(Co,Ci,3,3,3)) ), epilogue NONE or MASK (mask shaped like dIn).
+extern "C" int svr_conv3d_k3_bwd_data_bf16x3(const float *dout, const float *W, float *din, int32_t B, int32_t D, int32_t H,
+                                             int32_t Wd, int32_t Ci, int32_t Co, int epilogue, const float *mask,
+                                             void *workspace, void *stream) {
+  SVR_CHECK(dout && W && din && workspace, SVR_E_BADARG, "conv3d_bwd_data_bf16x3: null pointer");
+  SVR_CHECK(B > 0 && D > 0 && H > 0 && Wd > 0, SVR_E_BADSHAPE, "conv3d_bwd_data_bf16x3: empty volume");
+  SVR_CHECK(Co % 16 == 0 && Ci % 2 == 0 && Ci >= 2, SVR_E_UNSUPPORTED, "conv3d_bwd_data_bf16x3: need Co %% 16 == 0, Ci even (Ci=%d Co=%d)", Ci, Co);
+  SVR_CHECK(epilogue == SVR_EPI_NONE || (epilogue == SVR_EPI_MASK && mask), SVR_E_BADARG, "conv3d_bwd_data_bf16x3: epilogue %d", epilogue);
+  hipStream_t s = (hipStream_t)stream;
+  uint16_t *hi = (uint16_t *)(((uintptr_t)workspace + 15) & ~(uintptr_t)15);
+  uint16_t *mid = hi + (size_t)27 * Ci * Co;
+  // the transposed conv reads dOut (Co channels = its K) and writes Ci channels: planes [27][Ci][Co]
+  hipLaunchKernelGGL(pack_bwd_planes_kernel, dim3(cdiv(27 * Ci * (Co / 2), 256)), dim3(256), 0, s, W, hi, mid, Ci, Co);
+  ConvShape sh{B, D, H, Wd, /*K=*/Co, /*NOUT=*/Ci};
+  const int nbz = (int)cdiv(D, BRZ), nby = (int)cdiv(H, BRY), nbx = (int)cdiv(Wd, BRX);
+  const unsigned bricks = (unsigned)((int64_t)B * nbz * nby * nbx);
+#define LAUNCH_X3(CKV, TNV)                                                                                             \
+  hipLaunchKernelGGL((conv3d_brick_x3_kernel<CKV, TNV>), dim3(bricks, (unsigned)cdiv(Ci, TNV * 32)), dim3(256), 0, s, dout, \
+                     hi, mid, din, mask, sh, nbz, nby, nbx, epilogue)
+  const int tn = Ci <= 32 ? 1 : (Ci <= 64 ? 2 : 4);
+  if (Co % 32 == 0) {
+    if (tn == 1) LAUNCH_X3(32, 1); else if (tn == 2) LAUNCH_X3(32, 2); else LAUNCH_X3(32, 4);
+  } else {
+    if (tn == 1) LAUNCH_X3(16, 1); else if (tn == 2) LAUNCH_X3(16, 2); else LAUNCH_X3(16, 4);
+  }
+#undef LAUNCH_X3
+  return launch_status("conv3d_bwd_data_bf16x3");
+}

@@ -58,20 +58,19 @@ class _EncoderGatherFn(torch.autograd.Function):
         inp = x_cl
         nst = len(ext._stages)
         for si, (convs, bn) in enumerate(ext._stages):
-            acts, packed = [], []
+            acts = []
             cur = inp
             for conv in convs:
-                wf, wb = ops.conv3d_pack_weight(conv.weight.detach(), want_bwd=True)
+                wf, _ = ops.conv3d_pack_weight(conv.weight.detach(), want_bwd=False)
                 cur = ops.conv3d_k3(cur, wf, conv.bias.detach(), relu=True)
                 acts.append(cur)
-                packed.append(wb)
             y, pooled, argmax, ss, mean = ops.bn_forward(
                 cur, bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var, training,
                 eps=bn.eps, momentum=bn.momentum, want_pool=(si + 1 < nst))
             if training:
                 bn.num_batches_tracked += 1
             levels.append(y)
-            saved.append((inp, acts, packed, argmax, ss, mean))
+            saved.append((inp, acts, argmax, ss, mean))
             inp = pooled
         feat = ops.gather_fwd(levels, pts, ext._layout, ext._disp, ext._align)
         ctx.ext, ctx.saved, ctx.levels, ctx.pts = ext, saved, levels, pts
@@ -102,7 +101,7 @@ class _EncoderGatherFn(torch.autograd.Function):
         gx = None
         for si in range(len(ext._stages) - 1, -1, -1):
             convs, bn = ext._stages[si]
-            inp, acts, packed, argmax, ss, mean = saved[si]
+            inp, acts, argmax, ss, mean = saved[si]
             dout, dgamma, dbeta = ops.bn_backward(acts[-1], gvols[si + 1], dpooled, argmax if dpooled is not None else None,
                                                   mean, ss, relu_mask=True)
             grads[bn.weight], grads[bn.bias] = dgamma, dbeta
@@ -114,11 +113,11 @@ class _EncoderGatherFn(torch.autograd.Function):
                 grads[conv.weight] = ops.conv3d_unpack_wgrad(dwp, Ci, Co)
                 grads[conv.bias] = db
                 if k > 0:
-                    dout = ops.conv3d_k3(dout, packed[k], mask=acts[k - 1])
+                    dout = ops.conv3d_k3_bwd_data(dout, conv.weight.detach(), mask=acts[k - 1])
                 elif si > 0:
-                    dpooled = ops.conv3d_k3(dout, packed[k])
+                    dpooled = ops.conv3d_k3_bwd_data(dout, conv.weight.detach())
                 elif need_x:
-                    gx = ops.conv3d_k3(dout, packed[k])
+                    gx = ops.conv3d_k3_bwd_data(dout, conv.weight.detach())
         if need_x:
             gx = (gx + gvols[0]).view(ctx.x_shape)
         out = [None, gx, gpts]

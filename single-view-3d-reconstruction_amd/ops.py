@@ -280,6 +280,28 @@ def conv3d_k3(x, wp, bias=None, relu=False, mask=None):
     return out
 
 
+# Arithmetic of the encoder's backward-data convolutions: "bf16x3" (conv3d_bf16.hip) or "f32".
+BACKWARD_CONV = "bf16x3"
+
+
+def conv3d_k3_bwd_data(dout, w, mask=None, mode=None):
+    """din (B,D,H,W,Ci) = conv^T(dout (B,D,H,W,Co), w (Co,Ci,3,3,3)) [* (mask > 0)]."""
+    _f32(dout, w, mask)
+    B, D, H, W, Co = dout.shape
+    Ci = w.shape[1]
+    assert w.shape[0] == Co
+    if (mode or BACKWARD_CONV) == "bf16x3" and Ci % 2 == 0 and Co % 16 == 0:
+        l = _lib.lib()
+        din = torch.empty(B, D, H, W, Ci, device=dout.device, dtype=torch.float32)
+        ws = torch.empty(l.svr_conv3d_bwd_data_bf16x3_workspace(Ci, Co), device=dout.device, dtype=torch.uint8)
+        check(l.svr_conv3d_k3_bwd_data_bf16x3(_p(dout), _p(w), _p(din), B, D, H, W, Ci, Co,
+                                              EPI_MASK if mask is not None else EPI_NONE, _p(mask), _p(ws), _stream()),
+              "conv3d_bwd_data_bf16x3")
+        return din
+    _, wb = conv3d_pack_weight(w, want_bwd=True)
+    return conv3d_k3(dout, wb, mask=mask)
+
+
 def conv3d_k3_bwd_weight(x, dout, want_bias=True):
     """dWp [27][Ci][Co], db (Co)."""
     _f32(x, dout)

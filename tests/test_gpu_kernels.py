@@ -192,6 +192,13 @@ def test_conv3d_fwd_bwd(B, dims, Ci, Co):
     if Ci > 1:
         dxm = ops.conv3d_k3(_cl(dy), wb, mask=_cl(x.detach()))
         assert G.rel_err(_ncdhw(dxm).numpy(), (gx * (x > 0)).detach().numpy()) < 3e-6
+    # the production backward-data path: f32 fallback for Ci == 1, bf16x3 split otherwise (2^-16 per product)
+    for mode, tol in (("f32", 3e-6), ("bf16x3", 5e-5 if Ci > 1 else 3e-6)):
+        d2 = ops.conv3d_k3_bwd_data(_cl(dy), w.detach().cuda(), mode=mode)
+        assert G.rel_err(_ncdhw(d2).numpy(), gx.numpy()) < tol, mode
+        if Ci > 1:
+            d3 = ops.conv3d_k3_bwd_data(_cl(dy), w.detach().cuda(), mask=_cl(x.detach()), mode=mode)
+            assert G.rel_err(_ncdhw(d3).numpy(), (gx * (x > 0)).detach().numpy()) < tol, mode
 
 
 @pytest.mark.parametrize("B,dims,C,pool", [(2, (9, 7, 10), 16, True), (1, (8, 8, 8), 32, True), (2, (5, 4, 6), 64, True),
