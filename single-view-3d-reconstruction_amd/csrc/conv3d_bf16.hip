@@ -1,4 +1,5 @@
-// 3x3x3 convolution, backward-data, on the bf16 matrix cores with the 3-term split ("bf16x3"), gfx950.
+// 3x3x3 convolution on the bf16 matrix cores, gfx950: backward-data with the 3-term split ("bf16x3") and
+// forward with the 6-product split ("bf16x6", f32-equivalent accuracy: x = hi + mid + lo, see gemm_bf16x6.hip).
 //
 // Same brick structure as conv3d_brick_kernel (conv3d.hip): one workgroup = one 4x4x8 output brick, wave w =
 // z-slice w (32 voxels = one MFMA row tile); per 32-channel chunk the input halo tile (6x6x10 voxels) is staged
@@ -7,7 +8,8 @@
 //   x = hi + mid, products hi*hi + hi*mid + mid*hi, f32 accumulation in v_mfma_f32_32x32x16_bf16:
 //   ~1.5e-5 relative per product (see gemm_bf16x3.hip for why that is harmless in the BACKWARD pass), at a
 //   fraction of the exact-f32 MFMA cycles (6 x 32 cycles per 32x32x32 block instead of 16 x 64).
-// Used only for dIn = conv^T(dOut); the forward convolutions stay exact f32.
+// bf16x3 is used only for dIn = conv^T(dOut); the forward uses bf16x6 (three planes, six products, 16-channel
+// chunks so the three halo planes still fit two workgroups per CU) and is held to the exact-f32 kernel's gate.
 #include "common.h"
 
 using namespace svr;
@@ -35,6 +37,14 @@ __device__ __forceinline__ void split2(float x0, float x1, uint32_t &hi, uint32_
   mid = __builtin_bit_cast(uint32_t, m);
 }
 
+__device__ __forceinline__ void split3(float x0, float x1, uint32_t &hi, uint32_t &mid, uint32_t &lo) {
+  split2(x0, x1, hi, mid);
+  f32x2 r = {(x0 - __uint_as_float(hi << 16)) - __uint_as_float(mid << 16),
+             (x1 - __uint_as_float(hi & 0xffff0000u)) - __uint_as_float(mid & 0xffff0000u)};
+  bf16x2 l = __builtin_convertvector(r, bf16x2);
+  lo = __builtin_bit_cast(uint32_t, l);
+}
+
 __device__ __forceinline__ bf16x8 read_frag(const uint32_t *p) {  // 8 bf16 at an 8-byte aligned address
   const uint2 a = *reinterpret_cast<const uint2 *>(p);
   const uint2 b = *reinterpret_cast<const uint2 *>(p + 2);
@@ -59,22 +69,39 @@ __global__ void pack_bwd_planes_kernel(const float *__restrict__ W, uint16_t *__
   *reinterpret_cast<uint32_t *>(mid + o) = m;
 }
 
+// W (Co,Ci,3,3,3) f32 -> forward planes [3][27][Co][Ci] bf16 (row = output channel, k = input channel)
+__global__ void pack_fwd_planes_kernel(const float *__restrict__ W, uint16_t *__restrict__ p0, uint16_t *__restrict__ p1,
+                                       uint16_t *__restrict__ p2, int Ci, int Co) {
+  int idx = blockIdx.x * blockDim.x + threadIdx.x;  // over (tap, co, ci/2)
+  if (idx >= 27 * Co * (Ci / 2)) return;
+  const int ci = (idx % (Ci / 2)) * 2;
+  const int co = (idx / (Ci / 2)) % Co;
+  const int tap = idx / ((Ci / 2) * Co);
+  uint32_t h, m, l;
+  split3(W[((size_t)co * Ci + ci) * 27 + tap], W[((size_t)co * Ci + ci + 1) * 27 + tap], h, m, l);
+  const size_t o = ((size_t)tap * Co + co) * Ci + ci;
+  *reinterpret_cast<uint32_t *>(p0 + o) = h;
+  *reinterpret_cast<uint32_t *>(p1 + o) = m;
+  *reinterpret_cast<uint32_t *>(p2 + o) = l;
+}
+
 // out(B,D,H,W,NOUT) = epi( sum_{tap,k} in[voxel+tap][k] * P[tap][n][k] ), K = s.Ci input channels of THIS call,
 // NOUT = s.Co.  planes: hi then mid, each [27][NOUT][K] bf16.
-template <int CK, int TNB>
+// NP = 2: products mid*hi + hi*mid + hi*hi (bf16x3);  NP = 3: the six products of bf16x6.
+template <int CK, int TNB, int NP>
 __global__ __launch_bounds__(256) void conv3d_brick_x3_kernel(const float *__restrict__ in,
-                                                              const uint16_t *__restrict__ Ph,
-                                                              const uint16_t *__restrict__ Pm, float *__restrict__ out,
-                                                              const float *__restrict__ mask, ConvShape s, int nbz, int nby,
-                                                              int nbx, int mode) {
+                                                              const uint16_t *__restrict__ P0,
+                                                              int64_t plane_stride, const float *__restrict__ bias,
+                                                              float *__restrict__ out, const float *__restrict__ mask,
+                                                              ConvShape s, int nbz, int nby, int nbx, int mode) {
   constexpr int XW = (CK + 4) / 2;           // dwords per LDS row (CK bf16 + 8 B pad)
   constexpr int NC = TNB * 32;               // output columns of this workgroup
   constexpr int TG = TNB == 1 ? 3 : 1;       // taps per barrier
   constexpr int KS = CK / 16;                // MFMA k sub-steps per chunk
-  constexpr int PIECES = TG * 2 * NC * (CK / 8);  // 16-byte pieces per weight group
+  constexpr int PIECES = TG * NP * NC * (CK / 8);  // 16-byte pieces per weight group
   constexpr int WPT = (PIECES + 255) / 256;
-  __shared__ uint32_t sh[2][HLV * XW];       // halo tile, hi / mid planes: [voxel][k]
-  __shared__ uint32_t sw[2][TG][2][NC * XW]; // weight slices: [buffer][tap][plane][n][k]
+  __shared__ uint32_t sh[NP][HLV * XW];       // halo tile, hi / mid (/ lo) planes: [voxel][k]
+  __shared__ uint32_t sw[2][TG][NP][NC * XW]; // weight slices: [buffer][tap][plane][n][k]
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int l31 = lane & 31, lh = lane >> 5;
   int64_t q = blockIdx.x;
@@ -97,9 +124,9 @@ __global__ __launch_bounds__(256) void conv3d_brick_x3_kernel(const float *__res
 #pragma unroll
     for (int i = 0; i < WPT; ++i) {
       const int idx = t + 256 * i;
-      const int part = idx % (CK / 8), row = (idx / (CK / 8)) % NC, pl = (idx / (CK / 8 * NC)) % 2, tg = idx / (CK / 8 * NC * 2);
+      const int part = idx % (CK / 8), row = (idx / (CK / 8)) % NC, pl = (idx / (CK / 8 * NC)) % NP, tg = idx / (CK / 8 * NC * NP);
       const bool ok = idx < PIECES && n0 + row < s.Co;
-      const uint16_t *base = pl ? Pm : Ph;
+      const uint16_t *base = P0 + (ok ? pl : 0) * plane_stride;
       const uint2 *p = reinterpret_cast<const uint2 *>(base + ((size_t)(tap0 + (ok ? tg : 0)) * s.Co + (ok ? n0 + row : 0)) * s.Ci + k0 + part * 8);
       wreg[i][0] = ok ? p[0] : make_uint2(0, 0);
       wreg[i][1] = ok ? p[1] : make_uint2(0, 0);
@@ -110,7 +137,7 @@ __global__ __launch_bounds__(256) void conv3d_brick_x3_kernel(const float *__res
     for (int i = 0; i < WPT; ++i) {
       const int idx = t + 256 * i;
       if (idx < PIECES) {
-        const int part = idx % (CK / 8), row = (idx / (CK / 8)) % NC, pl = (idx / (CK / 8 * NC)) % 2, tg = idx / (CK / 8 * NC * 2);
+        const int part = idx % (CK / 8), row = (idx / (CK / 8)) % NC, pl = (idx / (CK / 8 * NC)) % NP, tg = idx / (CK / 8 * NC * NP);
         uint32_t *d = &sw[buf][tg][pl][row * XW + part * 4];
         *reinterpret_cast<uint2 *>(d) = wreg[i][0];
         *reinterpret_cast<uint2 *>(d + 2) = wreg[i][1];
@@ -128,9 +155,15 @@ __global__ __launch_bounds__(256) void conv3d_brick_x3_kernel(const float *__res
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (gz >= 0 && gz < s.D && gy >= 0 && gy < s.H && gx >= 0 && gx < s.W)
         v = *reinterpret_cast<const float4 *>(inb + (((int64_t)gz * s.H + gy) * s.W + gx) * s.Ci + k0 + c4);
-      uint32_t h0, m0, h1, m1;
-      split2(v.x, v.y, h0, m0);
-      split2(v.z, v.w, h1, m1);
+      uint32_t h0, m0, l0 = 0, h1, m1, l1 = 0;
+      if constexpr (NP == 3) {
+        split3(v.x, v.y, h0, m0, l0);
+        split3(v.z, v.w, h1, m1, l1);
+        *reinterpret_cast<uint2 *>(&sh[NP - 1][hv * XW + c4 / 2]) = make_uint2(l0, l1);
+      } else {
+        split2(v.x, v.y, h0, m0);
+        split2(v.z, v.w, h1, m1);
+      }
       *reinterpret_cast<uint2 *>(&sh[0][hv * XW + c4 / 2]) = make_uint2(h0, h1);
       *reinterpret_cast<uint2 *>(&sh[1][hv * XW + c4 / 2]) = make_uint2(m0, m1);
     }
@@ -152,6 +185,13 @@ __global__ __launch_bounds__(256) void conv3d_brick_x3_kernel(const float *__res
           for (int j = 0; j < TNB; ++j) {
             const bf16x8 bh = read_frag(&sw[buf][tg][0][(j * 32 + l31) * XW + kw]);
             const bf16x8 bm = read_frag(&sw[buf][tg][1][(j * 32 + l31) * XW + kw]);
+            if constexpr (NP == 3) {
+              const bf16x8 al = read_frag(&sh[NP - 1][arow * XW + kw]);
+              const bf16x8 bl = read_frag(&sw[buf][tg][NP - 1][(j * 32 + l31) * XW + kw]);
+              acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[j], 0, 0, 0);
+              acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[j], 0, 0, 0);
+              acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc[j], 0, 0, 0);
+            }
             acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc[j], 0, 0, 0);
             acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc[j], 0, 0, 0);
             acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[j], 0, 0, 0);
@@ -166,13 +206,15 @@ __global__ __launch_bounds__(256) void conv3d_brick_x3_kernel(const float *__res
   for (int j = 0; j < TNB; ++j) {
     const int n = n0 + j * 32 + l31;
     if (n >= s.Co) continue;
+    const float bv = (mode == SVR_EPI_BIAS || mode == SVR_EPI_BIAS_RELU) ? bias[n] : 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int i = (r & 3) + 8 * (r >> 2) + 4 * lh;
       const int gz = z0 + wave, gy = y0 + i / BRX, gx = x0 + i % BRX;
       if (gz < s.D && gy < s.H && gx < s.W) {
         const int64_t o = ((((int64_t)b * s.D + gz) * s.H + gy) * s.W + gx) * s.Co + n;
-        float v = acc[j][r];
+        float v = acc[j][r] + bv;
+        if (mode == SVR_EPI_BIAS_RELU) v = fmaxf(v, 0.f);
         if (mode == SVR_EPI_MASK) v = mask[o] > 0.f ? v : 0.f;
         out[o] = v;
       }
@@ -200,9 +242,9 @@ extern "C" int svr_conv3d_k3_bwd_data_bf16x3(const float *dout, const float *W, 
   ConvShape sh{B, D, H, Wd, /*K=*/Co, /*NOUT=*/Ci};
   const int nbz = (int)cdiv(D, BRZ), nby = (int)cdiv(H, BRY), nbx = (int)cdiv(Wd, BRX);
   const unsigned bricks = (unsigned)((int64_t)B * nbz * nby * nbx);
-#define LAUNCH_X3(CKV, TNV)                                                                                             \
-  hipLaunchKernelGGL((conv3d_brick_x3_kernel<CKV, TNV>), dim3(bricks, (unsigned)cdiv(Ci, TNV * 32)), dim3(256), 0, s, dout, \
-                     hi, mid, din, mask, sh, nbz, nby, nbx, epilogue)
+#define LAUNCH_X3(CKV, TNV)                                                                                               \
+  hipLaunchKernelGGL((conv3d_brick_x3_kernel<CKV, TNV, 2>), dim3(bricks, (unsigned)cdiv(Ci, TNV * 32)), dim3(256), 0, s, dout, \
+                     hi, (int64_t)27 * Ci * Co, (const float *)nullptr, din, mask, sh, nbz, nby, nbx, epilogue)
   const int tn = Ci <= 32 ? 1 : (Ci <= 64 ? 2 : 4);
   if (Co % 32 == 0) {
     if (tn == 1) LAUNCH_X3(32, 1); else if (tn == 2) LAUNCH_X3(32, 2); else LAUNCH_X3(32, 4);
@@ -211,4 +253,30 @@ extern "C" int svr_conv3d_k3_bwd_data_bf16x3(const float *dout, const float *W, 
   }
 #undef LAUNCH_X3
   return launch_status("conv3d_bwd_data_bf16x3");
+}
+
+extern "C" int64_t svr_conv3d_fwd_bf16x6_workspace(int32_t Ci, int32_t Co) { return 3LL * 27 * Ci * Co * (int64_t)sizeof(uint16_t) + 256; }
+
+// out(B,D,H,W,Co) = epi( conv(in(B,D,H,W,Ci), W(Co,Ci,3,3,3)) ) at f32 accuracy; epilogue NONE / BIAS / BIAS_RELU.
+extern "C" int svr_conv3d_k3_fwd_bf16x6(const float *in, const float *W, const float *bias, float *out, int32_t B, int32_t D,
+                                        int32_t H, int32_t Wd, int32_t Ci, int32_t Co, int epilogue, void *workspace,
+                                        void *stream) {
+  SVR_CHECK(in && W && out && workspace, SVR_E_BADARG, "conv3d_fwd_bf16x6: null pointer");
+  SVR_CHECK(B > 0 && D > 0 && H > 0 && Wd > 0, SVR_E_BADSHAPE, "conv3d_fwd_bf16x6: empty volume");
+  SVR_CHECK(Ci % 16 == 0 && Co >= 1, SVR_E_UNSUPPORTED, "conv3d_fwd_bf16x6: need Ci %% 16 == 0 (Ci=%d Co=%d)", Ci, Co);
+  SVR_CHECK(epilogue == SVR_EPI_NONE || ((epilogue == SVR_EPI_BIAS || epilogue == SVR_EPI_BIAS_RELU) && bias), SVR_E_BADARG,
+            "conv3d_fwd_bf16x6: epilogue %d", epilogue);
+  hipStream_t s = (hipStream_t)stream;
+  uint16_t *p0 = (uint16_t *)(((uintptr_t)workspace + 15) & ~(uintptr_t)15);
+  const int64_t ps = (int64_t)27 * Ci * Co;
+  hipLaunchKernelGGL(pack_fwd_planes_kernel, dim3(cdiv(27 * Co * (Ci / 2), 256)), dim3(256), 0, s, W, p0, p0 + ps, p0 + 2 * ps, Ci, Co);
+  ConvShape sh{B, D, H, Wd, Ci, Co};
+  const int nbz = (int)cdiv(D, BRZ), nby = (int)cdiv(H, BRY), nbx = (int)cdiv(Wd, BRX);
+  const unsigned bricks = (unsigned)((int64_t)B * nbz * nby * nbx);
+#define LAUNCH_X6(TNV)                                                                                                    \
+  hipLaunchKernelGGL((conv3d_brick_x3_kernel<16, TNV, 3>), dim3(bricks, (unsigned)cdiv(Co, TNV * 32)), dim3(256), 0, s, in, p0, \
+                     ps, bias, out, (const float *)nullptr, sh, nbz, nby, nbx, epilogue)
+  if (Co <= 32) LAUNCH_X6(1); else if (Co <= 64) LAUNCH_X6(2); else LAUNCH_X6(4);
+#undef LAUNCH_X6
+  return launch_status("conv3d_fwd_bf16x6");
 }

@@ -61,8 +61,7 @@ class _EncoderGatherFn(torch.autograd.Function):
             acts = []
             cur = inp
             for conv in convs:
-                wf, _ = ops.conv3d_pack_weight(conv.weight.detach(), want_bwd=False)
-                cur = ops.conv3d_k3(cur, wf, conv.bias.detach(), relu=True)
+                cur = ops.conv3d_k3_fwd(cur, conv.weight.detach(), conv.bias.detach(), relu=True)
                 acts.append(cur)
             y, pooled, argmax, ss, mean = ops.bn_forward(
                 cur, bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var, training,
@@ -187,8 +186,7 @@ class _ExtractorBase(nn.Module):
         for si, (convs, bn) in enumerate(self._stages):
             cur = inp
             for conv in convs:
-                wf, _ = ops.conv3d_pack_weight(conv.weight.detach(), want_bwd=False)
-                cur = ops.conv3d_k3(cur, wf, conv.bias.detach(), relu=True)
+                cur = ops.conv3d_k3_fwd(cur, conv.weight.detach(), conv.bias.detach(), relu=True)
             y, pooled, _, _, _ = ops.bn_forward(cur, bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var,
                                                 self.training, eps=bn.eps, momentum=bn.momentum, want_pool=(si + 1 < nst))
             levels.append(y)

@@ -282,6 +282,24 @@ def conv3d_k3(x, wp, bias=None, relu=False, mask=None):
 
 # Arithmetic of the encoder's backward-data convolutions: "bf16x3" (conv3d_bf16.hip) or "f32".
 BACKWARD_CONV = "bf16x3"
+# ... and of its forward convolutions: "bf16x6" (f32-equivalent) or "f32" (exact-f32 MFMA)
+FORWARD_CONV = "bf16x6"
+
+
+def conv3d_k3_fwd(x, w, bias, relu=True, mode=None):
+    """relu(conv(x (B,D,H,W,Ci), w (Co,Ci,3,3,3)) + bias) -> (B,D,H,W,Co)."""
+    _f32(x, w, bias)
+    B, D, H, W, Ci = x.shape
+    Co = w.shape[0]
+    if (mode or FORWARD_CONV) == "bf16x6" and Ci % 16 == 0:
+        l = _lib.lib()
+        out = torch.empty(B, D, H, W, Co, device=x.device, dtype=torch.float32)
+        ws = torch.empty(l.svr_conv3d_fwd_bf16x6_workspace(Ci, Co), device=x.device, dtype=torch.uint8)
+        check(l.svr_conv3d_k3_fwd_bf16x6(_p(x), _p(w), _p(bias), _p(out), B, D, H, W, Ci, Co,
+                                         EPI_BIAS_RELU if relu else EPI_BIAS, _p(ws), _stream()), "conv3d_fwd_bf16x6")
+        return out
+    wf, _ = conv3d_pack_weight(w, want_bwd=False)
+    return conv3d_k3(x, wf, bias, relu=relu)
 
 
 def conv3d_k3_bwd_data(dout, w, mask=None, mode=None):

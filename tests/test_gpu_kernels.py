@@ -183,6 +183,9 @@ def test_conv3d_fwd_bwd(B, dims, Ci, Co):
     wf, wb = ops.conv3d_pack_weight(w.detach().cuda())
     y = ops.conv3d_k3(_cl(x.detach()), wf, b.detach().cuda(), relu=True)
     assert G.rel_err(_ncdhw(y).numpy(), y_ref.detach().numpy()) < 3e-6
+    for mode in ("f32", "bf16x6"):      # production forward: bf16x6 where Ci % 16 == 0, held to the f32 gate
+        y2 = ops.conv3d_k3_fwd(_cl(x.detach()), w.detach().cuda(), b.detach().cuda(), relu=True, mode=mode)
+        assert G.rel_err(_ncdhw(y2).numpy(), y_ref.detach().numpy()) < 3e-6, mode
     dwp, db = ops.conv3d_k3_bwd_weight(_cl(x.detach()), _cl(dy))
     dw = ops.conv3d_unpack_wgrad(dwp, Ci, Co)
     assert G.rel_err(dw.cpu().numpy(), gw.numpy()) < 3e-6
