@@ -85,6 +85,10 @@ def lib():
             raise RuntimeError(
                 f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950).  There is no CPU fallback for the HIP path.")
+        # torch must load ITS HIP runtime first: libsvr_hip.so only names libamdhip64 by SONAME, and if the
+        # system copy gets mapped before torch's, the process ends up with two runtimes (kernels launched by one
+        # on memory owned by the other: "no ROCm-capable device" from rocPRIM).
+        import torch  # noqa: F401
         l = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(l, name)          # AttributeError here = header/library mismatch
