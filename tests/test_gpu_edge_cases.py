@@ -89,3 +89,32 @@ def test_spatial_sort_does_not_change_results():
         a = m(x, pts, spatial_sort=True)
         b = m(x, pts, spatial_sort=False)
     assert torch.equal(a, b)          # forward is order independent bit for bit (rows are independent)
+
+
+def test_baseline_config2_gather_plus_mlp_only():
+    """BASELINE configs[1] shape: six feature volumes at the 64^3 level sizes, 10k points, batch 4, the gather +
+    point-MLP kernels only (no encoder), against the CPU oracle's grid_sample + conv1d chain: 1e-4 on the logits."""
+    import svr_amd  # noqa: F401
+    from svr_amd import ops
+    B, D, N = 4, 64, 10000
+    chans = [1, 16, 32, 64, 128, 128]
+    g = torch.Generator().manual_seed(102)
+    vols, d = [], D
+    for i, c in enumerate(chans):
+        vols.append(torch.randn(B, c, d, d, d, generator=g))
+        if i >= 1:
+            d //= 2
+    pts = torch.rand(B, N, 3, generator=g) - 0.5
+    st = O.name_seeded_state(128)
+    ref = O.point_mlp(st, O.gather_features(vols, pts, 128))                      # (B, N)
+    layout = ops.FeatureLayout(chans)
+    rows = ops.gather_fwd([v.permute(0, 2, 3, 4, 1).contiguous().cuda() for v in vols], pts.cuda(), layout,
+                          float(np.float32(0.0722)), False)
+    perm = layout.reference_permutation()
+    w0 = st["fc_0.weight"].squeeze(2)
+    w0p = torch.cat([w0, w0.new_zeros(w0.shape[0], 1)], 1)[:, torch.where(perm >= 0, perm, torch.full_like(perm, w0.shape[1]))]
+    h = ops.linear_fwd(rows, w0p.contiguous().cuda(), st["fc_0.bias"].cuda(), relu=True)
+    h = ops.linear_fwd(h, st["fc_1.weight"].squeeze(2).contiguous().cuda(), st["fc_1.bias"].cuda(), relu=True)
+    h = ops.linear_fwd(h, st["fc_2.weight"].squeeze(2).contiguous().cuda(), st["fc_2.bias"].cuda(), relu=True)
+    z = ops.fc_out_fwd(h, st["fc_out.weight"].reshape(-1).contiguous().cuda(), st["fc_out.bias"].cuda()).view(B, N)
+    assert G.rel_err(z.cpu().numpy(), ref.numpy()) < 1e-4
