@@ -186,6 +186,13 @@ int64_t svr_conv3d_k3_bwd_weight_workspace(int32_t B, int32_t D, int32_t H, int3
 int svr_conv3d_k3_bwd_weight(const float *in, const float *dout, float *dWp, float *db, int32_t B,
                              int32_t D, int32_t H, int32_t W, int32_t Ci, int32_t Co,
                              void *workspace, void *stream);
+/* Same result on the bf16 matrix cores with the 3-term split (voxels are the MFMA reduction; ~1e-5 relative);
+ * Ci, Co % 4 == 0.  workspace: svr_conv3d_k3_bwd_weight_bf16x3_workspace(...) bytes.                      */
+int64_t svr_conv3d_k3_bwd_weight_bf16x3_workspace(int32_t B, int32_t D, int32_t H, int32_t W, int32_t Ci,
+                                                  int32_t Co);
+int svr_conv3d_k3_bwd_weight_bf16x3(const float *in, const float *dout, float *dWp, float *db, int32_t B,
+                                    int32_t D, int32_t H, int32_t W, int32_t Ci, int32_t Co,
+                                    void *workspace, void *stream);
 
 /* ---------------------------------------------------------------------------------------
  * BatchNorm3d (training or eval) + MaxPool3d(2), channels-last

@@ -21,6 +21,7 @@ SOURCES = {
     "gemm_bf16x6.hip": [],
     "conv3d.hip": [],
     "conv3d_bf16.hip": [],
+    "conv3d_bwdw_bf16.hip": [],
     "bn_pool.hip": [],
     "projection.hip": ["-ffp-contract=off"],
 }

@@ -447,6 +447,15 @@ int check_shape(int B, int D, int H, int W, int Ci, int Co) {
 
 }  // namespace
 
+namespace svr {
+// shared with conv3d_bwdw_bf16.hip: dWp = ordered f64 sum of `parts` slabs [part][tap][tile][32][32]
+void conv3d_bwd_weight_reduce_launch(const float *slab, float *dWp, int Ci, int Co, int cit, int cot, int parts,
+                                     hipStream_t s) {
+  const int per = 27 * cit * cot * 1024;
+  hipLaunchKernelGGL(conv3d_bwd_weight_reduce_kernel, dim3(cdiv(per, 64)), dim3(256), 0, s, slab, dWp, Ci, Co, cit, cot, parts);
+}
+}  // namespace svr
+
 extern "C" int svr_conv3d_pack_weight(const float *W, float *Wp_fwd, float *Wp_bwd, int32_t Ci, int32_t Co, void *stream) {
   SVR_CHECK(W && (Wp_fwd || Wp_bwd), SVR_E_BADARG, "pack_weight: null pointer");
   int n = Ci * Co * 27;

@@ -128,8 +128,8 @@ __global__ __launch_bounds__(256) void conv3d_brick_x3_kernel(const float *__res
       const bool ok = idx < PIECES && n0 + row < s.Co;
       const uint16_t *base = P0 + (ok ? pl : 0) * plane_stride;
       const uint2 *p = reinterpret_cast<const uint2 *>(base + ((size_t)(tap0 + (ok ? tg : 0)) * s.Co + (ok ? n0 + row : 0)) * s.Ci + k0 + part * 8);
-      wreg[i][0] = ok ? p[0] : make_uint2(0, 0);
-      wreg[i][1] = ok ? p[1] : make_uint2(0, 0);
+      wreg[i][0] = p[0];  // unconditional (clamped to piece 0 when out of range: those columns are never stored)
+      wreg[i][1] = p[1];
     }
   };
   auto wstore = [&](int buf) {
@@ -148,13 +148,28 @@ __global__ __launch_bounds__(256) void conv3d_brick_x3_kernel(const float *__res
   for (int k0 = 0; k0 < s.Ci; k0 += CK) {
     wload(k0, 0);
     if (k0 > 0) __syncthreads();  // previous chunk's tiles are no longer read
-    for (int idx = t; idx < HLV * (CK / 4); idx += 256) {
+    // Halo tile: all loads of the chunk are issued first, unconditionally and from clamped coordinates (a load inside
+    // a branch is waited for at the end of the branch, one full memory latency per iteration), zeroed afterwards.
+    constexpr int HIT = (HLV * (CK / 4) + 255) / 256;
+    float4 hreg[HIT];
+    uint32_t hok = 0;
+#pragma unroll
+    for (int i = 0; i < HIT; ++i) {
+      const int idx = min(t + 256 * i, HLV * (CK / 4) - 1);
       const int hv = idx / (CK / 4), c4 = (idx % (CK / 4)) * 4;
       const int hx = hv % HLX, hy = (hv / HLX) % HLY, hz = hv / (HLX * HLY);
       const int gz = z0 + hz - 1, gy = y0 + hy - 1, gx = x0 + hx - 1;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (gz >= 0 && gz < s.D && gy >= 0 && gy < s.H && gx >= 0 && gx < s.W)
-        v = *reinterpret_cast<const float4 *>(inb + (((int64_t)gz * s.H + gy) * s.W + gx) * s.Ci + k0 + c4);
+      if (gz >= 0 && gz < s.D && gy >= 0 && gy < s.H && gx >= 0 && gx < s.W) hok |= 1u << i;
+      const int cz = min(max(gz, 0), s.D - 1), cy = min(max(gy, 0), s.H - 1), cx = min(max(gx, 0), s.W - 1);
+      hreg[i] = *reinterpret_cast<const float4 *>(inb + (((int64_t)cz * s.H + cy) * s.W + cx) * s.Ci + k0 + c4);
+    }
+#pragma unroll
+    for (int i = 0; i < HIT; ++i) {
+      const int idx = t + 256 * i;
+      if (idx >= HLV * (CK / 4)) break;
+      const int hv = idx / (CK / 4), c4 = (idx % (CK / 4)) * 4;
+      const bool ok = (hok >> i) & 1u;
+      const float4 v = make_float4(ok ? hreg[i].x : 0.f, ok ? hreg[i].y : 0.f, ok ? hreg[i].z : 0.f, ok ? hreg[i].w : 0.f);
       uint32_t h0, m0, l0 = 0, h1, m1, l1 = 0;
       if constexpr (NP == 3) {
         split3(v.x, v.y, h0, m0, l0);
@@ -205,17 +220,29 @@ __global__ __launch_bounds__(256) void conv3d_brick_x3_kernel(const float *__res
 #pragma unroll
   for (int j = 0; j < TNB; ++j) {
     const int n = n0 + j * 32 + l31;
-    if (n >= s.Co) continue;
-    const float bv = (mode == SVR_EPI_BIAS || mode == SVR_EPI_BIAS_RELU) ? bias[n] : 0.f;
+    const int nc = min(n, s.Co - 1);
+    const float bv = (mode == SVR_EPI_BIAS || mode == SVR_EPI_BIAS_RELU) ? bias[nc] : 0.f;
+    const int gz = z0 + wave;
+    // the ReLU mask of the whole tile is fetched up front from clamped coordinates: loads inside the bounds
+    // branch would be waited for one at a time
+    float mk[16];
+    if (mode == SVR_EPI_MASK) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int i = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int cy = min(y0 + i / BRX, s.H - 1), cx = min(x0 + i % BRX, s.W - 1), cz = min(gz, s.D - 1);
+        mk[r] = mask[((((int64_t)b * s.D + cz) * s.H + cy) * s.W + cx) * s.Co + nc];
+      }
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int i = (r & 3) + 8 * (r >> 2) + 4 * lh;
-      const int gz = z0 + wave, gy = y0 + i / BRX, gx = x0 + i % BRX;
-      if (gz < s.D && gy < s.H && gx < s.W) {
+      const int gy = y0 + i / BRX, gx = x0 + i % BRX;
+      if (n < s.Co && gz < s.D && gy < s.H && gx < s.W) {
         const int64_t o = ((((int64_t)b * s.D + gz) * s.H + gy) * s.W + gx) * s.Co + n;
         float v = acc[j][r] + bv;
         if (mode == SVR_EPI_BIAS_RELU) v = fmaxf(v, 0.f);
-        if (mode == SVR_EPI_MASK) v = mask[o] > 0.f ? v : 0.f;
+        if (mode == SVR_EPI_MASK) v = mk[r] > 0.f ? v : 0.f;
         out[o] = v;
       }
     }

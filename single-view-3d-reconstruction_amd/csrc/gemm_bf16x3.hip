@@ -283,7 +283,7 @@ __global__ void pack_planes_kernel(const float *__restrict__ W, int64_t ldw, uin
 // as) whole 512-byte row pieces with 16 bytes per lane; the MFMA register layout would give 128-byte pieces
 // of 64 dword stores per lane.
 constexpr int NN_TM = 128, NN_TN = 128, NN_CLD = NN_TN + 4;
-__global__ __launch_bounds__(256) void linear_nn_x3_kernel(const float *__restrict__ dY, int64_t lddy,
+__global__ __launch_bounds__(256, 3) void linear_nn_x3_kernel(const float *__restrict__ dY, int64_t lddy,
                                                            const uint16_t *__restrict__ Wh,
                                                            const uint16_t *__restrict__ Wm, float *__restrict__ dX,
                                                            int64_t lddx, const float *__restrict__ mask, int64_t ldmask,
@@ -301,6 +301,16 @@ __global__ __launch_bounds__(256) void linear_nn_x3_kernel(const float *__restri
   const int wave = t >> 6;
 #pragma unroll
   for (int pass = 0; pass < 2; ++pass) {  // 64 rows per pass (the waves with wr == pass own them)
+    // this pass's ReLU mask, fetched up front from clamped rows (loads inside the bounds branch below would be
+    // waited for one by one) while the tile goes through LDS
+    float4 k4[8];
+    if (mask) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int64_t m = m0 + 64 * pass + (t >> 5) + 8 * i, c = c0 + (t & 31) * 4;
+        k4[i] = *reinterpret_cast<const float4 *>(mask + (m < M ? m : M - 1) * ldmask + (c < K ? c : K - 4));
+      }
+    }
     if ((wave >> 1) == pass)
       foreach_acc<2, 2>(acc, [&](int row, int col, float v) { ct[(row - 64 * pass) * NN_CLD + col] = v; });
     __syncthreads();
@@ -311,11 +321,10 @@ __global__ __launch_bounds__(256) void linear_nn_x3_kernel(const float *__restri
       if (m < M && c < K) {  // K % 4 == 0 (host-checked), so a float4 never straddles the edge
         float4 v = *reinterpret_cast<const float4 *>(ct + row * NN_CLD + c4);
         if (mask) {
-          const float4 k4 = *reinterpret_cast<const float4 *>(mask + m * ldmask + c);
-          v.x = k4.x > 0.f ? v.x : 0.f;
-          v.y = k4.y > 0.f ? v.y : 0.f;
-          v.z = k4.z > 0.f ? v.z : 0.f;
-          v.w = k4.w > 0.f ? v.w : 0.f;
+          v.x = k4[i].x > 0.f ? v.x : 0.f;
+          v.y = k4[i].y > 0.f ? v.y : 0.f;
+          v.z = k4[i].z > 0.f ? v.z : 0.f;
+          v.w = k4[i].w > 0.f ? v.w : 0.f;
         }
         *reinterpret_cast<float4 *>(dX + m * lddx + c) = v;
       }

@@ -320,12 +320,23 @@ def conv3d_k3_bwd_data(dout, w, mask=None, mode=None):
     return conv3d_k3(dout, wb, mask=mask)
 
 
-def conv3d_k3_bwd_weight(x, dout, want_bias=True):
+# Arithmetic of the encoder's weight gradients: "bf16x3" (conv3d_bwdw_bf16.hip) or "f32" (exact-f32 MFMA)
+BACKWARD_CONV_WEIGHT = "bf16x3"
+
+
+def conv3d_k3_bwd_weight(x, dout, want_bias=True, mode=None):
     """dWp [27][Ci][Co], db (Co)."""
     _f32(x, dout)
     B, D, H, W, Ci = x.shape
     Co = dout.shape[4]
     l = _lib.lib()
+    if (mode or BACKWARD_CONV_WEIGHT) == "bf16x3" and Ci % 4 == 0 and Co % 4 == 0:
+        ws = torch.empty(l.svr_conv3d_k3_bwd_weight_bf16x3_workspace(B, D, H, W, Ci, Co), device=x.device, dtype=torch.uint8)
+        dwp = torch.empty(27, Ci, Co, device=x.device, dtype=torch.float32)
+        db = torch.empty(Co, device=x.device, dtype=torch.float32) if want_bias else None
+        check(l.svr_conv3d_k3_bwd_weight_bf16x3(_p(x), _p(dout), _p(dwp), _p(db), B, D, H, W, Ci, Co, _p(ws), _stream()),
+              "conv3d_k3_bwd_weight_bf16x3")
+        return dwp, db
     ws = torch.empty(l.svr_conv3d_k3_bwd_weight_workspace(B, D, H, W, Ci, Co), device=x.device, dtype=torch.uint8)
     dwp = torch.empty(27, Ci, Co, device=x.device, dtype=torch.float32)
     db = torch.empty(Co, device=x.device, dtype=torch.float32) if want_bias else None

@@ -1,0 +1,263 @@
+// 3x3x3 convolution weight gradient on the bf16 matrix cores with the 3-term split ("bf16x3"), gfx950.
+//
+//   dW[tap][ci][co] = sum_voxel in[voxel + tap][ci] * dout[voxel][co]
+//
+// The reduction runs over VOXELS, so both MFMA operands need 8 consecutive voxels of one channel per lane:
+// the brick's input halo tile (6x6x10 voxels) and its dout tile (4x4x8) are transposed on the way into LDS,
+//   in plane  [ci][halo row (hz,hy)][12 bf16: the 10 voxels of the x-row + pad]      (hi and mid planes)
+//   dout plane[co][row (vz,vy)][8 bf16]
+// One 24-byte halo row read serves the three dx taps of a (dz,dy) pair: dx = -1 / +1 are dword-aligned
+// sub-rows, dx = 0 is a 16-bit funnel shift (v_alignbit).  k of v_mfma_f32_32x32x16_bf16 = 2 x-rows of 8 voxels.
+//   x = hi + mid, products mid*hi + hi*mid + hi*hi, f32 accumulation (~1.5e-5 relative per product; the weight
+//   gradient sums 10^4..10^6 such products of mixed sign, see gemm_bf16x3.hip for the error argument).
+//
+// Workgroup = 6 waves, persistent over bricks: wave (dz, h) owns the 9 taps of one dz for half of the brick's
+// voxels (h), 9 accumulator tiles (32 ci x 32 co) stay in registers over all bricks; the two halves and the
+// workgroups land in partial slabs that conv3d.hip's ordered f64 reduce sums (deterministic).  LDS is double
+// buffered: the next brick's global loads are issued before the MFMA phase and written to the other buffer
+// after it, one barrier per brick.  73 KB per buffer -> one workgroup per CU.
+#include "common.h"
+
+namespace svr {
+void colsum_launch(const float *Y, int64_t ldy, float *out, float *part, int64_t M, int64_t N, hipStream_t s);
+int64_t colsum_workspace_floats(int64_t M, int64_t N);
+void conv3d_bwd_weight_reduce_launch(const float *slab, float *dWp, int Ci, int Co, int cit, int cot, int parts,
+                                     hipStream_t s);
+}  // namespace svr
+
+using namespace svr;
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct ConvShape {
+  int B, D, H, W, Ci, Co;
+};
+
+constexpr int BRZ = 4, BRY = 4, BRX = 8;
+constexpr int HLY = BRY + 2;
+constexpr int HROWS = (BRZ + 2) * (BRY + 2);      // 36 halo x-rows
+constexpr int ROWDW = 6;                          // dwords per halo x-row: 10 voxels + 2 pad (bf16)
+constexpr int CIS = HROWS * ROWDW + 2;            // 218 dwords per input channel (26 mod 64: b64 reads conflict free)
+constexpr int COS = BRZ * BRY * 4 + 4;            // 68 dwords per output channel (b128 reads conflict free)
+constexpr int IN_PLANE = 32 * CIS, DO_PLANE = 32 * COS;
+constexpr int BUF = 2 * IN_PLANE + 2 * DO_PLANE;  // dwords per stage: 18 304 (73 216 B)
+constexpr int NT = 384;
+constexpr int IN_ITEMS = HROWS * 5 * 8;           // (halo row, voxel pair, 4-channel group) = 1440
+constexpr int DO_ITEMS = BRZ * BRY * 4 * 8;       // (row, voxel pair, 4-channel group)      = 512
+constexpr int IN_IT = (IN_ITEMS + NT - 1) / NT;   // 4
+constexpr int DO_IT = (DO_ITEMS + NT - 1) / NT;   // 2
+
+__device__ __forceinline__ void split2(float x0, float x1, uint32_t &hi, uint32_t &mid) {
+  f32x2 v = {x0, x1};
+  bf16x2 h = __builtin_convertvector(v, bf16x2);
+  hi = __builtin_bit_cast(uint32_t, h);
+  f32x2 r = {x0 - __uint_as_float(hi << 16), x1 - __uint_as_float(hi & 0xffff0000u)};
+  bf16x2 m = __builtin_convertvector(r, bf16x2);
+  mid = __builtin_bit_cast(uint32_t, m);
+}
+
+__device__ __forceinline__ bf16x8 frag(uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
+  union { uint4 q; bf16x8 v; } f;
+  f.q = make_uint4(a, b, c, d);
+  return f.v;
+}
+
+template <int V>
+__global__ __launch_bounds__(NT) void conv3d_bwd_weight_x3_kernel(const float *__restrict__ in,
+                                                                  const float *__restrict__ dout,
+                                                                  float *__restrict__ slab, ConvShape s, int nbz, int nby,
+                                                                  int nbx, int co_tiles) {
+  __shared__ uint32_t lds[2 * BUF];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int dzi = wave % 3, half = wave / 3;
+  const int pair = blockIdx.y;
+  const int ci0 = (pair / co_tiles) * 32, co0 = (pair % co_tiles) * 32;
+  const int64_t bricks = (int64_t)s.B * nbz * nby * nbx;
+
+  float4 ia[IN_IT / 2][2], da[DO_IT / 2][2];  // one half of the next brick in flight at a time
+  int iok[IN_IT / 2], dok[DO_IT / 2];            // bit v: voxel v of the pair is inside the volume
+
+  auto load = [&](int64_t brick, int ph) {
+    int64_t q = brick;
+    const int bx = (int)(q % nbx); q /= nbx;
+    const int by = (int)(q % nby); q /= nby;
+    const int bz = (int)(q % nbz);
+    const int64_t b = q / nbz;
+    const int z0 = bz * BRZ, y0 = by * BRY, x0 = bx * BRX;
+    const float *inb = in + b * (int64_t)s.D * s.H * s.W * s.Ci;
+    const float *dob = dout + b * (int64_t)s.D * s.H * s.W * s.Co;
+#pragma unroll
+    for (int j = 0; j < IN_IT / 2; ++j) {
+      const int idx = t + NT * (ph * (IN_IT / 2) + j);
+      const int hrow = idx / 40, rem = idx % 40, pr = rem >> 3, cg = rem & 7;
+      const int gz = z0 + hrow / HLY - 1, gy = y0 + hrow % HLY - 1, gx = x0 + 2 * pr - 1;
+      // unconditional loads from clamped coordinates (a load inside a branch makes the compiler wait for it at the
+      // end of the branch, which serialises the whole prefetch); out-of-range voxels are zeroed in store()
+      const bool rowok = gz >= 0 && gz < s.D && gy >= 0 && gy < s.H && ci0 + cg * 4 < s.Ci;
+      const int cz = min(max(gz, 0), s.D - 1), cy = min(max(gy, 0), s.H - 1), cc = min(ci0 + cg * 4, s.Ci - 4);
+      const float *p = inb + ((int64_t)cz * s.H + cy) * s.W * s.Ci + cc;
+      ia[j][0] = *reinterpret_cast<const float4 *>(p + (int64_t)min(max(gx, 0), s.W - 1) * s.Ci);
+      ia[j][1] = *reinterpret_cast<const float4 *>(p + (int64_t)min(max(gx + 1, 0), s.W - 1) * s.Ci);
+      iok[j] = (rowok && gx >= 0 && gx < s.W ? 1 : 0) | (rowok && gx + 1 >= 0 && gx + 1 < s.W ? 2 : 0);
+    }
+#pragma unroll
+    for (int j = 0; j < DO_IT / 2; ++j) {
+      const int idx = t + NT * (ph * (DO_IT / 2) + j);
+      const int row = idx >> 5, pr = (idx & 31) >> 3, cg = idx & 7;
+      const int gz = z0 + (row >> 2), gy = y0 + (row & 3), gx = x0 + 2 * pr;
+      const bool rowok = gz < s.D && gy < s.H && co0 + cg * 4 < s.Co;
+      const int cz = min(gz, s.D - 1), cy = min(gy, s.H - 1), cc = min(co0 + cg * 4, s.Co - 4);
+      const float *p = dob + ((int64_t)cz * s.H + cy) * s.W * s.Co + cc;
+      da[j][0] = *reinterpret_cast<const float4 *>(p + (int64_t)min(gx, s.W - 1) * s.Co);
+      da[j][1] = *reinterpret_cast<const float4 *>(p + (int64_t)min(gx + 1, s.W - 1) * s.Co);
+      dok[j] = (rowok && gx < s.W ? 1 : 0) | (rowok && gx + 1 < s.W ? 2 : 0);
+    }
+  };
+
+  auto store = [&](uint32_t *buf, int ph) {
+#pragma unroll
+    for (int j = 0; j < IN_IT / 2; ++j) {
+      const int idx = t + NT * (ph * (IN_IT / 2) + j);
+      if (idx < IN_ITEMS) {
+        const int hrow = idx / 40, rem = idx % 40, pr = rem >> 3, cg = rem & 7;
+        uint32_t *d = buf + (cg * 4) * CIS + hrow * ROWDW + pr;
+        const float v0[4] = {ia[j][0].x, ia[j][0].y, ia[j][0].z, ia[j][0].w};
+        const float v1[4] = {ia[j][1].x, ia[j][1].y, ia[j][1].z, ia[j][1].w};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          uint32_t h, m;
+          split2((iok[j] & 1) ? v0[c] : 0.f, (iok[j] & 2) ? v1[c] : 0.f, h, m);
+          d[c * CIS] = h;
+          d[IN_PLANE + c * CIS] = m;
+        }
+      }
+    }
+    uint32_t *dbuf = buf + 2 * IN_PLANE;
+#pragma unroll
+    for (int j = 0; j < DO_IT / 2; ++j) {
+      const int idx = t + NT * (ph * (DO_IT / 2) + j);
+      if (idx < DO_ITEMS) {
+        const int row = idx >> 5, pr = (idx & 31) >> 3, cg = idx & 7;
+        uint32_t *d = dbuf + (cg * 4) * COS + row * 4 + pr;
+        const float v0[4] = {da[j][0].x, da[j][0].y, da[j][0].z, da[j][0].w};
+        const float v1[4] = {da[j][1].x, da[j][1].y, da[j][1].z, da[j][1].w};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          uint32_t h, m;
+          split2((dok[j] & 1) ? v0[c] : 0.f, (dok[j] & 2) ? v1[c] : 0.f, h, m);
+          d[c * COS] = h;
+          d[DO_PLANE + c * COS] = m;
+        }
+      }
+    }
+  };
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+  int64_t brick = blockIdx.x;
+  if (brick < bricks) {
+    load(brick, 0);
+    store(lds, 0);
+    load(brick, 1);
+    store(lds, 1);
+  }
+  __syncthreads();
+  int cur = 0;
+  for (; brick < bricks; brick += gridDim.x) {
+    const int64_t next = brick + gridDim.x;
+    const bool more = next < bricks;
+    if (more && V != 1) load(next, 0);
+    const uint32_t *ibuf = lds + cur * BUF, *dbuf = ibuf + 2 * IN_PLANE;
+#pragma unroll 1
+    for (int kq = 0; kq < 4; ++kq) {
+      const int r = 2 * (half * 4 + kq) + lh;  // x-row of the brick handled by this half-wave: r = vz*4 + vy
+      const int vz = r >> 2, vy = r & 3;
+      const uint4 bh = *reinterpret_cast<const uint4 *>(dbuf + l31 * COS + r * 4);
+      const uint4 bm = *reinterpret_cast<const uint4 *>(dbuf + DO_PLANE + l31 * COS + r * 4);
+      const bf16x8 b_hi = frag(bh.x, bh.y, bh.z, bh.w), b_mid = frag(bm.x, bm.y, bm.z, bm.w);
+#pragma unroll
+      for (int dyi = 0; dyi < 3; ++dyi) {
+        const uint32_t *ph = ibuf + l31 * CIS + ((vz + dzi) * HLY + vy + dyi) * ROWDW;
+        {  // mid plane of the input x hi plane of dout (small terms first)
+          const uint2 m01 = *reinterpret_cast<const uint2 *>(ph + IN_PLANE), m23 = *reinterpret_cast<const uint2 *>(ph + IN_PLANE + 2);
+          const uint32_t m4 = ph[IN_PLANE + 4];
+          acc[dyi * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(m01.x, m01.y, m23.x, m23.y), b_hi, acc[dyi * 3 + 0], 0, 0, 0);
+          acc[dyi * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+              frag(__builtin_amdgcn_alignbit(m01.y, m01.x, 16), __builtin_amdgcn_alignbit(m23.x, m01.y, 16),
+                   __builtin_amdgcn_alignbit(m23.y, m23.x, 16), __builtin_amdgcn_alignbit(m4, m23.y, 16)),
+              b_hi, acc[dyi * 3 + 1], 0, 0, 0);
+          acc[dyi * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(m01.y, m23.x, m23.y, m4), b_hi, acc[dyi * 3 + 2], 0, 0, 0);
+        }
+        {
+          const uint2 h01 = *reinterpret_cast<const uint2 *>(ph), h23 = *reinterpret_cast<const uint2 *>(ph + 2);
+          const uint32_t h4 = ph[4];
+          bf16x8 a = frag(h01.x, h01.y, h23.x, h23.y);
+          acc[dyi * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b_mid, acc[dyi * 3 + 0], 0, 0, 0);
+          acc[dyi * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b_hi, acc[dyi * 3 + 0], 0, 0, 0);
+          a = frag(__builtin_amdgcn_alignbit(h01.y, h01.x, 16), __builtin_amdgcn_alignbit(h23.x, h01.y, 16),
+                   __builtin_amdgcn_alignbit(h23.y, h23.x, 16), __builtin_amdgcn_alignbit(h4, h23.y, 16));
+          acc[dyi * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b_mid, acc[dyi * 3 + 1], 0, 0, 0);
+          acc[dyi * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b_hi, acc[dyi * 3 + 1], 0, 0, 0);
+          a = frag(h01.y, h23.x, h23.y, h4);
+          acc[dyi * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b_mid, acc[dyi * 3 + 2], 0, 0, 0);
+          acc[dyi * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b_hi, acc[dyi * 3 + 2], 0, 0, 0);
+        }
+      }
+      if (kq == 1 && more) {  // first half of the next brick has arrived: park it in the other buffer, fetch the rest
+        if (V != 3) store(lds + (cur ^ 1) * BUF, 0);
+        if (V != 1) load(next, 1);
+      }
+    }
+    if (more && V != 3) store(lds + (cur ^ 1) * BUF, 1);
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  // slab layout shared with conv3d.hip's reduce kernel: [part][tap][pair][32 ci][32 co]
+  const int pairs = gridDim.y;
+  const int64_t part = (int64_t)blockIdx.x * 2 + half;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) {
+    const int tap = dzi * 9 + i;
+    float *o = slab + ((part * 27 + tap) * pairs + pair) * 1024;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[((r & 3) + 8 * (r >> 2) + 4 * lh) * 32 + l31] = acc[i][r];
+  }
+}
+
+
+}
+#include <cstdio>
+template <int V> float run(const float *in, const float *dout, float *slab, ConvShape sh) {
+  int nbz = sh.D / 4, nby = sh.H / 4, nbx = sh.W / 8;
+  dim3 grid(256 / ((sh.Ci + 31) / 32 * (sh.Co / 32)), (sh.Ci + 31) / 32 * (sh.Co / 32));
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  hipLaunchKernelGGL(conv3d_bwd_weight_x3_kernel<V>, grid, dim3(NT), 0, 0, in, dout, slab, sh, nbz, nby, nbx, sh.Co / 32);
+  hipEventRecord(e0);
+  for (int i = 0; i < 5; ++i) hipLaunchKernelGGL(conv3d_bwd_weight_x3_kernel<V>, grid, dim3(NT), 0, 0, in, dout, slab, sh, nbz, nby, nbx, sh.Co / 32);
+  hipEventRecord(e1); hipEventSynchronize(e1);
+  float ms; hipEventElapsedTime(&ms, e0, e1); return ms / 5 * 1e3f;
+}
+int main() {
+  float *in, *dout, *slab;
+  size_t n = (size_t)8 * 64 * 64 * 64 * 32;
+  hipMalloc(&in, n * 4); hipMalloc(&dout, n * 4); hipMalloc(&slab, (size_t)512 * 27 * 16 * 1024 * 4);
+  hipMemset(in, 0, n * 4); hipMemset(dout, 0, n * 4);
+  for (int ci : {32, 16}) {
+    ConvShape sh{8, 64, 64, 64, ci, 32};
+    printf("Ci=%d: V0 %.1f us | V1 no global loads %.1f | V3 no LDS stores %.1f\n", ci, run<0>(in, dout, slab, sh), run<1>(in, dout, slab, sh), run<3>(in, dout, slab, sh));
+  }
+  ConvShape sh{8, 32, 32, 32, 64, 64};
+  printf("32^3 64->64: V0 %.1f us | V1 %.1f | V3 %.1f\n", run<0>(in, dout, slab, sh), run<1>(in, dout, slab, sh), run<3>(in, dout, slab, sh));
+  return 0;
+}

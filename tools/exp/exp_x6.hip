@@ -1,21 +1,5 @@
-// Forward GEMMs of the point MLP at f32 accuracy on the bf16 matrix cores ("bf16x6"), gfx950.
-//
-//   x = hi + mid + lo exactly to 2^-24 |x|   (three round-to-nearest bf16 terms carry 24 mantissa bits)
-//   a*b ~= a_hi b_hi + a_hi b_mid + a_mid b_hi + a_mid b_mid + a_hi b_lo + a_lo b_hi     (f32 accumulate)
-//
-// The dropped terms (a_mid b_lo, a_lo b_mid, a_lo b_lo) are <= 2^-24 |a b|, i.e. the same size as the rounding
-// of an f32 product: results agree with the exact-f32 MFMA path to ~2e-7 relative (tests: 2e-6 vs f64, the same
-// gate as the f32 kernel), so logits and ReLU masks keep f32 fidelity, at 6 bf16 MFMAs (6 x 32 cycles per
-// 32x32x16 block) instead of 8 f32 MFMAs (8 x 64 cycles).
-//
-//   Y[M,N] = epi( X[M,K] W[N,K]^T )     X split on the fly, W pre-split once per call into 3 planes.
-//
-// 128x128 tile, 4 waves x (2x2) v_mfma_f32_32x32x16_bf16 tiles, k-step 16, LDS planes [row][k] with a 40-byte
-// row stride (ds_read_b64 fragment reads conflict free), one 30 KB LDS stage (4 workgroups per CU).
 #include "common.h"
-
 using namespace svr;
-
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -64,6 +48,7 @@ __global__ void split_planes_kernel(const float *__restrict__ W, int64_t ldw, ui
   *reinterpret_cast<uint32_t *>(p2 + n * K + k) = l;
 }
 
+template <int V>
 __global__ __launch_bounds__(256, 3) void linear_nt_x6_kernel(const float *__restrict__ X, int64_t ldx,
                                                            const uint16_t *__restrict__ W0,
                                                            const uint16_t *__restrict__ W1,
@@ -128,21 +113,28 @@ __global__ __launch_bounds__(256, 3) void linear_nt_x6_kernel(const float *__res
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+  bf16x8 a[3][2], b[3][2];
   load(0);
   store(lds);
   __syncthreads();
   for (int64_t k0 = 0; k0 < K; k0 += YK) {
     const bool more = k0 + YK < K;
-    if (more) load(k0 + YK);
+    if (more && V != 1) load(k0 + YK);
     const uint32_t *pa = lds, *pb = pa + 3 * PLANE;
-    bf16x8 a[3][2], b[3][2];
 #pragma unroll
     for (int p = 0; p < 3; ++p)
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
+        if (V != 3 || k0 == 0) {
         a[p][i] = read_frag(pa + p * PLANE, wr * 64 + i * 32 + l31, lh);
-        b[p][i] = read_frag(pb + p * PLANE, wc * 64 + i * 32 + l31, lh);
+        b[p][i] = read_frag(pb + p * PLANE, wc * 64 + i * 32 + l31, lh); }
       }
+    if (V == 2) {
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) { acc[i][0][p] += (float)a[p][i][0]; acc[i][1][p] += (float)b[p][i][0]; }
+    } else
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -177,26 +169,30 @@ __global__ __launch_bounds__(256, 3) void linear_nt_x6_kernel(const float *__res
     }
 }
 
+
 }  // namespace
-
-extern "C" int64_t svr_linear_fwd_bf16x6_workspace(int64_t N, int64_t K) { return 3 * N * K * (int64_t)sizeof(uint16_t) + 256; }
-
-extern "C" int svr_linear_fwd_bf16x6(const float *X, int64_t ldx, const float *W, int64_t ldw, const float *bias, float *Y,
-                                     int64_t ldy, int64_t M, int64_t N, int64_t K, int epilogue, void *workspace,
-                                     void *stream) {
-  if (M == 0) return SVR_OK;  // empty point set
-  SVR_CHECK(X && W && Y && workspace, SVR_E_BADARG, "linear_fwd_bf16x6: null pointer");
-  SVR_CHECK(M >= 0 && N > 0 && K > 0 && K % YK == 0, SVR_E_BADSHAPE, "linear_fwd_bf16x6: M=%ld N=%ld K=%ld (K %% 16)", (long)M, (long)N, (long)K);
-  SVR_CHECK(ldx % 4 == 0 && ((uintptr_t)X & 15) == 0, SVR_E_ALIGN, "linear_fwd_bf16x6: X must be 16-byte aligned");
-  SVR_CHECK(epilogue == SVR_EPI_NONE || ((epilogue == SVR_EPI_BIAS || epilogue == SVR_EPI_BIAS_RELU) && bias), SVR_E_BADARG,
-            "linear_fwd_bf16x6: epilogue %d", epilogue);
-  if (M == 0) return SVR_OK;
-  hipStream_t s = (hipStream_t)stream;
-  uint16_t *p0 = (uint16_t *)(((uintptr_t)workspace + 15) & ~(uintptr_t)15);
-  uint16_t *p1 = p0 + N * K, *p2 = p1 + N * K;
-  hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)cdiv(N * (K / 2), 256)), dim3(256), 0, s, W, ldw, p0, p1, p2, N, K);
+#include <cstdio>
+#include <vector>
+template <int V> float run(const float *X, const uint16_t *p0, const uint16_t *p1, const uint16_t *p2, const float *bias, float *Y, int64_t M, int64_t N, int64_t K) {
   dim3 grid((unsigned)cdiv(N, TN), (unsigned)cdiv(M, TM));
-  hipLaunchKernelGGL(linear_nt_x6_kernel, grid, dim3(256), 0, s, X, ldx, p0, p1, p2,
-                     epilogue == SVR_EPI_NONE ? nullptr : bias, Y, ldy, M, N, K, epilogue == SVR_EPI_BIAS_RELU ? 1 : 0);
-  return launch_status("linear_fwd_bf16x6");
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  hipLaunchKernelGGL(linear_nt_x6_kernel<V>, grid, dim3(256), 0, 0, X, K, p0, p1, p2, bias, Y, N, M, N, K, 1);
+  hipEventRecord(e0);
+  for (int i = 0; i < 5; ++i) hipLaunchKernelGGL(linear_nt_x6_kernel<V>, grid, dim3(256), 0, 0, X, K, p0, p1, p2, bias, Y, N, M, N, K, 1);
+  hipEventRecord(e1); hipEventSynchronize(e1);
+  float ms; hipEventElapsedTime(&ms, e0, e1); return ms / 5;
+}
+int main() {
+  const int64_t M = 400000, N = 256, K = 2592;
+  float *X, *W, *Y, *bias; uint16_t *p;
+  hipMalloc(&X, M * K * 4); hipMalloc(&W, N * K * 4); hipMalloc(&Y, M * N * 4); hipMalloc(&bias, N * 4); hipMalloc(&p, 3 * N * K * 2);
+  std::vector<float> h(N * K); for (auto &v : h) v = (rand() % 2001 - 1000) * 1e-4f;
+  hipMemcpy(W, h.data(), N * K * 4, hipMemcpyHostToDevice); hipMemset(bias, 0, N * 4);
+  for (int64_t off = 0; off < M * K; off += N * K) hipMemcpy(X + off, h.data(), std::min<int64_t>(N * K, M * K - off) * 4, hipMemcpyHostToDevice);
+  hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)cdiv(N * (K / 2), 256)), dim3(256), 0, 0, W, K, p, p + N * K, p + 2 * N * K, N, K);
+  printf("V0 baseline        %.3f ms\n", run<0>(X, p, p + N * K, p + 2 * N * K, bias, Y, M, N, K));
+  printf("V1 no global loads %.3f ms\n", run<1>(X, p, p + N * K, p + 2 * N * K, bias, Y, M, N, K));
+  printf("V2 no MFMA         %.3f ms\n", run<2>(X, p, p + N * K, p + 2 * N * K, bias, Y, M, N, K));
+  printf("V3 no frag reads   %.3f ms\n", run<3>(X, p, p + N * K, p + 2 * N * K, bias, Y, M, N, K));
+  return 0;
 }
