@@ -139,7 +139,8 @@ __global__ __launch_bounds__(256) void conv3d_to1_kernel(const float *__restrict
   out[m] = acc;
 }
 
-constexpr int BW_ROWS = 256;  // (b,z,y) rows per workgroup of the Ci == 1 weight-gradient kernel
+constexpr int BW_ROWS = 64;   // (b,z,y) rows per workgroup of the Ci == 1 weight-gradient kernel: 2048 workgroups at
+                              // 128^3 x 8 (with 256 rows the grid was 2 workgroups per CU and the kernel latency bound)
 
 // ---- backward-weight, brick version (production): a workgroup walks 4x4x8-voxel bricks of the output.
 // Per brick it stages the 32-channel slice of the input WITH its one-voxel halo (6x6x10 voxels) and the
@@ -393,25 +394,103 @@ __global__ __launch_bounds__(256) void conv3d_c1_bwd_weight_kernel(const float *
     int zz = z + dz, yy = y + dy;
     bool rok = tap_ok && zz >= 0 && zz < s.D && yy >= 0 && yy < s.H;
     const float *arow = in + ((b * s.D + (rok ? zz : 0)) * s.H + (rok ? yy : 0)) * (int64_t)s.W;
-    const float *brow = dout + row * (int64_t)s.W * s.Co + l31;
-    for (int x0 = 0; x0 < s.W; x0 += 8) {
-      float av[4], bv[4];
+    const float *brow = dout + row * (int64_t)s.W * s.Co + (co_ok ? l31 : 0);
+    for (int x0 = 0; x0 < s.W; x0 += 16) {  // 16 loads in flight per lane, then 8 MFMAs
+      float av[8], bv[8];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        int x = x0 + 2 * u + lh, xs = x + dx;
-        av[u] = (rok && x < s.W && xs >= 0 && xs < s.W) ? arow[xs] : 0.f;
-        bv[u] = (co_ok && x < s.W) ? brow[(int64_t)x * s.Co] : 0.f;
+      for (int u = 0; u < 8; ++u) {
+        const int x = x0 + 2 * u + lh, xs = x + dx;
+        const bool aok = rok && x < s.W && xs >= 0 && xs < s.W, bok = co_ok && x < s.W;
+        const float a = arow[aok ? xs : 0], bq = brow[bok ? (int64_t)x * s.Co : 0];  // unconditional, clamped
+        av[u] = aok ? a : 0.f;
+        bv[u] = bok ? bq : 0.f;
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u], acc, 0, 0, 0);
+      for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u], acc, 0, 0, 0);
     }
   }
-  float *o = slab + ((int64_t)chunk * 4 + wave) * 1024;  // [tap 32][co 32]
+  // the four waves' tiles are summed in a fixed order through LDS: one [tap 32][co 32] slab per workgroup
+  __shared__ float red[4 * 1024];
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     int i = (r & 3) + 8 * (r >> 2) + 4 * lh;
-    o[i * 32 + l31] = acc[r];
+    red[wave * 1024 + i * 32 + l31] = acc[r];
   }
+  __syncthreads();
+  float *o = slab + (int64_t)chunk * 1024;
+  for (int e = threadIdx.x; e < 1024; e += 256) o[e] = ((red[e] + red[1024 + e]) + red[2048 + e]) + red[3072 + e];
+}
+
+// ---- Ci == 1, Co == 16 (conv_in): v_mfma_f32_16x16x4f32 with k = 4 consecutive voxels.  The B operand
+// (lane: co = lane & 15, voxel = lane >> 4) is then one fully coalesced 256-byte load of dout per instruction;
+// the 27 taps are two 16-row A tiles.  Same slab layout as the generic kernel.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void conv3d_c1_bwd_weight_co16_kernel(const float *__restrict__ in,
+                                                                        const float *__restrict__ dout,
+                                                                        float *__restrict__ slab, ConvShape s) {
+  __shared__ float red[4 * 1024];
+  const int chunk = blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l15 = lane & 15, kq = lane >> 4;
+  for (int e = threadIdx.x; e < 4096; e += 256) red[e] = 0.f;
+  int dz[2], dy[2], dx[2];
+  bool tok[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int tap = 16 * h + l15;
+    dz[h] = tap / 9 - 1; dy[h] = (tap / 3) % 3 - 1; dx[h] = tap % 3 - 1;
+    tok[h] = tap < 27;
+  }
+  const int64_t nrows = (int64_t)s.B * s.D * s.H;
+  const int64_t r0 = (int64_t)chunk * BW_ROWS;
+  f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  for (int64_t row = r0 + wave; row < r0 + BW_ROWS && row < nrows; row += 4) {
+    const int y = (int)(row % s.H);
+    const int64_t t = row / s.H;
+    const int z = (int)(t % s.D);
+    const int64_t b = t / s.D;
+    // wave-uniform bases + 32-bit lane offsets (scalar-base addressing, no 64-bit lane arithmetic in the loop)
+    const float *inb = in + b * (int64_t)s.D * s.H * s.W;
+    const float *dob = dout + row * (int64_t)s.W * 16;
+    int aoff[2];
+    bool rok[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int zz = z + dz[h], yy = y + dy[h];
+      rok[h] = tok[h] && zz >= 0 && zz < s.D && yy >= 0 && yy < s.H;
+      aoff[h] = rok[h] ? (zz * s.H + yy) * s.W : 0;
+    }
+    for (int x0 = 0; x0 < s.W; x0 += 32) {  // 8 groups of 4 voxels: 24 loads in flight, then 16 MFMAs
+      float av[2][8], bv[8];
+      const bool full = x0 + 32 <= s.W;  // wave-uniform
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int x = x0 + 4 * u + kq;
+        const bool bok = full || x < s.W;
+        const float bq = dob[(bok ? x : 0) * 16 + l15];
+        bv[u] = bok ? bq : 0.f;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int xs = x + dx[h], xc = min(max(xs, 0), s.W - 1);
+          const float a = inb[aoff[h] + xc];
+          av[h][u] = (rok[h] && xs == xc && bok) ? a : 0.f;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0][u], bv[u], acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1][u], bv[u], acc[1], 0, 0, 0);
+      }
+    }
+  }
+  __syncthreads();  // red is zeroed
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[wave * 1024 + (16 * h + 4 * kq + r) * 32 + l15] = acc[h][r];
+  __syncthreads();
+  float *o = slab + (int64_t)chunk * 1024;
+  for (int e = threadIdx.x; e < 1024; e += 256) o[e] = ((red[e] + red[1024 + e]) + red[2048 + e]) + red[3072 + e];
 }
 
 // one workgroup per (tap, co): f64 tree over the per-wave partial slabs (fixed order)
@@ -521,7 +600,7 @@ extern "C" int64_t svr_conv3d_k3_bwd_weight_workspace(int32_t B, int32_t D, int3
   int64_t chunks = cdiv(nrows, BW_ROWS);
   int64_t M = nrows * W;
   int64_t cs = colsum_workspace_floats(M, Co);
-  if (Ci == 1) return (chunks * 4 * 1024 + cs) * (int64_t)sizeof(float);
+  if (Ci == 1) return (chunks * 1024 + cs) * (int64_t)sizeof(float);
   int64_t tiles = cdiv(Ci, 32) * cdiv(Co, 32);
   return ((int64_t)bw_brick_parts(B, D, H, W, Ci, Co) * 27 * tiles * 1024 + cs) * (int64_t)sizeof(float);
 }
@@ -538,9 +617,12 @@ extern "C" int svr_conv3d_k3_bwd_weight(const float *in, const float *dout, floa
   int64_t slab_floats;
   if (Ci == 1) {
     SVR_CHECK(Co <= 32, SVR_E_UNSUPPORTED, "conv3d_bwd_weight: Ci=1 needs Co<=32 (got %d)", Co);
-    hipLaunchKernelGGL(conv3d_c1_bwd_weight_kernel, dim3(chunks), dim3(256), 0, s, in, dout, slab, sh);
-    hipLaunchKernelGGL(conv3d_c1_bwd_weight_reduce_kernel, dim3(27 * Co), dim3(256), 0, s, slab, dWp, Co, chunks * 4);
-    slab_floats = (int64_t)chunks * 4 * 1024;
+    if (Co == 16)
+      hipLaunchKernelGGL(conv3d_c1_bwd_weight_co16_kernel, dim3(chunks), dim3(256), 0, s, in, dout, slab, sh);
+    else
+      hipLaunchKernelGGL(conv3d_c1_bwd_weight_kernel, dim3(chunks), dim3(256), 0, s, in, dout, slab, sh);
+    hipLaunchKernelGGL(conv3d_c1_bwd_weight_reduce_kernel, dim3(27 * Co), dim3(256), 0, s, slab, dWp, Co, chunks);
+    slab_floats = (int64_t)chunks * 1024;
   } else {
     SVR_CHECK(Ci % 4 == 0 && Co % 4 == 0, SVR_E_UNSUPPORTED, "conv3d_bwd_weight: need Ci, Co %% 4 == 0 (Ci=%d Co=%d)", Ci, Co);
     int cit = (int)cdiv(Ci, 32), cot = (int)cdiv(Co, 32);

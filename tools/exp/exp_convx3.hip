@@ -88,7 +88,7 @@ __global__ void pack_fwd_planes_kernel(const float *__restrict__ W, uint16_t *__
 // out(B,D,H,W,NOUT) = epi( sum_{tap,k} in[voxel+tap][k] * P[tap][n][k] ), K = s.Ci input channels of THIS call,
 // NOUT = s.Co.  planes: hi then mid, each [27][NOUT][K] bf16.
 // NP = 2: products mid*hi + hi*mid + hi*hi (bf16x3);  NP = 3: the six products of bf16x6.
-template <int CK, int TNB, int NP>
+template <int CK, int TNB, int NP, int V>
 __global__ __launch_bounds__(256) void conv3d_brick_x3_kernel(const float *__restrict__ in,
                                                               const uint16_t *__restrict__ P0,
                                                               int64_t plane_stride, const float *__restrict__ bias,
@@ -130,6 +130,7 @@ __global__ __launch_bounds__(256) void conv3d_brick_x3_kernel(const float *__res
       const bool ok = idx < PIECES && n0 + row < s.Co;
       const uint16_t *base = P0 + (ok ? pl : 0) * plane_stride;
       const uint2 *p = reinterpret_cast<const uint2 *>(base + ((size_t)(tap0 + (ok ? tg : 0)) * s.Co + (ok ? n0 + row : 0)) * s.Ci + k0 + part * 8);
+      if (V == 2) { wreg[i][0] = make_uint2(idx, 1); wreg[i][1] = make_uint2(2, 3); continue; }
       wreg[i][0] = p[0];  // unconditional (clamped to piece 0 when out of range: those columns are never stored)
       wreg[i][1] = p[1];
     }
@@ -165,7 +166,7 @@ __global__ __launch_bounds__(256) void conv3d_brick_x3_kernel(const float *__res
       const int gz = z0 + hz - 1, gy = y0 + hy - 1, gx = x0 + hx - 1;
       if (gz >= 0 && gz < s.D && gy >= 0 && gy < s.H && gx >= 0 && gx < s.W) hok |= 1u << i;
       const int cz = min(max(gz, 0), s.D - 1), cy = min(max(gy, 0), s.H - 1), cx = min(max(gx, 0), s.W - 1);
-      hreg[i] = *reinterpret_cast<const float4 *>(inb + (((int64_t)cz * s.H + cy) * s.W + cx) * s.Ci + k0 + c4);
+      if (V == 1) hreg[i] = make_float4(1.f, 2.f, 3.f, 4.f); else hreg[i] = *reinterpret_cast<const float4 *>(inb + (((int64_t)cz * s.H + cy) * s.W + cx) * s.Ci + k0 + c4);
     }
 #pragma unroll
     for (int i = 0; i < HIT; ++i) {
@@ -208,13 +209,13 @@ __global__ __launch_bounds__(256) void conv3d_brick_x3_kernel(const float *__res
             if constexpr (NP == 3) {
               const bf16x8 al = read_frag(&sh[NP - 1][arow * XW + kw]);
               const bf16x8 bl = read_frag(&sw[buf][tg][NP - 1][(j * 32 + l31) * XW + kw]);
-              acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[j], 0, 0, 0);
-              acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[j], 0, 0, 0);
-              acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc[j], 0, 0, 0);
+              if (V == 3) { acc[j][0] += (float)al[0] + (float)bh[0]; } else acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[j], 0, 0, 0);
+              if (V == 3) { acc[j][0] += (float)ah[0] + (float)bl[0]; } else acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[j], 0, 0, 0);
+              if (V == 3) { acc[j][0] += (float)am[0] + (float)bm[0]; } else acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc[j], 0, 0, 0);
             }
-            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc[j], 0, 0, 0);
-            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc[j], 0, 0, 0);
-            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[j], 0, 0, 0);
+            if (V == 3) { acc[j][0] += (float)am[0] + (float)bh[0]; } else acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc[j], 0, 0, 0);
+            if (V == 3) { acc[j][0] += (float)ah[0] + (float)bm[0]; } else acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc[j], 0, 0, 0);
+            if (V == 3) { acc[j][0] += (float)ah[0] + (float)bh[0]; } else acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[j], 0, 0, 0);
           }
         }
       }
@@ -258,61 +259,29 @@ __global__ __launch_bounds__(256) void conv3d_brick_x3_kernel(const float *__res
   }
 }
 
-}  // namespace
 
-extern "C" int64_t svr_conv3d_bwd_data_bf16x3_workspace(int32_t Ci, int32_t Co) { return 2LL * 27 * Ci * Co * (int64_t)sizeof(uint16_t) + 256; }
-
-// dIn(B,D,H,W,Ci) = epi( conv^T(dOut(B,D,H,W,Co), W(Co,Ci,3,3,3)) ), epilogue NONE or MASK (mask shaped like dIn).
-extern "C" int svr_conv3d_k3_bwd_data_bf16x3(const float *dout, const float *W, float *din, int32_t B, int32_t D, int32_t H,
-                                             int32_t Wd, int32_t Ci, int32_t Co, int epilogue, const float *mask,
-                                             void *workspace, void *stream) {
-  SVR_CHECK(dout && W && din && workspace, SVR_E_BADARG, "conv3d_bwd_data_bf16x3: null pointer");
-  SVR_CHECK(B > 0 && D > 0 && H > 0 && Wd > 0, SVR_E_BADSHAPE, "conv3d_bwd_data_bf16x3: empty volume");
-  SVR_CHECK(Co % 16 == 0 && Ci % 2 == 0 && Ci >= 2, SVR_E_UNSUPPORTED, "conv3d_bwd_data_bf16x3: need Co %% 16 == 0, Ci even (Ci=%d Co=%d)", Ci, Co);
-  SVR_CHECK(epilogue == SVR_EPI_NONE || (epilogue == SVR_EPI_MASK && mask), SVR_E_BADARG, "conv3d_bwd_data_bf16x3: epilogue %d", epilogue);
-  hipStream_t s = (hipStream_t)stream;
-  uint16_t *hi = (uint16_t *)(((uintptr_t)workspace + 15) & ~(uintptr_t)15);
-  uint16_t *mid = hi + (size_t)27 * Ci * Co;
-  // the transposed conv reads dOut (Co channels = its K) and writes Ci channels: planes [27][Ci][Co]
-  hipLaunchKernelGGL(pack_bwd_planes_kernel, dim3(cdiv(27 * Ci * (Co / 2), 256)), dim3(256), 0, s, W, hi, mid, Ci, Co);
-  ConvShape sh{B, D, H, Wd, /*K=*/Co, /*NOUT=*/Ci};
-  const int nbz = (int)cdiv(D, BRZ), nby = (int)cdiv(H, BRY), nbx = (int)cdiv(Wd, BRX);
-  const unsigned bricks = (unsigned)((int64_t)B * nbz * nby * nbx);
-#define LAUNCH_X3(CKV, TNV)                                                                                               \
-  hipLaunchKernelGGL((conv3d_brick_x3_kernel<CKV, TNV, 2>), dim3(bricks, (unsigned)cdiv(Ci, TNV * 32)), dim3(256), 0, s, dout, \
-                     hi, (int64_t)27 * Ci * Co, (const float *)nullptr, din, mask, sh, nbz, nby, nbx, epilogue)
-  const int tn = Ci <= 32 ? 1 : (Ci <= 64 ? 2 : 4);
-  if (Co % 32 == 0) {
-    if (tn == 1) LAUNCH_X3(32, 1); else if (tn == 2) LAUNCH_X3(32, 2); else LAUNCH_X3(32, 4);
-  } else {
-    if (tn == 1) LAUNCH_X3(16, 1); else if (tn == 2) LAUNCH_X3(16, 2); else LAUNCH_X3(16, 4);
-  }
-#undef LAUNCH_X3
-  return launch_status("conv3d_bwd_data_bf16x3");
 }
-
-extern "C" int64_t svr_conv3d_fwd_bf16x6_workspace(int32_t Ci, int32_t Co) { return 3LL * 27 * Ci * Co * (int64_t)sizeof(uint16_t) + 256; }
-
-// out(B,D,H,W,Co) = epi( conv(in(B,D,H,W,Ci), W(Co,Ci,3,3,3)) ) at f32 accuracy; epilogue NONE / BIAS / BIAS_RELU.
-extern "C" int svr_conv3d_k3_fwd_bf16x6(const float *in, const float *W, const float *bias, float *out, int32_t B, int32_t D,
-                                        int32_t H, int32_t Wd, int32_t Ci, int32_t Co, int epilogue, void *workspace,
-                                        void *stream) {
-  SVR_CHECK(in && W && out && workspace, SVR_E_BADARG, "conv3d_fwd_bf16x6: null pointer");
-  SVR_CHECK(B > 0 && D > 0 && H > 0 && Wd > 0, SVR_E_BADSHAPE, "conv3d_fwd_bf16x6: empty volume");
-  SVR_CHECK(Ci % 16 == 0 && Co >= 1, SVR_E_UNSUPPORTED, "conv3d_fwd_bf16x6: need Ci %% 16 == 0 (Ci=%d Co=%d)", Ci, Co);
-  SVR_CHECK(epilogue == SVR_EPI_NONE || ((epilogue == SVR_EPI_BIAS || epilogue == SVR_EPI_BIAS_RELU) && bias), SVR_E_BADARG,
-            "conv3d_fwd_bf16x6: epilogue %d", epilogue);
-  hipStream_t s = (hipStream_t)stream;
-  uint16_t *p0 = (uint16_t *)(((uintptr_t)workspace + 15) & ~(uintptr_t)15);
-  const int64_t ps = (int64_t)27 * Ci * Co;
-  hipLaunchKernelGGL(pack_fwd_planes_kernel, dim3(cdiv(27 * Co * (Ci / 2), 256)), dim3(256), 0, s, W, p0, p0 + ps, p0 + 2 * ps, Ci, Co);
-  ConvShape sh{B, D, H, Wd, Ci, Co};
-  const int nbz = (int)cdiv(D, BRZ), nby = (int)cdiv(H, BRY), nbx = (int)cdiv(Wd, BRX);
-  const unsigned bricks = (unsigned)((int64_t)B * nbz * nby * nbx);
-#define LAUNCH_X6(TNV)                                                                                                    \
-  hipLaunchKernelGGL((conv3d_brick_x3_kernel<16, TNV, 3>), dim3(bricks, (unsigned)cdiv(Co, TNV * 32)), dim3(256), 0, s, in, p0, \
-                     ps, bias, out, (const float *)nullptr, sh, nbz, nby, nbx, epilogue)
-  if (Co <= 32) LAUNCH_X6(1); else if (Co <= 64) LAUNCH_X6(2); else LAUNCH_X6(4);
-#undef LAUNCH_X6
-  return launch_status("conv3d_fwd_bf16x6");
+#include <cstdio>
+template <int CK, int TNB, int NP, int V> float run(const float *in, const uint16_t *P, float *out, ConvShape sh) {
+  int nbz = sh.D / 4, nby = sh.H / 4, nbx = sh.W / 8;
+  dim3 grid(sh.B * nbz * nby * nbx, (sh.Co + TNB * 32 - 1) / (TNB * 32));
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  auto go = [&]() { hipLaunchKernelGGL((conv3d_brick_x3_kernel<CK, TNB, NP, V>), grid, dim3(256), 0, 0, in, P, (int64_t)27 * sh.Ci * sh.Co, (const float *)nullptr, out, (const float *)nullptr, sh, nbz, nby, nbx, 0); };
+  go();
+  hipEventRecord(e0);
+  for (int i = 0; i < 5; ++i) go();
+  hipEventRecord(e1); hipEventSynchronize(e1);
+  float ms; hipEventElapsedTime(&ms, e0, e1); return ms / 5 * 1e3f;
+}
+int main() {
+  float *in, *out; uint16_t *P;
+  size_t n = (size_t)8 * 64 * 64 * 64 * 32;
+  hipMalloc(&in, n * 4); hipMalloc(&out, n * 4); hipMalloc(&P, (size_t)3 * 27 * 128 * 128 * 2);
+  hipMemset(in, 0, n * 4); hipMemset(P, 0, (size_t)3 * 27 * 128 * 128 * 2);
+  ConvShape sh{8, 64, 64, 64, 32, 32};
+  printf("fwd x6 <16,1,3> 64^3 32->32: V0 %.1f us | V1 no halo loads %.1f | V2 no weight loads %.1f | V3 no MFMA %.1f\n", run<16,1,3,0>(in, P, out, sh), run<16,1,3,1>(in, P, out, sh), run<16,1,3,2>(in, P, out, sh), run<16,1,3,3>(in, P, out, sh));
+  printf("bwd x3 <32,1,2> 64^3 32->32: V0 %.1f us | V1 no halo loads %.1f | V2 no weight loads %.1f | V3 no MFMA %.1f\n", run<32,1,2,0>(in, P, out, sh), run<32,1,2,1>(in, P, out, sh), run<32,1,2,2>(in, P, out, sh), run<32,1,2,3>(in, P, out, sh));
+  ConvShape s2{8, 32, 32, 32, 64, 64};
+  printf("fwd x6 <16,2,3> 32^3 64->64: V0 %.1f us | V1 %.1f | V2 %.1f | V3 %.1f\n", run<16,2,3,0>(in, P, out, s2), run<16,2,3,1>(in, P, out, s2), run<16,2,3,2>(in, P, out, s2), run<16,2,3,3>(in, P, out, s2));
+  return 0;
 }
