@@ -120,6 +120,14 @@ int64_t svr_linear_fwd_bf16x6_workspace(int64_t N, int64_t K);
 int svr_linear_fwd_bf16x6(const float *X, int64_t ldx, const float *W, int64_t ldw, const float *bias,
                           float *Y, int64_t ldy, int64_t M, int64_t N, int64_t K, int epilogue,
                           void *workspace, void *stream);
+/* Same result with the 3-product f16 split (x = hi + lo in f16: 22 mantissa bits; W normalised by a power of two,
+ * lo terms kept normal by exact 2^11 scaling, see gemm_f16x3.hip): as accurate as an f32 GEMM (~3e-7 of f64) at
+ * half the matrix-core work of bf16x6.  Domain: |X| < 65504 (f16 range).
+ * workspace: svr_linear_fwd_f16x3_workspace(N, K) bytes.                                                  */
+int64_t svr_linear_fwd_f16x3_workspace(int64_t N, int64_t K);
+int svr_linear_fwd_f16x3(const float *X, int64_t ldx, const float *W, int64_t ldw, const float *bias,
+                          float *Y, int64_t ldy, int64_t M, int64_t N, int64_t K, int epilogue,
+                          void *workspace, void *stream);
 
 /* The same two backward products on the bf16 matrix cores with a 3-term split (x = hi + mid, products
  * hi*hi + hi*mid + mid*hi, f32 accumulation): ~1.5e-5 relative error per product, ~5x fewer matrix-core

@@ -41,6 +41,8 @@ SIGNATURES = {
     "svr_linear_bwd_weight": (C.c_int, [P, I64, P, I64, P, I64, P, I64, I64, I64, P, P]),
     "svr_linear_fwd_bf16x6_workspace": (I64, [I64, I64]),
     "svr_linear_fwd_bf16x6": (C.c_int, [P, I64, P, I64, P, P, I64, I64, I64, I64, C.c_int, P, P]),
+    "svr_linear_fwd_f16x3_workspace": (I64, [I64, I64]),
+    "svr_linear_fwd_f16x3": (C.c_int, [P, I64, P, I64, P, P, I64, I64, I64, I64, C.c_int, P, P]),
     "svr_linear_bwd_data_bf16x3_workspace": (I64, [I64, I64]),
     "svr_linear_bwd_data_bf16x3": (C.c_int, [P, I64, P, I64, P, I64, I64, I64, I64, C.c_int, P, I64, P, P]),
     "svr_linear_bwd_weight_bf16x3_workspace": (I64, [I64, I64, I64]),

@@ -19,6 +19,7 @@ SOURCES = {
     "gemm.hip": [],
     "gemm_bf16x3.hip": [],
     "gemm_bf16x6.hip": [],
+    "gemm_f16x3.hip": [],
     "conv3d.hip": [],
     "conv3d_bf16.hip": [],
     "conv3d_bwdw_bf16.hip": [],

@@ -1,0 +1,279 @@
+// Forward GEMMs of the point MLP at f32 accuracy on the f16 matrix cores ("f16x3"), gfx950.
+//
+// An f32 value splits into two f16 terms that carry 22 mantissa bits:  x = hi + lo,  hi = rn16(x),
+// lo = rn16(x - hi),  |x - hi - lo| <= 2^-22 |x|.  With f32 accumulation
+//   x*w ~= hi(x) hi(w) + hi(x) lo(w) + lo(x) hi(w)                       (the dropped lo*lo is <= 2^-22 |x w|)
+// is as accurate as a plain f32 GEMM (measured: 3e-7 of the f64 result, the same as an f32 FMA chain and within
+// the gates the exact-f32 MFMA kernel is held to) at 3 f16 MFMAs (3 x 32 cycles per 32x32x16 block) instead of
+// the 6 of the bf16 split (gemm_bf16x6.hip) or 8 x 64 cycles of f32 MFMAs.
+//
+// f16 has 5 exponent bits, so the lo terms would be subnormal (and lose bits) for |x| < 0.125.  Both are kept
+// in the normal range by exact power-of-two scaling, without a second accumulator:
+//   * W is normalised once per call: Ws = W * 2^s with amax(Ws) in [2^13, 2^14); planes wh = rn16(Ws),
+//     wl = rn16(Ws - wh) and wq = wh * 2^-11 (exact; normal for every weight above 7.6e-6 of the largest);
+//   * X is split on the fly into xh = rn16(x) and xl' = rn16((x - xh) * 2^11)   (normal whenever xh is);
+//   * acc += xh wh + xh wl + xl' wq   (xl' wq == xl wh exactly), and the epilogue multiplies by 2^-s.
+// Domain: |x| < 65504 (f16 range; beyond that the result is inf/nan, not silently wrong).  |x| < 6e-5 keeps an
+// absolute error of 1.5e-11.  "bf16x6" (any f32 range) and "f32" stay selectable.
+//
+//   Y[M,N] = epi( X[M,K] W[N,K]^T )    128x256 tile, 8 waves x (2x2) v_mfma_f32_32x32x16_f16 tiles, k-step 16.
+// The kernel is bound by bytes through L2 (X streamed from HBM, W re-read by every workgroup), not by the matrix
+// cores: the tile spans N = 256 so X is read once, only wh and wl travel (wq is one v_pk_mul_f16 per fragment
+// register), and X is prefetched two k-steps ahead.
+#include "common.h"
+#include <algorithm>
+#include <cstdlib>
+
+using namespace svr;
+
+namespace {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int YK = 16;   // reduction elements per step
+constexpr int YLW = 10;  // dwords per LDS row (16 halves + 8 B pad: ds_read_b64 fragment reads conflict free)
+constexpr int TM = 128;
+constexpr int APLANE = TM * YLW;  // dwords per X plane
+
+__device__ __forceinline__ uint32_t pack_f16(float a, float b) {
+  f32x2 v = {a, b};
+  f16x2 h = __builtin_convertvector(v, f16x2);  // round to nearest even
+  return __builtin_bit_cast(uint32_t, h);
+}
+__device__ __forceinline__ f32x2 unpack_f16(uint32_t p) {
+  return __builtin_convertvector(__builtin_bit_cast(f16x2, p), f32x2);
+}
+
+// (x0, x1) -> packed hi pair, packed (lo * 2^11) pair
+__device__ __forceinline__ void split_x(float x0, float x1, uint32_t &hi, uint32_t &lo) {
+  hi = pack_f16(x0, x1);
+  const f32x2 h = unpack_f16(hi);
+  lo = pack_f16((x0 - h.x) * 2048.f, (x1 - h.y) * 2048.f);
+}
+
+__device__ __forceinline__ f16x8 read_frag(const uint32_t *plane, int row, int lh) {
+  const uint2 a = *reinterpret_cast<const uint2 *>(plane + row * YLW + lh * 4);
+  const uint2 b = *reinterpret_cast<const uint2 *>(plane + row * YLW + lh * 4 + 2);
+  union { uint4 q; f16x8 v; } f;
+  f.q = make_uint4(a.x, a.y, b.x, b.y);
+  return f.v;
+}
+
+// amax[0] = bit pattern of max |W| (non-negative floats order like unsigned integers); zeroed by the host first
+__global__ __launch_bounds__(256) void w_amax_kernel(const float *__restrict__ W, int64_t ldw, int64_t N, int64_t K,
+                                                     uint32_t *__restrict__ amax) {
+  __shared__ float red[256];
+  float m = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < N * K; i += (int64_t)gridDim.x * 256)
+    m = fmaxf(m, fabsf(W[(i / K) * ldw + i % K]));
+  red[threadIdx.x] = m;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + o]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) atomicMax(amax, __float_as_uint(red[0]));
+}
+
+// 2^s (or 2^-s) with amax * 2^s in [2^13, 2^14); s = 0 for an all-zero or non-finite W
+__device__ __forceinline__ float w_scale(uint32_t amax_bits, bool inverse) {
+  const float amax = __uint_as_float(amax_bits);
+  int e = 0;
+  if (amax > 0.f && amax < 3.0e38f) {
+    frexpf(amax, &e);  // amax = f * 2^e, f in [0.5, 1)
+    e = 14 - e;
+    e = e > 100 ? 100 : (e < -100 ? -100 : e);
+  }
+  return ldexpf(1.f, inverse ? -e : e);
+}
+
+// W[N][K] f32 -> planes [N][K] f16: hi(Ws), lo(Ws)
+__global__ void split_w_kernel(const float *__restrict__ W, int64_t ldw, const uint32_t *__restrict__ amax,
+                               uint16_t *__restrict__ p0, uint16_t *__restrict__ p1, int64_t N, int64_t K) {
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // over (n, k/2)
+  if (idx >= N * (K / 2)) return;
+  const int64_t n = idx / (K / 2), k = (idx % (K / 2)) * 2;
+  const float sc = w_scale(amax[0], false);
+  const float w0 = W[n * ldw + k] * sc, w1 = W[n * ldw + k + 1] * sc;
+  const uint32_t hi = pack_f16(w0, w1);
+  const f32x2 h = unpack_f16(hi);
+  *reinterpret_cast<uint32_t *>(p0 + n * K + k) = hi;
+  *reinterpret_cast<uint32_t *>(p1 + n * K + k) = pack_f16(w0 - h.x, w1 - h.y);
+}
+
+__device__ __forceinline__ f16x8 scale_2m11(f16x8 v) {  // exact: every normal hi(Ws) stays normal (see header)
+  return v * (_Float16)(1.f / 2048.f);
+}
+
+// TN = 128: 4 waves, three workgroups per CU (the k-step is a latency chain global -> split -> LDS -> MFMA; more
+// resident workgroups hide it better than the wider tile, which reads X once but runs one workgroup per CU)
+template <int TN, int NX>
+__global__ __launch_bounds__(2 * TN, 1024 / (2 * TN) >= 4 ? 3 : 2) void linear_nt_h3_kernel(
+    const float *__restrict__ X, int64_t ldx, const uint16_t *__restrict__ W0, const uint16_t *__restrict__ W1,
+    const uint32_t *__restrict__ amax, const float *__restrict__ bias, float *__restrict__ Y, int64_t ldy, int64_t M,
+    int64_t N, int64_t K, int relu) {
+  constexpr int NT = 2 * TN, BPLANE = TN * YLW, XPT = 512 / NT;
+  __shared__ uint32_t lds[2 * APLANE + 2 * BPLANE];  // one stage (hi/lo planes of X and W), two barriers per k-step
+  const int t = threadIdx.x;
+  const int lane = t & 63, wave = t >> 6;
+  const int wr = wave / (TN / 64), wc = wave % (TN / 64);   // 2 x (TN/64) waves of 64 x 64
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int64_t n0 = (int64_t)blockIdx.x * TN, m0 = (int64_t)blockIdx.y * TM;
+
+  // loaders (rows past the extent are clamped: they only feed outputs the guarded epilogue never stores)
+  const float *xp[XPT];
+#pragma unroll
+  for (int i = 0; i < XPT; ++i) {
+    int64_t xr = m0 + (t >> 2) + (NT / 4) * i;
+    xr = xr < M ? xr : M - 1;
+    xp[i] = X + xr * ldx + (t & 3) * 4;             // 128 rows x 16 floats
+  }
+  int64_t wrow = n0 + (t >> 1);
+  wrow = wrow < N ? wrow : N - 1;
+  const int64_t woff = wrow * K + (t & 1) * 8;      // TN rows x 16 halves per plane: 16 bytes per thread
+  // X (streamed from HBM) is fetched TWO k-steps ahead, W (L2) one
+  float4 xa0[XPT], xa1[XPT];
+  uint4 wv[2];
+  auto loadx = [&](float4 (&xa)[XPT], int64_t k0) {
+#pragma unroll
+    for (int i = 0; i < XPT; ++i) {
+      if constexpr (NX) {  // streaming hint: X is read once, keep L2 for the weight planes
+        const float *q = xp[i] + k0;
+        xa[i] = make_float4(__builtin_nontemporal_load(q), __builtin_nontemporal_load(q + 1),
+                            __builtin_nontemporal_load(q + 2), __builtin_nontemporal_load(q + 3));
+      } else {
+        xa[i] = *reinterpret_cast<const float4 *>(xp[i] + k0);
+      }
+    }
+  };
+  auto loadw = [&](int64_t k0) {
+    wv[0] = *reinterpret_cast<const uint4 *>(W0 + woff + k0);
+    wv[1] = *reinterpret_cast<const uint4 *>(W1 + woff + k0);
+  };
+  auto store = [&](const float4 (&xa)[XPT], uint32_t *st) {
+#pragma unroll
+    for (int i = 0; i < XPT; ++i) {
+      uint32_t h0, l0, h1, l1;
+      split_x(xa[i].x, xa[i].y, h0, l0);
+      split_x(xa[i].z, xa[i].w, h1, l1);
+      const int off = ((t >> 2) + (NT / 4) * i) * YLW + (t & 3) * 2;
+      *reinterpret_cast<uint2 *>(st + off) = make_uint2(h0, h1);
+      *reinterpret_cast<uint2 *>(st + APLANE + off) = make_uint2(l0, l1);
+    }
+    uint32_t *sb = st + 2 * APLANE;
+    const int offb = (t >> 1) * YLW + (t & 1) * 4;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      *reinterpret_cast<uint2 *>(sb + p * BPLANE + offb) = make_uint2(wv[p].x, wv[p].y);
+      *reinterpret_cast<uint2 *>(sb + p * BPLANE + offb + 2) = make_uint2(wv[p].z, wv[p].w);
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // one k-step: MFMAs on the LDS stage (step k0); `nxt` holds X of step k0+16 (in flight since the previous step),
+  // `fre` is refilled with X of step k0+32
+  auto step = [&](int64_t k0, float4 (&nxt)[XPT], float4 (&fre)[XPT]) {
+    const bool more = k0 + YK < K;
+    if (k0 + 2 * YK < K) loadx(fre, k0 + 2 * YK);
+    if (more) loadw(k0 + YK);
+    const uint32_t *pa = lds, *pb = pa + 2 * APLANE;
+    f16x8 a[2][2], b[3][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      a[0][i] = read_frag(pa, wr * 64 + i * 32 + l31, lh);
+      a[1][i] = read_frag(pa + APLANE, wr * 64 + i * 32 + l31, lh);
+      b[0][i] = read_frag(pb, wc * 64 + i * 32 + l31, lh);
+      b[1][i] = read_frag(pb + BPLANE, wc * 64 + i * 32 + l31, lh);
+      b[2][i] = scale_2m11(b[0][i]);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1][i], b[2][j], acc[i][j], 0, 0, 0);  // lo(x) hi(w)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0][i], b[1][j], acc[i][j], 0, 0, 0);  // hi(x) lo(w)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0][i], b[0][j], acc[i][j], 0, 0, 0);  // hi(x) hi(w)
+      }
+    __syncthreads();  // every wave has read its fragments
+    if (more) store(nxt, lds);
+    __syncthreads();
+  };
+
+  loadx(xa0, 0);
+  loadw(0);
+  if (YK < K) loadx(xa1, YK);
+  store(xa0, lds);
+  __syncthreads();
+  for (int64_t k0 = 0; k0 < K; k0 += 2 * YK) {
+    step(k0, xa1, xa0);
+    if (k0 + YK < K) step(k0 + YK, xa0, xa1);
+  }
+
+  const float inv = w_scale(amax[0], true);
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int64_t n = n0 + wc * 64 + j * 32 + l31;
+      const float bv = (bias && n < N) ? bias[n] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t m = m0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (m < M && n < N) {
+          float v = acc[i][j][r] * inv + bv;
+          if (relu) v = fmaxf(v, 0.f);
+          Y[m * ldy + n] = v;
+        }
+      }
+    }
+}
+
+}  // namespace
+
+extern "C" int64_t svr_linear_fwd_f16x3_workspace(int64_t N, int64_t K) { return 2 * N * K * (int64_t)sizeof(uint16_t) + 512; }
+
+extern "C" int svr_linear_fwd_f16x3(const float *X, int64_t ldx, const float *W, int64_t ldw, const float *bias, float *Y,
+                                    int64_t ldy, int64_t M, int64_t N, int64_t K, int epilogue, void *workspace,
+                                    void *stream) {
+  if (M == 0) return SVR_OK;  // empty point set
+  SVR_CHECK(X && W && Y && workspace, SVR_E_BADARG, "linear_fwd_f16x3: null pointer");
+  SVR_CHECK(M >= 0 && N > 0 && K > 0 && K % YK == 0, SVR_E_BADSHAPE, "linear_fwd_f16x3: M=%ld N=%ld K=%ld (K %% 16)", (long)M, (long)N, (long)K);
+  SVR_CHECK(ldx % 4 == 0 && ((uintptr_t)X & 15) == 0, SVR_E_ALIGN, "linear_fwd_f16x3: X must be 16-byte aligned");
+  SVR_CHECK(epilogue == SVR_EPI_NONE || ((epilogue == SVR_EPI_BIAS || epilogue == SVR_EPI_BIAS_RELU) && bias), SVR_E_BADARG,
+            "linear_fwd_f16x3: epilogue %d", epilogue);
+  hipStream_t s = (hipStream_t)stream;
+  uint32_t *amax = (uint32_t *)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+  uint16_t *p0 = (uint16_t *)(amax + 64);
+  uint16_t *p1 = p0 + N * K;
+  hipMemsetAsync(amax, 0, sizeof(uint32_t), s);
+  hipLaunchKernelGGL(w_amax_kernel, dim3((unsigned)std::min<int64_t>(cdiv(N * K, 1024), 1024)), dim3(256), 0, s, W, ldw, N, K, amax);
+  hipLaunchKernelGGL(split_w_kernel, dim3((unsigned)cdiv(N * (K / 2), 256)), dim3(256), 0, s, W, ldw, amax, p0, p1, N, K);
+  static const int variant = getenv("SVR_H3_VARIANT") ? atoi(getenv("SVR_H3_VARIANT")) : 0;  // experiment switch
+  const float *eb = epilogue == SVR_EPI_NONE ? nullptr : bias;
+  const int relu = epilogue == SVR_EPI_BIAS_RELU ? 1 : 0;
+  if (variant == 1) {
+    hipLaunchKernelGGL((linear_nt_h3_kernel<128, 1>), dim3((unsigned)cdiv(N, 128), (unsigned)cdiv(M, TM)), dim3(256), 0, s, X, ldx, p0, p1, amax, eb, Y, ldy, M, N, K, relu);
+    return launch_status("linear_fwd_f16x3");
+  } else if (variant == 2) {
+    hipLaunchKernelGGL((linear_nt_h3_kernel<256, 0>), dim3((unsigned)cdiv(N, 256), (unsigned)cdiv(M, TM)), dim3(512), 0, s, X, ldx, p0, p1, amax, eb, Y, ldy, M, N, K, relu);
+    return launch_status("linear_fwd_f16x3");
+  } else if (variant == 3) {
+    hipLaunchKernelGGL((linear_nt_h3_kernel<256, 1>), dim3((unsigned)cdiv(N, 256), (unsigned)cdiv(M, TM)), dim3(512), 0, s, X, ldx, p0, p1, amax, eb, Y, ldy, M, N, K, relu);
+    return launch_status("linear_fwd_f16x3");
+  }
+  constexpr int TN = 128;
+  dim3 grid((unsigned)cdiv(N, TN), (unsigned)cdiv(M, TM));
+  hipLaunchKernelGGL((linear_nt_h3_kernel<128, 0>), grid, dim3(256), 0, s, X, ldx, p0, p1, amax,
+                     epilogue == SVR_EPI_NONE ? nullptr : bias, Y, ldy, M, N, K, epilogue == SVR_EPI_BIAS_RELU ? 1 : 0);
+  return launch_status("linear_fwd_f16x3");
+}

@@ -136,9 +136,10 @@ def corner_indices(vols, points, layout, level, displacement, align_corners):
 # ------------------------------------------------------------------------------------------
 # point MLP
 # ------------------------------------------------------------------------------------------
-# Arithmetic of the forward GEMMs of the point MLP: "bf16x6" (6-product bf16 split, f32-equivalent accuracy,
+# Arithmetic of the forward GEMMs of the point MLP: "f16x3" (3-product f16 split with power-of-two scaling, as
+# accurate as an f32 GEMM for |x| < 65504, gemm_f16x3.hip), "bf16x6" (6-product bf16 split, any f32 range,
 # gemm_bf16x6.hip) or "f32" (exact-f32 MFMA).
-FORWARD_GEMM = "bf16x6"
+FORWARD_GEMM = "f16x3"
 
 
 def linear_fwd(x, w, bias, relu=True, out=None, mode=None):
@@ -150,6 +151,12 @@ def linear_fwd(x, w, bias, relu=True, out=None, mode=None):
     if out is None:
         out = torch.empty(M, N, device=x.device, dtype=torch.float32)
     epi = EPI_NONE if bias is None else (EPI_BIAS_RELU if relu else EPI_BIAS)
+    if (mode or FORWARD_GEMM) == "f16x3" and K % 16 == 0:
+        l = _lib.lib()
+        ws = torch.empty(l.svr_linear_fwd_f16x3_workspace(N, K), device=x.device, dtype=torch.uint8)
+        check(l.svr_linear_fwd_f16x3(C.c_void_p(x.data_ptr()), x.stride(0), C.c_void_p(w.data_ptr()), w.stride(0), _p(bias),
+                                     _p(out), out.stride(0), M, N, K, epi, _p(ws), _stream()), "linear_fwd_f16x3")
+        return out
     if (mode or FORWARD_GEMM) == "bf16x6" and K % 16 == 0:
         l = _lib.lib()
         ws = torch.empty(l.svr_linear_fwd_bf16x6_workspace(N, K), device=x.device, dtype=torch.uint8)

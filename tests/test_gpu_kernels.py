@@ -115,11 +115,25 @@ def test_linear_fwd_bwd(M, N, K):
     w = torch.randn(N, K, generator=g) / K ** 0.5
     b = torch.randn(N, generator=g)
     y_ref = F.relu(x.double() @ w.double().t() + b.double())
-    for mode in ("f32", "bf16x6"):          # both forward paths are held to the same f32-level gate
+    errs = {}
+    for mode in ("f32", "bf16x6", "f16x3"):  # all forward paths are held to the same f32-level gate
         y = ops.linear_fwd(x.cuda(), w.cuda(), b.cuda(), relu=True, mode=mode)
         assert G.rel_err(y.cpu().numpy(), y_ref.numpy()) < 2e-6, mode
         yl = ops.linear_fwd(x.cuda(), w.cuda(), b.cuda(), relu=False, mode=mode)
-        assert G.rel_err(yl.cpu().numpy(), (x.double() @ w.double().t() + b.double()).numpy()) < 2e-6, mode
+        errs[mode] = G.rel_err(yl.cpu().numpy(), (x.double() @ w.double().t() + b.double()).numpy())
+        assert errs[mode] < 2e-6, mode
+    assert errs["f16x3"] < 3 * errs["f32"] + 1e-7, errs     # the f16 split is as accurate as the exact-f32 MFMA kernel
+    # f16x3 over a wide dynamic range (rows from ~1e-8 to ~6e4, weights scaled far from 1: the power-of-two
+    # normalisation of W is exact).  Contract (gemm_f16x3.hip): f32-level relative accuracy for |x| >= 6e-5 (the f16
+    # normal range), an absolute error floor of 1.5e-11 |w| per term below that.
+    for xs, wsc in ((1e-4, 300.0), (2000.0, 1e-5), (1.0, 1.0)):
+        x2 = (x * xs * torch.exp(3 * torch.randn(M, 1, generator=g))).clamp(-6e4, 6e4)
+        w2 = w * wsc
+        ref2 = x2.double() @ w2.double().t()
+        y2 = ops.linear_fwd(x2.cuda(), w2.cuda(), None, relu=False, mode="f16x3")
+        err = (y2.cpu().double() - ref2).abs().amax(1)
+        bound = 2e-6 * ref2.abs().amax(1) + 1.5e-11 * w2.abs().max().item() * K ** 0.5
+        assert bool((err <= bound).all()), (xs, wsc, (err / bound).max().item())
     dy = torch.randn(M, N, generator=g)
     dx_ref = (dy.double() @ w.double()) * (x.double() > 0)
     dw_ref = dy.double().t() @ x.double()

@@ -26,7 +26,7 @@ for (N, K) in ((256, 2592), (256, 256)):
     b = torch.randn(N, device=dev)
     dy = torch.randn(M, N, device=dev)
     fl = 2.0 * M * N * K / 1e12
-    for mode in ("f32", "bf16x6"):
+    for mode in ("f32", "bf16x6", "f16x3"):
         t = timeit(lambda: ops.linear_fwd(x, w, b, relu=True, mode=mode))
         print(f"N={N} K={K}: fwd      {mode:7s} {t:7.3f} ms  {fl/t*1e3:7.1f} TF/s")
     for mode in ("f32", "bf16x3"):
