@@ -16,13 +16,13 @@
 // Domain: |x| < 65504 (f16 range; beyond that the result is inf/nan, not silently wrong).  |x| < 6e-5 keeps an
 // absolute error of 1.5e-11.  "bf16x6" (any f32 range) and "f32" stay selectable.
 //
-//   Y[M,N] = epi( X[M,K] W[N,K]^T )    128x256 tile, 8 waves x (2x2) v_mfma_f32_32x32x16_f16 tiles, k-step 16.
-// The kernel is bound by bytes through L2 (X streamed from HBM, W re-read by every workgroup), not by the matrix
-// cores: the tile spans N = 256 so X is read once, only wh and wl travel (wq is one v_pk_mul_f16 per fragment
-// register), and X is prefetched two k-steps ahead.
+//   Y[M,N] = epi( X[M,K] W[N,K]^T )    128x128 tile, 4 waves x (2x2) v_mfma_f32_32x32x16_f16 tiles, k-step 16.
+// The kernel is bound by the bytes it pulls through L2 / Infinity Cache (X from HBM, W re-read by every
+// workgroup: 16.6 GB at 400 000 x 2592 x 256 = 6.9 TB/s), not by the matrix cores: only wh and wl travel (wq is
+// one v_pk_mul_f16 per fragment register) and both streams are prefetched two k-steps ahead.  A 128x256 tile
+// (X read once) ran one workgroup per CU and was slower (3.1 ms vs 2.4); `nt` loads of X were slower too (3.5).
 #include "common.h"
 #include <algorithm>
-#include <cstdlib>
 
 using namespace svr;
 
@@ -108,15 +108,20 @@ __device__ __forceinline__ f16x8 scale_2m11(f16x8 v) {  // exact: every normal h
   return v * (_Float16)(1.f / 2048.f);
 }
 
-// TN = 128: 4 waves, three workgroups per CU (the k-step is a latency chain global -> split -> LDS -> MFMA; more
-// resident workgroups hide it better than the wider tile, which reads X once but runs one workgroup per CU)
-template <int TN, int NX>
+// TN = 128: 4 waves, three workgroups per CU.  SCHED selects the instruction-scheduling hint of the k-step.
+//
+// Every wave runs the same k-step, so waves of different workgroups drift into lockstep and the LDS / VALU phase
+// of one does NOT hide behind the MFMA phase of another (measured: MFMA, LDS+VALU and global-load times simply
+// add up).  The k-step is therefore software pipelined INSIDE the wave: two LDS stages and two register sets, so
+// that the split + LDS stores of step k+1 and the global loads of step k+2 sit in the same barrier-free region
+// as the MFMAs of step k and can be issued between them (MFMA co-execution); one barrier per step.
+template <int TN, int NX, int SCHED>
 __global__ __launch_bounds__(2 * TN, 1024 / (2 * TN) >= 4 ? 3 : 2) void linear_nt_h3_kernel(
     const float *__restrict__ X, int64_t ldx, const uint16_t *__restrict__ W0, const uint16_t *__restrict__ W1,
     const uint32_t *__restrict__ amax, const float *__restrict__ bias, float *__restrict__ Y, int64_t ldy, int64_t M,
     int64_t N, int64_t K, int relu) {
-  constexpr int NT = 2 * TN, BPLANE = TN * YLW, XPT = 512 / NT;
-  __shared__ uint32_t lds[2 * APLANE + 2 * BPLANE];  // one stage (hi/lo planes of X and W), two barriers per k-step
+  constexpr int NT = 2 * TN, BPLANE = TN * YLW, XPT = 512 / NT, STAGE = 2 * APLANE + 2 * BPLANE;
+  __shared__ uint32_t lds[2 * STAGE];  // two stages of (hi/lo planes of X and W)
   const int t = threadIdx.x;
   const int lane = t & 63, wave = t >> 6;
   const int wr = wave / (TN / 64), wc = wave % (TN / 64);   // 2 x (TN/64) waves of 64 x 64
@@ -134,31 +139,33 @@ __global__ __launch_bounds__(2 * TN, 1024 / (2 * TN) >= 4 ? 3 : 2) void linear_n
   int64_t wrow = n0 + (t >> 1);
   wrow = wrow < N ? wrow : N - 1;
   const int64_t woff = wrow * K + (t & 1) * 8;      // TN rows x 16 halves per plane: 16 bytes per thread
-  // X (streamed from HBM) is fetched TWO k-steps ahead, W (L2) one
-  float4 xa0[XPT], xa1[XPT];
-  uint4 wv[2];
-  auto loadx = [&](float4 (&xa)[XPT], int64_t k0) {
+  struct Regs {
+    float4 x[XPT];
+    uint4 w[2];
+  };
+  Regs ra, rb;
+  const int64_t klast = K - YK;
+  auto load = [&](Regs &r, int64_t k0) {
+    k0 = k0 < klast ? k0 : klast;  // past the end: re-read the last step (never used), keeps the loop branch free
 #pragma unroll
     for (int i = 0; i < XPT; ++i) {
-      if constexpr (NX) {  // streaming hint: X is read once, keep L2 for the weight planes
+      if constexpr (NX) {
         const float *q = xp[i] + k0;
-        xa[i] = make_float4(__builtin_nontemporal_load(q), __builtin_nontemporal_load(q + 1),
-                            __builtin_nontemporal_load(q + 2), __builtin_nontemporal_load(q + 3));
+        r.x[i] = make_float4(__builtin_nontemporal_load(q), __builtin_nontemporal_load(q + 1),
+                             __builtin_nontemporal_load(q + 2), __builtin_nontemporal_load(q + 3));
       } else {
-        xa[i] = *reinterpret_cast<const float4 *>(xp[i] + k0);
+        r.x[i] = *reinterpret_cast<const float4 *>(xp[i] + k0);
       }
     }
+    r.w[0] = *reinterpret_cast<const uint4 *>(W0 + woff + k0);
+    r.w[1] = *reinterpret_cast<const uint4 *>(W1 + woff + k0);
   };
-  auto loadw = [&](int64_t k0) {
-    wv[0] = *reinterpret_cast<const uint4 *>(W0 + woff + k0);
-    wv[1] = *reinterpret_cast<const uint4 *>(W1 + woff + k0);
-  };
-  auto store = [&](const float4 (&xa)[XPT], uint32_t *st) {
+  auto store = [&](const Regs &r, uint32_t *st) {
 #pragma unroll
     for (int i = 0; i < XPT; ++i) {
       uint32_t h0, l0, h1, l1;
-      split_x(xa[i].x, xa[i].y, h0, l0);
-      split_x(xa[i].z, xa[i].w, h1, l1);
+      split_x(r.x[i].x, r.x[i].y, h0, l0);
+      split_x(r.x[i].z, r.x[i].w, h1, l1);
       const int off = ((t >> 2) + (NT / 4) * i) * YLW + (t & 3) * 2;
       *reinterpret_cast<uint2 *>(st + off) = make_uint2(h0, h1);
       *reinterpret_cast<uint2 *>(st + APLANE + off) = make_uint2(l0, l1);
@@ -167,8 +174,8 @@ __global__ __launch_bounds__(2 * TN, 1024 / (2 * TN) >= 4 ? 3 : 2) void linear_n
     const int offb = (t >> 1) * YLW + (t & 1) * 4;
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
-      *reinterpret_cast<uint2 *>(sb + p * BPLANE + offb) = make_uint2(wv[p].x, wv[p].y);
-      *reinterpret_cast<uint2 *>(sb + p * BPLANE + offb + 2) = make_uint2(wv[p].z, wv[p].w);
+      *reinterpret_cast<uint2 *>(sb + p * BPLANE + offb) = make_uint2(r.w[p].x, r.w[p].y);
+      *reinterpret_cast<uint2 *>(sb + p * BPLANE + offb + 2) = make_uint2(r.w[p].z, r.w[p].w);
     }
   };
 
@@ -180,13 +187,11 @@ __global__ __launch_bounds__(2 * TN, 1024 / (2 * TN) >= 4 ? 3 : 2) void linear_n
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  // one k-step: MFMAs on the LDS stage (step k0); `nxt` holds X of step k0+16 (in flight since the previous step),
-  // `fre` is refilled with X of step k0+32
-  auto step = [&](int64_t k0, float4 (&nxt)[XPT], float4 (&fre)[XPT]) {
-    const bool more = k0 + YK < K;
-    if (k0 + 2 * YK < K) loadx(fre, k0 + 2 * YK);
-    if (more) loadw(k0 + YK);
-    const uint32_t *pa = lds, *pb = pa + 2 * APLANE;
+  // step k0 on LDS stage `cur`: fragments -> MFMAs; `nxt` (step k0+16, in flight since the previous step) is split
+  // and stored to the other stage; `fre` (stored one step ago) is refilled with step k0+32
+  auto step = [&](int64_t k0, int cur, Regs &nxt, Regs &fre) {
+    load(fre, k0 + 2 * YK);
+    const uint32_t *pa = lds + cur * STAGE, *pb = pa + 2 * APLANE;
     f16x8 a[2][2], b[3][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -204,19 +209,28 @@ __global__ __launch_bounds__(2 * TN, 1024 / (2 * TN) >= 4 ? 3 : 2) void linear_n
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0][i], b[1][j], acc[i][j], 0, 0, 0);  // hi(x) lo(w)
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0][i], b[0][j], acc[i][j], 0, 0, 0);  // hi(x) hi(w)
       }
-    __syncthreads();  // every wave has read its fragments
-    if (more) store(nxt, lds);
+    store(nxt, lds + (cur ^ 1) * STAGE);
+    if constexpr (SCHED == 1) {
+      __builtin_amdgcn_iglp_opt(0);
+    } else if constexpr (SCHED == 2) {
+      // after the fragment reads: one MFMA, then a slice of the split (VALU) and of the LDS stores, twelve times
+#pragma unroll
+      for (int g = 0; g < 12; ++g) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
+        __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);  // VALU
+        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);  // DS write
+      }
+    }
     __syncthreads();
   };
 
-  loadx(xa0, 0);
-  loadw(0);
-  if (YK < K) loadx(xa1, YK);
-  store(xa0, lds);
+  load(ra, 0);
+  load(rb, YK);
+  store(ra, lds);
   __syncthreads();
   for (int64_t k0 = 0; k0 < K; k0 += 2 * YK) {
-    step(k0, xa1, xa0);
-    if (k0 + YK < K) step(k0 + YK, xa0, xa1);
+    step(k0, 0, rb, ra);
+    if (k0 + YK < K) step(k0 + YK, 1, ra, rb);
   }
 
   const float inv = w_scale(amax[0], true);
@@ -258,22 +272,11 @@ extern "C" int svr_linear_fwd_f16x3(const float *X, int64_t ldx, const float *W,
   hipMemsetAsync(amax, 0, sizeof(uint32_t), s);
   hipLaunchKernelGGL(w_amax_kernel, dim3((unsigned)std::min<int64_t>(cdiv(N * K, 1024), 1024)), dim3(256), 0, s, W, ldw, N, K, amax);
   hipLaunchKernelGGL(split_w_kernel, dim3((unsigned)cdiv(N * (K / 2), 256)), dim3(256), 0, s, W, ldw, amax, p0, p1, N, K);
-  static const int variant = getenv("SVR_H3_VARIANT") ? atoi(getenv("SVR_H3_VARIANT")) : 0;  // experiment switch
   const float *eb = epilogue == SVR_EPI_NONE ? nullptr : bias;
   const int relu = epilogue == SVR_EPI_BIAS_RELU ? 1 : 0;
-  if (variant == 1) {
-    hipLaunchKernelGGL((linear_nt_h3_kernel<128, 1>), dim3((unsigned)cdiv(N, 128), (unsigned)cdiv(M, TM)), dim3(256), 0, s, X, ldx, p0, p1, amax, eb, Y, ldy, M, N, K, relu);
-    return launch_status("linear_fwd_f16x3");
-  } else if (variant == 2) {
-    hipLaunchKernelGGL((linear_nt_h3_kernel<256, 0>), dim3((unsigned)cdiv(N, 256), (unsigned)cdiv(M, TM)), dim3(512), 0, s, X, ldx, p0, p1, amax, eb, Y, ldy, M, N, K, relu);
-    return launch_status("linear_fwd_f16x3");
-  } else if (variant == 3) {
-    hipLaunchKernelGGL((linear_nt_h3_kernel<256, 1>), dim3((unsigned)cdiv(N, 256), (unsigned)cdiv(M, TM)), dim3(512), 0, s, X, ldx, p0, p1, amax, eb, Y, ldy, M, N, K, relu);
-    return launch_status("linear_fwd_f16x3");
-  }
-  constexpr int TN = 128;
-  dim3 grid((unsigned)cdiv(N, TN), (unsigned)cdiv(M, TM));
-  hipLaunchKernelGGL((linear_nt_h3_kernel<128, 0>), grid, dim3(256), 0, s, X, ldx, p0, p1, amax,
-                     epilogue == SVR_EPI_NONE ? nullptr : bias, Y, ldy, M, N, K, epilogue == SVR_EPI_BIAS_RELU ? 1 : 0);
+  dim3 grid((unsigned)cdiv(N, 128), (unsigned)cdiv(M, TM));
+  // SCHED = 2 (one MFMA, a slice of the split, one LDS store, ...): 2.39 ms at 400 000 x 2592 x 256 against 2.49 for
+  // the compiler's own order and 2.50 for iglp_opt(0)
+  hipLaunchKernelGGL((linear_nt_h3_kernel<128, 0, 2>), grid, dim3(256), 0, s, X, ldx, p0, p1, amax, eb, Y, ldy, M, N, K, relu);
   return launch_status("linear_fwd_f16x3");
 }
