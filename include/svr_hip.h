@@ -181,6 +181,12 @@ int64_t svr_conv3d_fwd_bf16x6_workspace(int32_t Ci, int32_t Co);
 int svr_conv3d_k3_fwd_bf16x6(const float *in, const float *W, const float *bias, float *out, int32_t B,
                              int32_t D, int32_t H, int32_t Wd, int32_t Ci, int32_t Co, int epilogue,
                              void *workspace, void *stream);
+/* Same contract with the 3-product f16 split (see svr_linear_fwd_f16x3): f32-level accuracy for |in| < 65504 at half
+ * the matrix-core work of bf16x6.  workspace: svr_conv3d_fwd_f16x3_workspace(Ci, Co) bytes.               */
+int64_t svr_conv3d_fwd_f16x3_workspace(int32_t Ci, int32_t Co);
+int svr_conv3d_k3_fwd_f16x3(const float *in, const float *W, const float *bias, float *out, int32_t B,
+                             int32_t D, int32_t H, int32_t Wd, int32_t Ci, int32_t Co, int epilogue,
+                             void *workspace, void *stream);
 /* Backward-data on the bf16 matrix cores with the 3-term split (see svr_linear_bwd_data_bf16x3):
  * din(B,D,H,W,Ci) = epi( conv^T(dout(B,D,H,W,Co), W(Co,Ci,3,3,3)) ), epilogue NONE or MASK (mask like din).
  * Takes the UNPACKED weights; workspace: svr_conv3d_bwd_data_bf16x3_workspace(Ci, Co) bytes.  Ci even.   */

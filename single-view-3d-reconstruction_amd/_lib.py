@@ -56,6 +56,8 @@ SIGNATURES = {
     "svr_conv3d_k3": (C.c_int, [P, P, P, P, I32, I32, I32, I32, I32, I32, C.c_int, P, P]),
     "svr_conv3d_fwd_bf16x6_workspace": (I64, [I32, I32]),
     "svr_conv3d_k3_fwd_bf16x6": (C.c_int, [P, P, P, P, I32, I32, I32, I32, I32, I32, C.c_int, P, P]),
+    "svr_conv3d_fwd_f16x3_workspace": (I64, [I32, I32]),
+    "svr_conv3d_k3_fwd_f16x3": (C.c_int, [P, P, P, P, I32, I32, I32, I32, I32, I32, C.c_int, P, P]),
     "svr_conv3d_bwd_data_bf16x3_workspace": (I64, [I32, I32]),
     "svr_conv3d_k3_bwd_data_bf16x3": (C.c_int, [P, P, P, I32, I32, I32, I32, I32, I32, C.c_int, P, P, P]),
     "svr_conv3d_k3_bwd_weight_workspace": (I64, [I32, I32, I32, I32, I32, I32]),

@@ -11,6 +11,7 @@
 // bf16x3 is used only for dIn = conv^T(dOut); the forward uses bf16x6 (three planes, six products, 16-channel
 // chunks so the three halo planes still fit two workgroups per CU) and is held to the exact-f32 kernel's gate.
 #include "common.h"
+#include "f16x3.h"
 
 using namespace svr;
 
@@ -18,7 +19,6 @@ namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 struct ConvShape {
@@ -51,6 +51,31 @@ __device__ __forceinline__ bf16x8 read_frag(const uint32_t *p) {  // 8 bf16 at a
   union { uint4 q; bf16x8 v; } f;
   f.q = make_uint4(a.x, a.y, b.x, b.y);
   return f.v;
+}
+
+__device__ __forceinline__ f16x8 read_frag_h(const uint32_t *p) {  // the same 16 bytes as 8 halves
+  const uint2 a = *reinterpret_cast<const uint2 *>(p);
+  const uint2 b = *reinterpret_cast<const uint2 *>(p + 2);
+  union { uint4 q; f16x8 v; } f;
+  f.q = make_uint4(a.x, a.y, b.x, b.y);
+  return f.v;
+}
+
+// W (Co,Ci,3,3,3) f32 -> forward planes of the f16 split [2][27][Co][Ci]: hi(W 2^s), lo(W 2^s)  (f16x3.h / gemm_f16x3.hip)
+__global__ void pack_fwd_planes_f16_kernel(const float *__restrict__ W, const uint32_t *__restrict__ amax,
+                                           uint16_t *__restrict__ p0, uint16_t *__restrict__ p1, int Ci, int Co) {
+  int idx = blockIdx.x * blockDim.x + threadIdx.x;  // over (tap, co, ci/2)
+  if (idx >= 27 * Co * (Ci / 2)) return;
+  const int ci = (idx % (Ci / 2)) * 2;
+  const int co = (idx / (Ci / 2)) % Co;
+  const int tap = idx / ((Ci / 2) * Co);
+  const float sc = w_scale(amax[0], false);
+  const float w0 = W[((size_t)co * Ci + ci) * 27 + tap] * sc, w1 = W[((size_t)co * Ci + ci + 1) * 27 + tap] * sc;
+  const uint32_t hi = pack_f16(w0, w1);
+  const f32x2 h = unpack_f16(hi);
+  const size_t o = ((size_t)tap * Co + co) * Ci + ci;
+  *reinterpret_cast<uint32_t *>(p0 + o) = hi;
+  *reinterpret_cast<uint32_t *>(p1 + o) = pack_f16(w0 - h.x, w1 - h.y);
 }
 
 // W (Co,Ci,3,3,3) f32 -> backward-data planes [2][27][Ci][Co] bf16: row = ORIGINAL input channel (the output
@@ -87,13 +112,16 @@ __global__ void pack_fwd_planes_kernel(const float *__restrict__ W, uint16_t *__
 
 // out(B,D,H,W,NOUT) = epi( sum_{tap,k} in[voxel+tap][k] * P[tap][n][k] ), K = s.Ci input channels of THIS call,
 // NOUT = s.Co.  planes: hi then mid, each [27][NOUT][K] bf16.
-// NP = 2: products mid*hi + hi*mid + hi*hi (bf16x3);  NP = 3: the six products of bf16x6.
-template <int CK, int TNB, int NP>
+// NP = 2: products mid*hi + hi*mid + hi*hi (bf16x3);  NP = 3: the six products of bf16x6;
+// F16 (NP = 2): the f16 split of gemm_f16x3.hip -- planes hi / lo*2^11 of the input, hi / lo of the normalised
+// weights, products lo'(x) wq + hi(x) lo(w) + hi(x) hi(w) with wq = hi(w) 2^-11 made in registers, epilogue * 2^-s.
+template <int CK, int TNB, int NP, bool F16 = false>
 __global__ __launch_bounds__(256) void conv3d_brick_x3_kernel(const float *__restrict__ in,
                                                               const uint16_t *__restrict__ P0,
                                                               int64_t plane_stride, const float *__restrict__ bias,
                                                               float *__restrict__ out, const float *__restrict__ mask,
-                                                              ConvShape s, int nbz, int nby, int nbx, int mode) {
+                                                              ConvShape s, int nbz, int nby, int nbx, int mode,
+                                                              const uint32_t *__restrict__ amax = nullptr) {
   constexpr int XW = (CK + 4) / 2;           // dwords per LDS row (CK bf16 + 8 B pad)
   constexpr int NC = TNB * 32;               // output columns of this workgroup
   constexpr int TG = TNB == 1 ? 3 : 1;       // taps per barrier
@@ -179,6 +207,9 @@ __global__ __launch_bounds__(256) void conv3d_brick_x3_kernel(const float *__res
         split3(v.x, v.y, h0, m0, l0);
         split3(v.z, v.w, h1, m1, l1);
         *reinterpret_cast<uint2 *>(&sh[NP - 1][hv * XW + c4 / 2]) = make_uint2(l0, l1);
+      } else if constexpr (F16) {
+        split_x(v.x, v.y, h0, m0);
+        split_x(v.z, v.w, h1, m1);
       } else {
         split2(v.x, v.y, h0, m0);
         split2(v.z, v.w, h1, m1);
@@ -199,6 +230,19 @@ __global__ __launch_bounds__(256) void conv3d_brick_x3_kernel(const float *__res
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
           const int kw = ks * 8 + lh * 4;
+          if constexpr (F16) {
+            const f16x8 xh = read_frag_h(&sh[0][arow * XW + kw]);
+            const f16x8 xl = read_frag_h(&sh[1][arow * XW + kw]);
+#pragma unroll
+            for (int j = 0; j < TNB; ++j) {
+              const f16x8 wh = read_frag_h(&sw[buf][tg][0][(j * 32 + l31) * XW + kw]);
+              const f16x8 wl = read_frag_h(&sw[buf][tg][1][(j * 32 + l31) * XW + kw]);
+              acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xl, scale_2m11(wh), acc[j], 0, 0, 0);
+              acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, wl, acc[j], 0, 0, 0);
+              acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, wh, acc[j], 0, 0, 0);
+            }
+            continue;
+          }
           const bf16x8 ah = read_frag(&sh[0][arow * XW + kw]);
           const bf16x8 am = read_frag(&sh[1][arow * XW + kw]);
 #pragma unroll
@@ -231,6 +275,7 @@ __global__ __launch_bounds__(256) void conv3d_brick_x3_kernel(const float *__res
     const int n = n0 + j * 32 + l31;
     const int nc = min(n, s.Co - 1);
     const float bv = (mode == SVR_EPI_BIAS || mode == SVR_EPI_BIAS_RELU) ? bias[nc] : 0.f;
+    const float inv = F16 ? w_scale(amax[0], true) : 1.f;
     const int gz = z0 + wave;
     // the ReLU mask of the whole tile is fetched up front from clamped coordinates: loads inside the bounds
     // branch would be waited for one at a time
@@ -249,7 +294,7 @@ __global__ __launch_bounds__(256) void conv3d_brick_x3_kernel(const float *__res
       const int gy = y0 + i / BRX, gx = x0 + i % BRX;
       if (n < s.Co && gz < s.D && gy < s.H && gx < s.W) {
         const int64_t o = ((((int64_t)b * s.D + gz) * s.H + gy) * s.W + gx) * s.Co + n;
-        float v = acc[j][r] + bv;
+        float v = (F16 ? acc[j][r] * inv : acc[j][r]) + bv;
         if (mode == SVR_EPI_BIAS_RELU) v = fmaxf(v, 0.f);
         if (mode == SVR_EPI_MASK) v = mk[r] > 0.f ? v : 0.f;
         out[o] = v;
@@ -315,4 +360,39 @@ extern "C" int svr_conv3d_k3_fwd_bf16x6(const float *in, const float *W, const f
   if (Co <= 32) LAUNCH_X6(1); else if (Co <= 64) LAUNCH_X6(2); else LAUNCH_X6(4);
 #undef LAUNCH_X6
   return launch_status("conv3d_fwd_bf16x6");
+}
+
+extern "C" int64_t svr_conv3d_fwd_f16x3_workspace(int32_t Ci, int32_t Co) { return 2LL * 27 * Ci * Co * (int64_t)sizeof(uint16_t) + 512; }
+
+// out(B,D,H,W,Co) = epi( conv(in(B,D,H,W,Ci), W(Co,Ci,3,3,3)) ) with the 3-product f16 split: f32-level accuracy for
+// |in| < 65504 (see gemm_f16x3.hip); epilogue NONE / BIAS / BIAS_RELU.
+extern "C" int svr_conv3d_k3_fwd_f16x3(const float *in, const float *W, const float *bias, float *out, int32_t B, int32_t D,
+                                       int32_t H, int32_t Wd, int32_t Ci, int32_t Co, int epilogue, void *workspace,
+                                       void *stream) {
+  SVR_CHECK(in && W && out && workspace, SVR_E_BADARG, "conv3d_fwd_f16x3: null pointer");
+  SVR_CHECK(B > 0 && D > 0 && H > 0 && Wd > 0, SVR_E_BADSHAPE, "conv3d_fwd_f16x3: empty volume");
+  SVR_CHECK(Ci % 16 == 0 && Co >= 1, SVR_E_UNSUPPORTED, "conv3d_fwd_f16x3: need Ci %% 16 == 0 (Ci=%d Co=%d)", Ci, Co);
+  SVR_CHECK(epilogue == SVR_EPI_NONE || ((epilogue == SVR_EPI_BIAS || epilogue == SVR_EPI_BIAS_RELU) && bias), SVR_E_BADARG,
+            "conv3d_fwd_f16x3: epilogue %d", epilogue);
+  hipStream_t s = (hipStream_t)stream;
+  uint32_t *amax = (uint32_t *)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+  uint16_t *p0 = (uint16_t *)(amax + 64);
+  const int64_t ps = (int64_t)27 * Ci * Co;
+  (void)hipMemsetAsync(amax, 0, sizeof(uint32_t), s);
+  hipLaunchKernelGGL(w_amax_kernel, dim3((unsigned)cdiv(ps, 1024)), dim3(256), 0, s, W, ps, (int64_t)1, ps, amax);
+  hipLaunchKernelGGL(pack_fwd_planes_f16_kernel, dim3(cdiv(27 * Co * (Ci / 2), 256)), dim3(256), 0, s, W, amax, p0, p0 + ps, Ci, Co);
+  ConvShape sh{B, D, H, Wd, Ci, Co};
+  const int nbz = (int)cdiv(D, BRZ), nby = (int)cdiv(H, BRY), nbx = (int)cdiv(Wd, BRX);
+  const unsigned bricks = (unsigned)((int64_t)B * nbz * nby * nbx);
+#define LAUNCH_H3(CKV, TNV)                                                                                                 \
+  hipLaunchKernelGGL((conv3d_brick_x3_kernel<CKV, TNV, 2, true>), dim3(bricks, (unsigned)cdiv(Co, TNV * 32)), dim3(256), 0, s, \
+                     in, p0, ps, bias, out, (const float *)nullptr, sh, nbz, nby, nbx, epilogue, amax)
+  const int tn = Co <= 32 ? 1 : (Co <= 64 ? 2 : 4);
+  if (Ci % 32 == 0) {
+    if (tn == 1) LAUNCH_H3(32, 1); else if (tn == 2) LAUNCH_H3(32, 2); else LAUNCH_H3(32, 4);
+  } else {
+    if (tn == 1) LAUNCH_H3(16, 1); else if (tn == 2) LAUNCH_H3(16, 2); else LAUNCH_H3(16, 4);
+  }
+#undef LAUNCH_H3
+  return launch_status("conv3d_fwd_f16x3");
 }

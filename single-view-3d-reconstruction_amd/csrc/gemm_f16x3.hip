@@ -22,15 +22,13 @@
 // one v_pk_mul_f16 per fragment register) and both streams are prefetched two k-steps ahead.  A 128x256 tile
 // (X read once) ran one workgroup per CU and was slower (3.1 ms vs 2.4); `nt` loads of X were slower too (3.5).
 #include "common.h"
+#include "f16x3.h"
 #include <algorithm>
 
 using namespace svr;
 
 namespace {
 
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int YK = 16;   // reduction elements per step
@@ -38,56 +36,12 @@ constexpr int YLW = 10;  // dwords per LDS row (16 halves + 8 B pad: ds_read_b64
 constexpr int TM = 128;
 constexpr int APLANE = TM * YLW;  // dwords per X plane
 
-__device__ __forceinline__ uint32_t pack_f16(float a, float b) {
-  f32x2 v = {a, b};
-  f16x2 h = __builtin_convertvector(v, f16x2);  // round to nearest even
-  return __builtin_bit_cast(uint32_t, h);
-}
-__device__ __forceinline__ f32x2 unpack_f16(uint32_t p) {
-  return __builtin_convertvector(__builtin_bit_cast(f16x2, p), f32x2);
-}
-
-// (x0, x1) -> packed hi pair, packed (lo * 2^11) pair
-__device__ __forceinline__ void split_x(float x0, float x1, uint32_t &hi, uint32_t &lo) {
-  hi = pack_f16(x0, x1);
-  const f32x2 h = unpack_f16(hi);
-  lo = pack_f16((x0 - h.x) * 2048.f, (x1 - h.y) * 2048.f);
-}
-
 __device__ __forceinline__ f16x8 read_frag(const uint32_t *plane, int row, int lh) {
   const uint2 a = *reinterpret_cast<const uint2 *>(plane + row * YLW + lh * 4);
   const uint2 b = *reinterpret_cast<const uint2 *>(plane + row * YLW + lh * 4 + 2);
   union { uint4 q; f16x8 v; } f;
   f.q = make_uint4(a.x, a.y, b.x, b.y);
   return f.v;
-}
-
-// amax[0] = bit pattern of max |W| (non-negative floats order like unsigned integers); zeroed by the host first
-__global__ __launch_bounds__(256) void w_amax_kernel(const float *__restrict__ W, int64_t ldw, int64_t N, int64_t K,
-                                                     uint32_t *__restrict__ amax) {
-  __shared__ float red[256];
-  float m = 0.f;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < N * K; i += (int64_t)gridDim.x * 256)
-    m = fmaxf(m, fabsf(W[(i / K) * ldw + i % K]));
-  red[threadIdx.x] = m;
-  __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) {
-    if (threadIdx.x < o) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + o]);
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) atomicMax(amax, __float_as_uint(red[0]));
-}
-
-// 2^s (or 2^-s) with amax * 2^s in [2^13, 2^14); s = 0 for an all-zero or non-finite W
-__device__ __forceinline__ float w_scale(uint32_t amax_bits, bool inverse) {
-  const float amax = __uint_as_float(amax_bits);
-  int e = 0;
-  if (amax > 0.f && amax < 3.0e38f) {
-    frexpf(amax, &e);  // amax = f * 2^e, f in [0.5, 1)
-    e = 14 - e;
-    e = e > 100 ? 100 : (e < -100 ? -100 : e);
-  }
-  return ldexpf(1.f, inverse ? -e : e);
 }
 
 // W[N][K] f32 -> planes [N][K] f16: hi(Ws), lo(Ws)
@@ -104,9 +58,6 @@ __global__ void split_w_kernel(const float *__restrict__ W, int64_t ldw, const u
   *reinterpret_cast<uint32_t *>(p1 + n * K + k) = pack_f16(w0 - h.x, w1 - h.y);
 }
 
-__device__ __forceinline__ f16x8 scale_2m11(f16x8 v) {  // exact: every normal hi(Ws) stays normal (see header)
-  return v * (_Float16)(1.f / 2048.f);
-}
 
 // TN = 128: 4 waves, three workgroups per CU.  SCHED selects the instruction-scheduling hint of the k-step.
 //
@@ -269,7 +220,7 @@ extern "C" int svr_linear_fwd_f16x3(const float *X, int64_t ldx, const float *W,
   uint32_t *amax = (uint32_t *)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
   uint16_t *p0 = (uint16_t *)(amax + 64);
   uint16_t *p1 = p0 + N * K;
-  hipMemsetAsync(amax, 0, sizeof(uint32_t), s);
+  (void)hipMemsetAsync(amax, 0, sizeof(uint32_t), s);
   hipLaunchKernelGGL(w_amax_kernel, dim3((unsigned)std::min<int64_t>(cdiv(N * K, 1024), 1024)), dim3(256), 0, s, W, ldw, N, K, amax);
   hipLaunchKernelGGL(split_w_kernel, dim3((unsigned)cdiv(N * (K / 2), 256)), dim3(256), 0, s, W, ldw, amax, p0, p1, N, K);
   const float *eb = epilogue == SVR_EPI_NONE ? nullptr : bias;

@@ -289,8 +289,9 @@ def conv3d_k3(x, wp, bias=None, relu=False, mask=None):
 
 # Arithmetic of the encoder's backward-data convolutions: "bf16x3" (conv3d_bf16.hip) or "f32".
 BACKWARD_CONV = "bf16x3"
-# ... and of its forward convolutions: "bf16x6" (f32-equivalent) or "f32" (exact-f32 MFMA)
-FORWARD_CONV = "bf16x6"
+# ... and of its forward convolutions: "f16x3" (3-product f16 split, f32-level accuracy for |x| < 65504), "bf16x6"
+# (6-product bf16 split, any f32 range) or "f32" (exact-f32 MFMA)
+FORWARD_CONV = "f16x3"
 
 
 def conv3d_k3_fwd(x, w, bias, relu=True, mode=None):
@@ -298,6 +299,13 @@ def conv3d_k3_fwd(x, w, bias, relu=True, mode=None):
     _f32(x, w, bias)
     B, D, H, W, Ci = x.shape
     Co = w.shape[0]
+    if (mode or FORWARD_CONV) == "f16x3" and Ci % 16 == 0:
+        l = _lib.lib()
+        out = torch.empty(B, D, H, W, Co, device=x.device, dtype=torch.float32)
+        ws = torch.empty(l.svr_conv3d_fwd_f16x3_workspace(Ci, Co), device=x.device, dtype=torch.uint8)
+        check(l.svr_conv3d_k3_fwd_f16x3(_p(x), _p(w), _p(bias), _p(out), B, D, H, W, Ci, Co,
+                                        EPI_BIAS_RELU if relu else EPI_BIAS, _p(ws), _stream()), "conv3d_fwd_f16x3")
+        return out
     if (mode or FORWARD_CONV) == "bf16x6" and Ci % 16 == 0:
         l = _lib.lib()
         out = torch.empty(B, D, H, W, Co, device=x.device, dtype=torch.float32)

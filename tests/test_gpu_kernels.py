@@ -197,7 +197,7 @@ def test_conv3d_fwd_bwd(B, dims, Ci, Co):
     wf, wb = ops.conv3d_pack_weight(w.detach().cuda())
     y = ops.conv3d_k3(_cl(x.detach()), wf, b.detach().cuda(), relu=True)
     assert G.rel_err(_ncdhw(y).numpy(), y_ref.detach().numpy()) < 3e-6
-    for mode in ("f32", "bf16x6"):      # production forward: bf16x6 where Ci % 16 == 0, held to the f32 gate
+    for mode in ("f32", "bf16x6", "f16x3"):  # production forward: f16x3 where Ci % 16 == 0, all held to the f32 gate
         y2 = ops.conv3d_k3_fwd(_cl(x.detach()), w.detach().cuda(), b.detach().cuda(), relu=True, mode=mode)
         assert G.rel_err(_ncdhw(y2).numpy(), y_ref.detach().numpy()) < 3e-6, mode
     # weight gradient: exact-f32 MFMA kernel, and the production bf16x3 split (f32 fallback for Ci == 1)
