@@ -16,7 +16,14 @@ inline int launch_status(const char *what) {
   }
   return SVR_OK;
 }
-inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+__host__ __device__ inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// XCD-aware workgroup order: blocks are dealt round-robin over the 8 XCDs (each with its own 4 MB L2), so tiles
+// that share an operand panel should have equal `block id % 8`.  1-D grids are padded to a multiple of 8 and the
+// linear block id is mapped to a logical index that is contiguous per XCD; indices >= the real count exit.
+constexpr int kXcds = 8;
+inline unsigned xcd_grid(int64_t total) { return (unsigned)(kXcds * cdiv(total, kXcds)); }
+__device__ __forceinline__ int64_t xcd_logical(int64_t bid, int64_t grid) { return (bid % kXcds) * (grid / kXcds) + bid / kXcds; }
 }  // namespace svr
 
 #define SVR_CHECK(cond, code, ...)      \

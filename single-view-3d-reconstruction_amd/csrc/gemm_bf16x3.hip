@@ -291,7 +291,10 @@ __global__ __launch_bounds__(256, 3) void linear_nn_x3_kernel(const float *__res
   using G = Geo<2, 2>;
   static_assert(G::LDS_DWORDS >= (NN_TM / 2) * NN_CLD, "half the epilogue tile must fit the staging buffer");
   __shared__ uint32_t lds[G::LDS_DWORDS];
-  const int64_t c0 = (int64_t)blockIdx.x * NN_TN, m0 = (int64_t)blockIdx.y * NN_TM;
+  // all column tiles of a row panel run on one XCD, back to back: dY comes from HBM once, then from that L2
+  const int64_t nct = cdiv(K, NN_TN), lidx = xcd_logical(blockIdx.x, gridDim.x);
+  if (lidx >= nct * cdiv(M, NN_TM)) return;
+  const int64_t c0 = (lidx % nct) * NN_TN, m0 = (lidx / nct) * NN_TM;
   RowKLoader<NN_TM, 256> al(dY, lddy, m0, M);
   PlaneLoader<NN_TN, 256> bl(Wh, Wm, N, c0, K);
   f32x16 acc[2][2];
@@ -340,17 +343,22 @@ constexpr int TN_TM = 128, TN_TN = 128;
 __global__ __launch_bounds__(256) void linear_tn_x3_kernel(const float *__restrict__ dY, int64_t lddy,
                                                            const float *__restrict__ X, int64_t ldx,
                                                            float *__restrict__ slab, int64_t M, int64_t N, int64_t K,
-                                                           int64_t rows_per_split) {
+                                                           int64_t rows_per_split, int splits) {
   using G = Geo<2, 2>;
   __shared__ uint32_t lds[G::LDS_DWORDS];
-  const int64_t j0 = (int64_t)blockIdx.x * TN_TN, i0 = (int64_t)blockIdx.y * TN_TM;
-  const int64_t kbeg = (int64_t)blockIdx.z * rows_per_split;
+  // all output tiles of one row range (split) run on one XCD, back to back, and walk the rows together: dY and X
+  // rows come from HBM once, the other tiles read them from that XCD's L2
+  const int64_t tk = cdiv(K, TN_TN), tiles = tk * cdiv(N, TN_TM), lidx = xcd_logical(blockIdx.x, gridDim.x);
+  if (lidx >= tiles * splits) return;
+  const int64_t split = lidx / tiles, tile = lidx % tiles;
+  const int64_t j0 = (tile % tk) * TN_TN, i0 = (tile / tk) * TN_TM;
+  const int64_t kbeg = split * rows_per_split;
   const int64_t kend = min(M, kbeg + rows_per_split);
   TransLoader<TN_TM, 256> al(dY, lddy, i0, N);
   TransLoader<TN_TN, 256> bl(X, ldx, j0, K);
   f32x16 acc[2][2];
   mainloop<2, 2>(al, bl, lds, kbeg, kend, acc);
-  float *out = slab + (int64_t)blockIdx.z * N * K;
+  float *out = slab + split * N * K;
   foreach_acc<2, 2>(acc, [&](int row, int col, float v) {
     int64_t i = i0 + row, j = j0 + col;
     if (i < N && j < K) out[i * K + j] = v;
@@ -394,7 +402,7 @@ extern "C" int svr_linear_bwd_data_bf16x3(const float *dY, int64_t lddy, const f
   uint16_t *hi = (uint16_t *)(((uintptr_t)workspace + 15) & ~(uintptr_t)15);
   uint16_t *mid = hi + N * K;
   hipLaunchKernelGGL(pack_planes_kernel, dim3((unsigned)cdiv(K * (N / 2), 256)), dim3(256), 0, s, W, ldw, hi, mid, N, K);
-  dim3 grid((unsigned)cdiv(K, NN_TN), (unsigned)cdiv(M, NN_TM));
+  dim3 grid(xcd_grid(cdiv(K, NN_TN) * cdiv(M, NN_TM)));
   hipLaunchKernelGGL(linear_nn_x3_kernel, grid, dim3(256), 0, s, dY, lddy, hi, mid, dX, lddx,
                      epilogue == SVR_EPI_MASK ? mask : nullptr, ldmask, M, N, K);
   return launch_status("linear_bwd_data_bf16x3");
@@ -415,8 +423,8 @@ extern "C" int svr_linear_bwd_weight_bf16x3(const float *dY, int64_t lddy, const
   int64_t rps;
   int splits = tn_splits(M, N, K, &rps);
   float *slab = (float *)workspace;
-  dim3 grid((unsigned)cdiv(K, TN_TN), (unsigned)cdiv(N, TN_TM), (unsigned)splits);
-  hipLaunchKernelGGL(linear_tn_x3_kernel, grid, dim3(256), 0, s, dY, lddy, X, ldx, slab, M, N, K, rps);
+  dim3 grid(xcd_grid(cdiv(K, TN_TN) * cdiv(N, TN_TM) * splits));
+  hipLaunchKernelGGL(linear_tn_x3_kernel, grid, dim3(256), 0, s, dY, lddy, X, ldx, slab, M, N, K, rps, splits);
   hipLaunchKernelGGL(slab_reduce_x3_kernel, dim3((unsigned)cdiv(N * K, 256)), dim3(256), 0, s, slab, dW, N, K, lddw, splits);
   if (db) colsum_launch(dY, lddy, db, slab + (int64_t)splits * N * K, M, N, s);
   return launch_status("linear_bwd_weight_bf16x3");

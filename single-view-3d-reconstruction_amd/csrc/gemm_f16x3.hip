@@ -77,7 +77,10 @@ __global__ __launch_bounds__(2 * TN, 1024 / (2 * TN) >= 4 ? 3 : 2) void linear_n
   const int lane = t & 63, wave = t >> 6;
   const int wr = wave / (TN / 64), wc = wave % (TN / 64);   // 2 x (TN/64) waves of 64 x 64
   const int l31 = lane & 31, lh = lane >> 5;
-  const int64_t n0 = (int64_t)blockIdx.x * TN, m0 = (int64_t)blockIdx.y * TM;
+  // both column tiles of a row panel run on one XCD, back to back: X comes from HBM once, then from that L2
+  const int64_t ntn = cdiv(N, TN), lidx = xcd_logical(blockIdx.x, gridDim.x);
+  if (lidx >= ntn * cdiv(M, TM)) return;
+  const int64_t n0 = (lidx % ntn) * TN, m0 = (lidx / ntn) * TM;
 
   // loaders (rows past the extent are clamped: they only feed outputs the guarded epilogue never stores)
   const float *xp[XPT];
@@ -225,7 +228,7 @@ extern "C" int svr_linear_fwd_f16x3(const float *X, int64_t ldx, const float *W,
   hipLaunchKernelGGL(split_w_kernel, dim3((unsigned)cdiv(N * (K / 2), 256)), dim3(256), 0, s, W, ldw, amax, p0, p1, N, K);
   const float *eb = epilogue == SVR_EPI_NONE ? nullptr : bias;
   const int relu = epilogue == SVR_EPI_BIAS_RELU ? 1 : 0;
-  dim3 grid((unsigned)cdiv(N, 128), (unsigned)cdiv(M, TM));
+  dim3 grid(xcd_grid(cdiv(N, 128) * cdiv(M, TM)));
   // SCHED = 2 (one MFMA, a slice of the split, one LDS store, ...): 2.39 ms at 400 000 x 2592 x 256 against 2.49 for
   // the compiler's own order and 2.50 for iglp_opt(0)
   hipLaunchKernelGGL((linear_nt_h3_kernel<128, 0, 2>), grid, dim3(256), 0, s, X, ldx, p0, p1, amax, eb, Y, ldy, M, N, K, relu);
