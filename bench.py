@@ -168,9 +168,9 @@ def main():
                                    f"{a.batch}/GPU, full 3D conv encoder + 6-level trilinear gather + occupancy MLP, "
                                    "fwd+bwd+grad all-reduce+Adam",
                        "global_batch": world * a.batch, "parallelism": f"dp{world}", "loss": loss, "points": a.dist,
-                       "arithmetic": "f32 storage everywhere; forward GEMMs/convs: bf16x6 split on the bf16 MFMA "
-                                     "(f32-equivalent, ~2e-7); backward dX/dW GEMMs and conv backward-data: bf16x3 split "
-                                     "(~1.5e-5 per product); conv weight gradients, conv_in, BN, gather/scatter: exact f32"},
+                       "arithmetic": "f32 storage everywhere; forward GEMMs/convs: 3-product f16 split on the f16 MFMA "
+                                     "(f32-level, ~3e-7 of f64); backward dX/dW GEMMs, conv backward-data and conv weight "
+                                     "gradients: bf16x3 split (~1.5e-5 per product); conv_in, BN, gather/scatter: exact f32"},
             "roofline": {"kernel": "gather_fwd_fused_kernel (svr_gather_trilinear_fwd, all 6 levels in one launch)", "bound": "hbm", "achieved": achieved,
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                          "ms_per_launch": gather_ms, "algorithmic_bytes_per_launch": alg_bytes, "traffic": traffic},
