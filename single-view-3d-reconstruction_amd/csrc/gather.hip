@@ -312,16 +312,33 @@ __device__ __forceinline__ void gather_bwd_runs_body(const LevelArgs L, const fl
 #pragma unroll
   for (int k = 0; k < 8; ++k) acc0[k] = acc1[k] = 0.f;
   int cur0 = -1, cur1 = -1;
-  auto flush = [&](int cur, const float (&acc)[8]) {
+  // flush the corners of a run whose bit is NOT set in `skip`
+  auto flush = [&](int cur, const float (&acc)[8], int skip) {
     if (cur >= 0) {
       const int x0 = (cur & 1023) - 1, y0 = ((cur >> 10) & 1023) - 1, z0 = (cur >> 20) - 1;
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
         const int z = z0 + (k >> 2), y = y0 + ((k >> 1) & 1), x = x0 + (k & 1);
-        if (z >= 0 && z < L.D && y >= 0 && y < L.H && x >= 0 && x < L.W)
+        if (!((skip >> k) & 1) && z >= 0 && z < L.D && y >= 0 && y < L.H && x >= 0 && x < L.W)
           atomicAdd(gb + (((size_t)z * L.H + y) * L.W + x) * C, acc[k]);
       }
     }
+  };
+  // Retire run `old`.  If the run that stays open (`surv`) is its face neighbour (base voxels one apart in x, y or
+  // z -- consecutive cells of the voxel order, or the two bases a displaced sample alternates between), the four
+  // corner voxels of the shared face are handed over in registers and only the other four go out as atomics.
+  auto retire = [&]() {  // retires slot 1 (cur1 / acc1); slot 0 stays open
+    int skip = 0;
+    if (cur1 >= 0 && cur0 >= 0) {
+      const int d = cur0 - cur1;
+      if (d == 1) { acc0[0] += acc1[1]; acc0[2] += acc1[3]; acc0[4] += acc1[5]; acc0[6] += acc1[7]; skip = 0xAA; }
+      else if (d == -1) { acc0[1] += acc1[0]; acc0[3] += acc1[2]; acc0[5] += acc1[4]; acc0[7] += acc1[6]; skip = 0x55; }
+      else if (d == 1024) { acc0[0] += acc1[2]; acc0[1] += acc1[3]; acc0[4] += acc1[6]; acc0[5] += acc1[7]; skip = 0xCC; }
+      else if (d == -1024) { acc0[2] += acc1[0]; acc0[3] += acc1[1]; acc0[6] += acc1[4]; acc0[7] += acc1[5]; skip = 0x33; }
+      else if (d == (1 << 20)) { acc0[0] += acc1[4]; acc0[1] += acc1[5]; acc0[2] += acc1[6]; acc0[3] += acc1[7]; skip = 0xF0; }
+      else if (d == -(1 << 20)) { acc0[4] += acc1[0]; acc0[5] += acc1[1]; acc0[6] += acc1[2]; acc0[7] += acc1[3]; skip = 0x0F; }
+    }
+    flush(cur1, acc1, skip);
   };
   constexpr int UNR = 4;
 #pragma unroll
@@ -358,7 +375,7 @@ __device__ __forceinline__ void gather_bwd_runs_body(const LevelArgs L, const fl
             for (int k = 0; k < 8; ++k) { const float t = acc0[k]; acc0[k] = acc1[k]; acc1[k] = t; }
             cur1 = cur0;
           } else {           // miss: retire the older run, age the recent one, open a new one
-            flush(cur1, acc1);
+            retire();
 #pragma unroll
             for (int k = 0; k < 8; ++k) { acc1[k] = acc0[k]; acc0[k] = 0.f; }
             cur1 = cur0;
@@ -375,8 +392,8 @@ __device__ __forceinline__ void gather_bwd_runs_body(const LevelArgs L, const fl
       }
     }
   }
-  flush(cur1, acc1);
-  flush(cur0, acc0);
+  retire();
+  flush(cur0, acc0, 0);
 }
 
 __host__ __device__ inline int64_t bwd_runs_waves(int C, int B, int N) {
