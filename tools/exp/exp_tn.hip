@@ -239,12 +239,12 @@ __device__ __forceinline__ void mainloop(AL &al, BL &bl, uint32_t *lds, int64_t 
   for (int64_t k0 = kbeg; k0 < kend; k0 += XK) {
     const bool more = k0 + XK < kend;
     if (more) {
-      al.load(k0 + XK, kend);
-      bl.load(k0 + XK, kend);
+      if (!(VARIANT & 1)) al.load(k0 + XK, kend);
+      if (!(VARIANT & 2)) bl.load(k0 + XK, kend);
     }
-    compute_step<WR, WC>(lds, acc);
+    if (!(VARIANT & 4)) compute_step<WR, WC>(lds, acc);
     __syncthreads();  // every wave has read its fragments
-    if (more) {
+    if (more && !(VARIANT & 8)) {
       al.store(lds);
       bl.store(lds + 2 * G::TM * XLW);
     }
@@ -351,9 +351,7 @@ __global__ __launch_bounds__(256) void linear_tn_x3_kernel(const float *__restri
   const int64_t tk = cdiv(K, TN_TN), tiles = tk * cdiv(N, TN_TM), lidx = xcd_logical(blockIdx.x, gridDim.x);
   if (lidx >= tiles * splits) return;
   const int64_t split = lidx / tiles, tile = lidx % tiles;
-  // the N-tiles of one K-tile (they read the same X columns) are neighbours in the dispatch order
-  const int64_t tn = cdiv(N, TN_TM);
-  const int64_t i0 = (tile % tn) * TN_TM, j0 = (tile / tn) * TN_TN;
+  const int64_t j0 = (tile % tk) * TN_TN, i0 = (tile / tk) * TN_TM;
   const int64_t kbeg = split * rows_per_split;
   const int64_t kend = min(M, kbeg + rows_per_split);
   TransLoader<TN_TM, 256> al(dY, lddy, i0, N);
@@ -386,48 +384,23 @@ int tn_splits(int64_t M, int64_t N, int64_t K, int64_t *rows_per_split) {
   return (int)cdiv(M, rps);
 }
 
-}  // namespace
 
-extern "C" int64_t svr_linear_bwd_data_bf16x3_workspace(int64_t N, int64_t K) { return 2 * N * K * (int64_t)sizeof(uint16_t) + 256; }
-
-extern "C" int svr_linear_bwd_data_bf16x3(const float *dY, int64_t lddy, const float *W, int64_t ldw, float *dX, int64_t lddx,
-                                          int64_t M, int64_t N, int64_t K, int epilogue, const float *mask, int64_t ldmask,
-                                          void *workspace, void *stream) {
-  if (M == 0) return SVR_OK;
-  SVR_CHECK(dY && W && dX && workspace, SVR_E_BADARG, "linear_bwd_data_bf16x3: null pointer");
-  SVR_CHECK(M >= 0 && N > 0 && K > 0 && N % XK == 0 && K % 4 == 0 && lddx % 4 == 0 && ldmask % 4 == 0, SVR_E_BADSHAPE,
-            "linear_bwd_data_bf16x3: M=%ld N=%ld K=%ld (need N %% 32 == 0, K and leading dims %% 4 == 0)", (long)M, (long)N, (long)K);
-  SVR_CHECK(lddy % 4 == 0 && ((uintptr_t)dY & 15) == 0, SVR_E_ALIGN, "linear_bwd_data_bf16x3: dY must be 16-byte aligned");
-  SVR_CHECK(epilogue == SVR_EPI_NONE || (epilogue == SVR_EPI_MASK && mask), SVR_E_BADARG, "linear_bwd_data_bf16x3: epilogue %d", epilogue);
-  if (M == 0) return SVR_OK;
-  hipStream_t s = (hipStream_t)stream;
-  uint16_t *hi = (uint16_t *)(((uintptr_t)workspace + 15) & ~(uintptr_t)15);
-  uint16_t *mid = hi + N * K;
-  hipLaunchKernelGGL(pack_planes_kernel, dim3((unsigned)cdiv(K * (N / 2), 256)), dim3(256), 0, s, W, ldw, hi, mid, N, K);
-  dim3 grid(xcd_grid(cdiv(K, NN_TN) * cdiv(M, NN_TM)));
-  hipLaunchKernelGGL(linear_nn_x3_kernel, grid, dim3(256), 0, s, dY, lddy, hi, mid, dX, lddx,
-                     epilogue == SVR_EPI_MASK ? mask : nullptr, ldmask, M, N, K);
-  return launch_status("linear_bwd_data_bf16x3");
 }
-
-extern "C" int64_t svr_linear_bwd_weight_bf16x3_workspace(int64_t M, int64_t N, int64_t K) {
-  int64_t rps;
-  int splits = tn_splits(M, N, K, &rps);
-  return ((int64_t)splits * N * K + colsum_workspace_floats(M, N)) * (int64_t)sizeof(float);
-}
-
-extern "C" int svr_linear_bwd_weight_bf16x3(const float *dY, int64_t lddy, const float *X, int64_t ldx, float *dW,
-                                            int64_t lddw, float *db, int64_t M, int64_t N, int64_t K, void *workspace,
-                                            void *stream) {
-  SVR_CHECK(dY && X && dW && workspace, SVR_E_BADARG, "linear_bwd_weight_bf16x3: null pointer");
-  SVR_CHECK(M > 0 && N > 0 && K > 0, SVR_E_BADSHAPE, "linear_bwd_weight_bf16x3: M=%ld N=%ld K=%ld", (long)M, (long)N, (long)K);
-  hipStream_t s = (hipStream_t)stream;
-  int64_t rps;
-  int splits = tn_splits(M, N, K, &rps);
-  float *slab = (float *)workspace;
+#include <cstdio>
+#include <vector>
+int main() {
+  const int64_t M = 400000, N = 256, K = 2592;
+  float *X, *dY, *slab;
+  hipMalloc(&X, M * K * 4); hipMalloc(&dY, M * N * 4);
+  int64_t rps; int splits = tn_splits(M, N, K, &rps);
+  hipMalloc(&slab, (size_t)splits * N * K * 4);
+  hipMemset(X, 0, M * K * 4); hipMemset(dY, 0, M * N * 4);
   dim3 grid(xcd_grid(cdiv(K, TN_TN) * cdiv(N, TN_TM) * splits));
-  hipLaunchKernelGGL(linear_tn_x3_kernel, grid, dim3(256), 0, s, dY, lddy, X, ldx, slab, M, N, K, rps, splits);
-  hipLaunchKernelGGL(slab_reduce_x3_kernel, dim3((unsigned)cdiv(N * K, 256)), dim3(256), 0, s, slab, dW, N, K, lddw, splits);
-  if (db) colsum_launch(dY, lddy, db, slab + (int64_t)splits * N * K, M, N, s);
-  return launch_status("linear_bwd_weight_bf16x3");
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  hipLaunchKernelGGL(linear_tn_x3_kernel, grid, dim3(256), 0, 0, dY, N, X, K, slab, M, N, K, rps, splits);
+  hipEventRecord(e0);
+  for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(linear_tn_x3_kernel, grid, dim3(256), 0, 0, dY, N, X, K, slab, M, N, K, rps, splits);
+  hipEventRecord(e1); hipEventSynchronize(e1);
+  float ms; hipEventElapsedTime(&ms, e0, e1); printf("tn variant %d: %.3f ms (splits %d)\n", VARIANT, ms / 3, splits);
+  return 0;
 }
