@@ -70,7 +70,7 @@ __device__ __forceinline__ bf16x8 frag(uint32_t a, uint32_t b, uint32_t c, uint3
 __global__ __launch_bounds__(NT) void conv3d_bwd_weight_x3_kernel(const float *__restrict__ in,
                                                                   const float *__restrict__ dout,
                                                                   float *__restrict__ slab, ConvShape s, int nbz, int nby,
-                                                                  int nbx, int co_tiles) {
+                                                                  int nbx, int co_tiles, float *__restrict__ dbpart) {
   __shared__ uint32_t lds[2 * BUF];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int l31 = lane & 31, lh = lane >> 5;
@@ -81,6 +81,10 @@ __global__ __launch_bounds__(NT) void conv3d_bwd_weight_x3_kernel(const float *_
 
   float4 ia[IN_IT / 2][2], da[DO_IT / 2][2];  // one half of the next brick in flight at a time
   int iok[IN_IT / 2], dok[DO_IT / 2];            // bit v: voxel v of the pair is inside the volume
+  // bias gradient: dout passes through this thread's registers exactly once per brick; its 4 channels (cg = t & 7
+  // for every item, 384 % 8 == 0) are summed here by the workgroups of the first ci tile -> no separate pass over dout
+  const bool want_db = dbpart != nullptr && ci0 == 0;
+  float4 dbs = make_float4(0.f, 0.f, 0.f, 0.f);
 
   auto load = [&](int64_t brick, int ph) {
     int64_t q = brick;
@@ -144,14 +148,19 @@ __global__ __launch_bounds__(NT) void conv3d_bwd_weight_x3_kernel(const float *_
       if (idx < DO_ITEMS) {
         const int row = idx >> 5, pr = (idx & 31) >> 3, cg = idx & 7;
         uint32_t *d = dbuf + (cg * 4) * COS + row * 4 + pr;
-        const float v0[4] = {da[j][0].x, da[j][0].y, da[j][0].z, da[j][0].w};
-        const float v1[4] = {da[j][1].x, da[j][1].y, da[j][1].z, da[j][1].w};
+        float v0[4] = {da[j][0].x, da[j][0].y, da[j][0].z, da[j][0].w};
+        float v1[4] = {da[j][1].x, da[j][1].y, da[j][1].z, da[j][1].w};
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
+          v0[c] = (dok[j] & 1) ? v0[c] : 0.f;
+          v1[c] = (dok[j] & 2) ? v1[c] : 0.f;
           uint32_t h, m;
-          split2((dok[j] & 1) ? v0[c] : 0.f, (dok[j] & 2) ? v1[c] : 0.f, h, m);
+          split2(v0[c], v1[c], h, m);
           d[c * COS] = h;
           d[DO_PLANE + c * COS] = m;
+        }
+        if (want_db) {
+          dbs.x += v0[0] + v1[0]; dbs.y += v0[1] + v1[1]; dbs.z += v0[2] + v1[2]; dbs.w += v0[3] + v1[3];
         }
       }
     }
@@ -222,6 +231,17 @@ __global__ __launch_bounds__(NT) void conv3d_bwd_weight_x3_kernel(const float *_
     cur ^= 1;
   }
 
+  if (want_db) {  // fixed-order sum of the 48 threads per channel group through LDS (free after the last barrier)
+    float *sred = reinterpret_cast<float *>(lds);
+    sred[t * 4 + 0] = dbs.x; sred[t * 4 + 1] = dbs.y; sred[t * 4 + 2] = dbs.z; sred[t * 4 + 3] = dbs.w;
+    __syncthreads();
+    if (t < 32) {
+      const int cg = t >> 2, c = t & 3;
+      float sum = 0.f;
+      for (int i = 0; i < NT / 8; ++i) sum += sred[(i * 8 + cg) * 4 + c];
+      if (co0 + t < s.Co) dbpart[(int64_t)blockIdx.x * s.Co + co0 + t] = sum;
+    }
+  }
   // slab layout shared with conv3d.hip's reduce kernel: [part][tap][pair][32 ci][32 co]
   const int pairs = gridDim.y;
   const int64_t part = (int64_t)blockIdx.x * 2 + half;
@@ -232,6 +252,15 @@ __global__ __launch_bounds__(NT) void conv3d_bwd_weight_x3_kernel(const float *_
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[((r & 3) + 8 * (r >> 2) + 4 * lh) * 32 + l31] = acc[i][r];
   }
+}
+
+// db[co] = ordered f64 sum of the workgroups' partial bias gradients
+__global__ void db_reduce_kernel(const float *__restrict__ dbpart, float *__restrict__ db, int Co, int parts) {
+  const int co = blockIdx.x * blockDim.x + threadIdx.x;
+  if (co >= Co) return;
+  double sum = 0.0;
+  for (int p = 0; p < parts; ++p) sum += (double)dbpart[(int64_t)p * Co + co];
+  db[co] = (float)sum;
 }
 
 // persistent workgroups per channel-tile pair: one workgroup per CU in total (LDS bound)
@@ -248,8 +277,8 @@ int x3_parts(int B, int D, int H, int W, int Ci, int Co) {
 extern "C" int64_t svr_conv3d_k3_bwd_weight_bf16x3_workspace(int32_t B, int32_t D, int32_t H, int32_t W, int32_t Ci,
                                                              int32_t Co) {
   int64_t tiles = cdiv(Ci, 32) * cdiv(Co, 32);
-  int64_t cs = colsum_workspace_floats((int64_t)B * D * H * W, Co);
-  return ((int64_t)x3_parts(B, D, H, W, Ci, Co) * 2 * 27 * tiles * 1024 + cs) * (int64_t)sizeof(float);
+  const int64_t parts = x3_parts(B, D, H, W, Ci, Co);
+  return (parts * 2 * 27 * tiles * 1024 + parts * Co) * (int64_t)sizeof(float);
 }
 
 extern "C" int svr_conv3d_k3_bwd_weight_bf16x3(const float *in, const float *dout, float *dWp, float *db, int32_t B,
@@ -266,9 +295,10 @@ extern "C" int svr_conv3d_k3_bwd_weight_bf16x3(const float *in, const float *dou
   const int nbz = (int)cdiv(D, BRZ), nby = (int)cdiv(H, BRY), nbx = (int)cdiv(W, BRX);
   const int parts = x3_parts(B, D, H, W, Ci, Co);
   float *slab = (float *)workspace;
+  float *dbpart = db ? slab + (int64_t)parts * 2 * 27 * cit * cot * 1024 : nullptr;
   hipLaunchKernelGGL(conv3d_bwd_weight_x3_kernel, dim3((unsigned)parts, (unsigned)(cit * cot)), dim3(NT), 0, s, in, dout,
-                     slab, sh, nbz, nby, nbx, cot);
+                     slab, sh, nbz, nby, nbx, cot, dbpart);
   conv3d_bwd_weight_reduce_launch(slab, dWp, Ci, Co, cit, cot, parts * 2, s);
-  if (db) colsum_launch(dout, Co, db, slab + (int64_t)parts * 2 * 27 * cit * cot * 1024, (int64_t)B * D * H * W, Co, s);
+  if (db) hipLaunchKernelGGL(db_reduce_kernel, dim3((unsigned)cdiv(Co, 64)), dim3(64), 0, s, dbpart, db, Co, parts);
   return launch_status("conv3d_bwd_weight_bf16x3");
 }

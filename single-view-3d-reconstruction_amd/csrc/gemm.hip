@@ -224,6 +224,52 @@ __global__ __launch_bounds__(256) void fc_out_bwd_kernel(const float *__restrict
   }
 }
 
+// K == 256 form: a workgroup row = 64 threads x float4, four rows per pass, four passes in flight; the rows'
+// dlogits are staged in LDS first (one dependent row_map -> dlogits lookup per row instead of per thread and row).
+__global__ __launch_bounds__(256) void fc_out_bwd_k256_kernel(const float *__restrict__ H, int64_t ldh,
+                                                              const float *__restrict__ w,
+                                                              const float *__restrict__ dlogits,
+                                                              const int32_t *__restrict__ row_map, float *__restrict__ dH,
+                                                              int64_t lddh, float *__restrict__ part, int64_t M,
+                                                              int64_t rows_per_block) {
+  __shared__ float gs[512];
+  __shared__ float red[4][257];
+  const int t = threadIdx.x, c4 = (t & 63) * 4, rs = t >> 6;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  const int nr = (int)min(rows_per_block, M - r0);
+  for (int i = t; i < nr; i += 256) gs[i] = dlogits[row_map ? (int64_t)row_map[r0 + i] : r0 + i];
+  __syncthreads();
+  const float4 wk = *reinterpret_cast<const float4 *>(w + c4);
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int i0 = rs; i0 < nr; i0 += 16) {
+    float4 h[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = min(i0 + 4 * u, nr - 1);
+      h[u] = *reinterpret_cast<const float4 *>(H + (r0 + i) * ldh + c4);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + 4 * u;
+      if (i < nr) {
+        const float g = gs[i];
+        s.x += g * h[u].x; s.y += g * h[u].y; s.z += g * h[u].z; s.w += g * h[u].w;
+        *reinterpret_cast<float4 *>(dH + (r0 + i) * lddh + c4) =
+            make_float4(h[u].x > 0.f ? g * wk.x : 0.f, h[u].y > 0.f ? g * wk.y : 0.f, h[u].z > 0.f ? g * wk.z : 0.f,
+                        h[u].w > 0.f ? g * wk.w : 0.f);
+      }
+    }
+  }
+  red[rs][c4] = s.x; red[rs][c4 + 1] = s.y; red[rs][c4 + 2] = s.z; red[rs][c4 + 3] = s.w;
+  __syncthreads();
+  part[(int64_t)blockIdx.x * 257 + t] = ((red[0][t] + red[1][t]) + red[2][t]) + red[3][t];
+  if (t == 0) {
+    float sb = 0.f;
+    for (int i = 0; i < nr; ++i) sb += gs[i];
+    part[(int64_t)blockIdx.x * 257 + 256] = sb;
+  }
+}
+
 __global__ __launch_bounds__(256) void fc_out_bwd_final_kernel(const float *__restrict__ part, float *__restrict__ dw,
                                                                float *__restrict__ db, int64_t K, int blocks) {
   const int64_t k = blockIdx.x;  // 0..K (K = the bias slot)
@@ -389,7 +435,10 @@ extern "C" int svr_fc_out_bwd(const float *H, int64_t ldh, const float *w, const
   hipStream_t s = (hipStream_t)stream;
   int blocks = (int)cdiv(M, FCO_ROWS);
   float *part = (float *)workspace;
-  hipLaunchKernelGGL(fc_out_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, s, H, ldh, w, dlogits, row_map, dH, lddh, part, M, K, FCO_ROWS);
+  if (K == 256 && ldh % 4 == 0 && lddh % 4 == 0 && ((((uintptr_t)H | (uintptr_t)dH | (uintptr_t)w)) & 15) == 0)
+    hipLaunchKernelGGL(fc_out_bwd_k256_kernel, dim3((unsigned)blocks), dim3(256), 0, s, H, ldh, w, dlogits, row_map, dH, lddh, part, M, FCO_ROWS);
+  else
+    hipLaunchKernelGGL(fc_out_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, s, H, ldh, w, dlogits, row_map, dH, lddh, part, M, K, FCO_ROWS);
   hipLaunchKernelGGL(fc_out_bwd_final_kernel, dim3((unsigned)(K + 1)), dim3(256), 0, s, part, dw, db, K, blocks);
   return launch_status("fc_out_bwd");
 }

@@ -371,8 +371,14 @@ __global__ void slab_reduce_x3_kernel(const float *__restrict__ slab, float *__r
                                       int64_t ldo, int splits) {
   int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= rows * cols) return;
-  float s = 0.f;
-  for (int z = 0; z < splits; ++z) s += slab[(int64_t)z * rows * cols + idx];
+  float s = 0.f;  // fixed order; four slabs in flight
+  const int64_t st = rows * cols;
+  int z = 0;
+  for (; z + 4 <= splits; z += 4) {
+    const float a = slab[z * st + idx], b = slab[(z + 1) * st + idx], c = slab[(z + 2) * st + idx], d = slab[(z + 3) * st + idx];
+    s = (((s + a) + b) + c) + d;
+  }
+  for (; z < splits; ++z) s += slab[z * st + idx];
   out[(idx / cols) * ldo + (idx % cols)] = s;
 }
 

@@ -31,7 +31,7 @@ __device__ __forceinline__ uint64_t spread3_10(uint32_t v) {  // 10 bits -> ever
 // floor(source index)+1 of the undisplaced sample in a D x H x W volume (same arithmetic as gather.hip;
 // a last-bit difference would only cost a run split, never correctness).
 __global__ void sort_key_kernel(const float *__restrict__ points, uint64_t *__restrict__ keys, int32_t *__restrict__ vals,
-                                int64_t total, int N, int mode, int D, int H, int W, int ac) {
+                                int64_t total, int N, int mode, int D, int H, int W, int ac, int code_bits) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
   uint32_t q[3];  // z, y, x
@@ -55,7 +55,7 @@ __global__ void sort_key_kernel(const float *__restrict__ points, uint64_t *__re
   }
   // points[...,0] walks the slowest volume axis (z), [...,2] the fastest (x): x in the low bit
   uint64_t m = spread3_10(q[2]) | (spread3_10(q[1]) << 1) | (spread3_10(q[0]) << 2);
-  keys[i] = ((uint64_t)(i / N) << 30) | m;
+  keys[i] = ((uint64_t)(i / N) << code_bits) | m;  // only the occupied bits are sorted: fewer radix passes
   vals[i] = (int32_t)i;
 }
 
@@ -69,10 +69,19 @@ __global__ void permute_points_kernel(const float *__restrict__ points, const in
   out[i * 3 + 2] = points[src * 3 + 2];
 }
 
-int key_bits(int B) {
+// bits of the interleaved cell code: 3 x (bits of the largest per-axis cell index)
+int code_bits(int mode, int D, int H, int W) {
+  int hi = (1 << MORTON_BITS) - 1;
+  if (mode == 1) hi = D > H ? (D > W ? D : W) : (H > W ? H : W);
+  int nb = 1;
+  while ((1 << nb) <= hi) ++nb;
+  return 3 * nb;
+}
+
+int key_bits(int B, int cbits) {
   int bb = 0;
   while ((1LL << bb) < B) ++bb;
-  return 30 + bb;
+  return cbits + bb;
 }
 
 size_t rocprim_temp_bytes(int64_t total, int bits) {
@@ -98,10 +107,11 @@ int sort_points(const float *points, int32_t *order, float *sorted_points, int B
   w += align256(total * 8);
   int32_t *vals_in = (int32_t *)w;
   w += align256(total * 4);
-  int bits = key_bits(B);
+  const int cbits = code_bits(mode, D, H, W);
+  int bits = key_bits(B, cbits);
   size_t tmp = rocprim_temp_bytes(total, bits);
   hipLaunchKernelGGL(sort_key_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, s, points, keys_in, vals_in, total, N,
-                     mode, D, H, W, ac);
+                     mode, D, H, W, ac, cbits);
   hipError_t e = rocprim::radix_sort_pairs((void *)w, tmp, keys_in, keys_out, vals_in, order, (size_t)total, 0, bits, s);
   SVR_CHECK(e == hipSuccess, (int)e, "%s: radix sort failed: %s", what, hipGetErrorString(e));
   if (sorted_points)
@@ -115,7 +125,7 @@ int sort_points(const float *points, int32_t *order, float *sorted_points, int B
 extern "C" int64_t svr_points_morton_order_workspace(int32_t B, int32_t N) {
   int64_t total = (int64_t)B * N;
   if (total <= 0) return 256;
-  return 2 * align256(total * 8) + align256(total * 4) + align256((int64_t)rocprim_temp_bytes(total, key_bits(B))) + 256;
+  return 2 * align256(total * 8) + align256(total * 4) + align256((int64_t)rocprim_temp_bytes(total, key_bits(B, 30))) + 256;
 }
 
 extern "C" int svr_points_morton_order(const float *points, int32_t *order, float *sorted_points, int32_t B, int32_t N,
