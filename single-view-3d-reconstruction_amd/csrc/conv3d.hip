@@ -427,11 +427,13 @@ __global__ __launch_bounds__(256) void conv3d_c1_bwd_weight_kernel(const float *
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) void conv3d_c1_bwd_weight_co16_kernel(const float *__restrict__ in,
                                                                         const float *__restrict__ dout,
-                                                                        float *__restrict__ slab, ConvShape s) {
+                                                                        float *__restrict__ slab, ConvShape s,
+                                                                        float *__restrict__ dbpart) {
   __shared__ float red[4 * 1024];
   const int chunk = blockIdx.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int l15 = lane & 15, kq = lane >> 4;
+  float dbs = 0.f;  // bias gradient of channel l15 over this lane's voxels (dout is read exactly once, here)
   for (int e = threadIdx.x; e < 4096; e += 256) red[e] = 0.f;
   int dz[2], dy[2], dx[2];
   bool tok[2];
@@ -469,6 +471,7 @@ __global__ __launch_bounds__(256) void conv3d_c1_bwd_weight_co16_kernel(const fl
         const bool bok = full || x < s.W;
         const float bq = dob[(bok ? x : 0) * 16 + l15];
         bv[u] = bok ? bq : 0.f;
+        dbs += bv[u];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           const int xs = x + dx[h], xc = min(max(xs, 0), s.W - 1);
@@ -491,6 +494,31 @@ __global__ __launch_bounds__(256) void conv3d_c1_bwd_weight_co16_kernel(const fl
   __syncthreads();
   float *o = slab + (int64_t)chunk * 1024;
   for (int e = threadIdx.x; e < 1024; e += 256) o[e] = ((red[e] + red[1024 + e]) + red[2048 + e]) + red[3072 + e];
+  if (dbpart) {  // fixed-order sum of the 16 (wave, voxel-slot) partials per channel
+    __syncthreads();
+    red[threadIdx.x] = dbs;
+    __syncthreads();
+    if (threadIdx.x < 16) {
+      float sum = 0.f;
+      for (int i = 0; i < 16; ++i) sum += red[i * 16 + threadIdx.x];
+      dbpart[(int64_t)chunk * 16 + threadIdx.x] = sum;
+    }
+  }
+}
+
+// db[co] = ordered f64 sum of the per-workgroup partial bias gradients [parts][Co]
+__global__ void conv3d_db_reduce_kernel(const float *__restrict__ dbpart, float *__restrict__ db, int Co, int parts) {
+  __shared__ double red[256];
+  const int co = blockIdx.x;
+  double sum = 0.0;
+  for (int p = threadIdx.x; p < parts; p += 256) sum += (double)dbpart[(int64_t)p * Co + co];
+  red[threadIdx.x] = sum;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) db[co] = (float)red[0];
 }
 
 // one workgroup per (tap, co): f64 tree over the per-wave partial slabs (fixed order)
@@ -600,7 +628,7 @@ extern "C" int64_t svr_conv3d_k3_bwd_weight_workspace(int32_t B, int32_t D, int3
   int64_t chunks = cdiv(nrows, BW_ROWS);
   int64_t M = nrows * W;
   int64_t cs = colsum_workspace_floats(M, Co);
-  if (Ci == 1) return (chunks * 1024 + cs) * (int64_t)sizeof(float);
+  if (Ci == 1) return (chunks * 1024 + (cs > chunks * 16 ? cs : chunks * 16)) * (int64_t)sizeof(float);
   int64_t tiles = cdiv(Ci, 32) * cdiv(Co, 32);
   return ((int64_t)bw_brick_parts(B, D, H, W, Ci, Co) * 27 * tiles * 1024 + cs) * (int64_t)sizeof(float);
 }
@@ -617,9 +645,14 @@ extern "C" int svr_conv3d_k3_bwd_weight(const float *in, const float *dout, floa
   int64_t slab_floats;
   if (Ci == 1) {
     SVR_CHECK(Co <= 32, SVR_E_UNSUPPORTED, "conv3d_bwd_weight: Ci=1 needs Co<=32 (got %d)", Co);
-    if (Co == 16)
-      hipLaunchKernelGGL(conv3d_c1_bwd_weight_co16_kernel, dim3(chunks), dim3(256), 0, s, in, dout, slab, sh);
-    else
+    if (Co == 16) {
+      float *dbpart = db ? slab + (int64_t)chunks * 1024 : nullptr;  // the colsum scratch is at least chunks * 16 floats
+      hipLaunchKernelGGL(conv3d_c1_bwd_weight_co16_kernel, dim3(chunks), dim3(256), 0, s, in, dout, slab, sh, dbpart);
+      if (db) {
+        hipLaunchKernelGGL(conv3d_db_reduce_kernel, dim3(16), dim3(256), 0, s, dbpart, db, 16, chunks);
+        db = nullptr;  // done
+      }
+    } else
       hipLaunchKernelGGL(conv3d_c1_bwd_weight_kernel, dim3(chunks), dim3(256), 0, s, in, dout, slab, sh);
     hipLaunchKernelGGL(conv3d_c1_bwd_weight_reduce_kernel, dim3(27 * Co), dim3(256), 0, s, slab, dWp, Co, chunks);
     slab_floats = (int64_t)chunks * 1024;
