@@ -100,6 +100,16 @@ __device__ __forceinline__ void gather_fwd_body(const LevelArgs L, const float *
   Weights w = corner_weights(c);
   const float *vb = L.vol + (size_t)b * L.D * L.H * L.W * C;
   if constexpr (C >= 4) {
+    // All eight corner loads are issued first, unconditionally and from clamped coordinates: a load inside the
+    // bounds branch is waited for at the end of that branch, i.e. eight memory latencies in a row.  The sum keeps
+    // ATen's order and still SKIPS out-of-range corners (bit-exact with grid_sample's zero padding).
+    float4 v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int z = min(max(w.z0 + (k >> 2), 0), L.D - 1), y = min(max(w.y0 + ((k >> 1) & 1), 0), L.H - 1),
+                x = min(max(w.x0 + (k & 1), 0), L.W - 1);
+      v[k] = *reinterpret_cast<const float4 *>(vb + (((size_t)z * L.H + y) * L.W + x) * C + q * 4);
+    }
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int dz = 0; dz < 2; ++dz)
@@ -110,11 +120,11 @@ __device__ __forceinline__ void gather_fwd_body(const LevelArgs L, const float *
           int z = w.z0 + dz, y = w.y0 + dy, x = w.x0 + dx;
           if (z >= 0 && z < L.D && y >= 0 && y < L.H && x >= 0 && x < L.W) {
             float wt = (w.wx[dx] * w.wy[dy]) * w.wz[dz];
-            float4 v = *reinterpret_cast<const float4 *>(vb + (((size_t)z * L.H + y) * L.W + x) * C + q * 4);
-            acc.x = acc.x + v.x * wt;
-            acc.y = acc.y + v.y * wt;
-            acc.z = acc.z + v.z * wt;
-            acc.w = acc.w + v.w * wt;
+            const float4 u = v[dz * 4 + dy * 2 + dx];
+            acc.x = acc.x + u.x * wt;
+            acc.y = acc.y + u.y * wt;
+            acc.z = acc.z + u.z * wt;
+            acc.w = acc.w + u.w * wt;
           }
         }
     *reinterpret_cast<float4 *>(feat + pn * row_stride + L.col + j * C + q * 4) = acc;
@@ -362,7 +372,9 @@ __device__ __forceinline__ void gather_bwd_runs_body(const LevelArgs L, const fl
           pn = (int64_t)b * N + n0 + s * CW + tb + u;
         }
         const bool live = s * CW + tb + u < cnt;
-        gq[u] = live ? gfeat[pn * row_stride + coff] : 0.f;
+        if (!live) pn = (int64_t)b * N;  // any valid row: the value is discarded (unconditional load, no branch)
+        const float gload = gfeat[pn * row_stride + coff];
+        gq[u] = live ? gload : 0.f;
         if (!live) kq[u] = -1;
       }
 #pragma unroll
