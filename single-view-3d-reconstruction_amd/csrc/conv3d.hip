@@ -463,26 +463,32 @@ __global__ __launch_bounds__(256) void conv3d_c1_bwd_weight_co16_kernel(const fl
       aoff[h] = rok[h] ? (zz * s.H + yy) * s.W : 0;
     }
     for (int x0 = 0; x0 < s.W; x0 += 32) {  // 8 groups of 4 voxels: 24 loads in flight, then 16 MFMAs
-      float av[2][8], bv[8];
       const bool full = x0 + 32 <= s.W;  // wave-uniform
+      // phase 1: all 24 loads, unconditional, from clamped coordinates, plus the validity masks; phase 2 (behind a
+      // scheduling barrier, otherwise the compiler interleaves load / wait / MFMA one at a time): mask and multiply.
+      // The loaded value is always consumed (bit mask, not a select) so the load cannot be sunk into a branch.
+      float ar[2][8], br[8];
+      uint32_t am[2][8], bm[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         const int x = x0 + 4 * u + kq;
         const bool bok = full || x < s.W;
-        const float bq = dob[(bok ? x : 0) * 16 + l15];
-        bv[u] = bok ? bq : 0.f;
-        dbs += bv[u];
+        br[u] = dob[(bok ? x : 0) * 16 + l15];
+        bm[u] = bok ? 0xffffffffu : 0u;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           const int xs = x + dx[h], xc = min(max(xs, 0), s.W - 1);
-          const float a = inb[aoff[h] + xc];
-          av[h][u] = (rok[h] && xs == xc && bok) ? a : 0.f;
+          ar[h][u] = inb[aoff[h] + xc];
+          am[h][u] = (rok[h] && xs == xc && bok) ? 0xffffffffu : 0u;
         }
       }
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
-        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0][u], bv[u], acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1][u], bv[u], acc[1], 0, 0, 0);
+        const float bv = __uint_as_float(__float_as_uint(br[u]) & bm[u]);
+        dbs += bv;
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(__float_as_uint(ar[0][u]) & am[0][u]), bv, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(__float_as_uint(ar[1][u]) & am[1][u]), bv, acc[1], 0, 0, 0);
       }
     }
   }

@@ -18,11 +18,20 @@ for f in files:
             cur = m.group(1); stats[cur] = [0, 0]
         if cur and ("global_load" in l or "buffer_load" in l):
             stats[cur][0] += 1
-            j = i + 1
-            while j < len(lines) and (not lines[j].strip() or lines[j].strip().startswith(";")):
-                j += 1
-            if "vmcnt(0)" in lines[j]:
-                stats[cur][1] += 1
+            # a vmcnt(0) within the next few instructions and before any other load = this load is waited for alone
+            seen = 0
+            for j in range(i + 1, min(i + 40, len(lines))):
+                t = lines[j].strip()
+                if not t or t.startswith(";") or t.endswith(":") or t.startswith("."):
+                    continue
+                if "global_load" in t or "buffer_load" in t:
+                    break
+                if "vmcnt(0)" in t:
+                    stats[cur][1] += 1
+                    break
+                seen += 1
+                if seen >= 8:
+                    break
     for k, (a, b) in stats.items():
         if b:
             print(f"{f}: {k[:90]} loads={a} immediately-waited={b}")
