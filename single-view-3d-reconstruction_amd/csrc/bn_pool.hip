@@ -125,12 +125,23 @@ __global__ __launch_bounds__(256) void bn_apply_pool_kernel(const float *__restr
   float4 best = make_float4(0.f, 0.f, 0.f, 0.f);
   int am[4] = {0, 0, 0, 0};
   bool first = true;
+  // the cell's eight voxels are loaded up front, unconditionally, from clamped coordinates (loads inside the bounds
+  // branch would be waited for one at a time); the scheduling barrier keeps the compiler from re-serialising them
+  float4 in8[8];
+  int64_t off8[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int z = min(cz * 2 + (k >> 2), v.D - 1), yy = min(cy * 2 + ((k >> 1) & 1), v.H - 1), xx = min(cx * 2 + (k & 1), v.W - 1);
+    off8[k] = (((b * v.D + z) * v.H + yy) * v.W + xx) * v.C + q * 4;
+    in8[k] = *reinterpret_cast<const float4 *>(x + off8[k]);
+  }
+  __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
     int z = cz * 2 + (k >> 2), yy = cy * 2 + ((k >> 1) & 1), xx = cx * 2 + (k & 1);
     if (z < v.D && yy < v.H && xx < v.W) {
-      int64_t off = (((b * v.D + z) * v.H + yy) * v.W + xx) * v.C + q * 4;
-      float4 a = *reinterpret_cast<const float4 *>(x + off);
+      const int64_t off = off8[k];
+      const float4 a = in8[k];
       float4 o;
       o.x = a.x * sc.x + sh.x; o.y = a.y * sc.y + sh.y; o.z = a.z * sc.z + sh.z; o.w = a.w * sc.w + sh.w;
       *reinterpret_cast<float4 *>(y + off) = o;
@@ -191,13 +202,30 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(const float *__restrict__ x
       am = *reinterpret_cast<const uint32_t *>(argmax + po);
     }
     float f1[4] = {0, 0, 0, 0}, f2[4] = {0, 0, 0, 0};
+    // all 16 loads of the cell first (see bn_apply_pool_kernel)
+    float4 a8[8], g8[8];
+    int64_t off8[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int z = min(cz * 2 + (k >> 2), v.D - 1), yy = min(cy * 2 + ((k >> 1) & 1), v.H - 1), xx = min(cx * 2 + (k & 1), v.W - 1);
+      off8[k] = (((b * v.D + z) * v.H + yy) * v.W + xx) * v.C + q * 4;
+      a8[k] = *reinterpret_cast<const float4 *>(x + off8[k]);
+    }
+    if (dy) {  // wave-uniform
+#pragma unroll
+      for (int k = 0; k < 8; ++k) g8[k] = *reinterpret_cast<const float4 *>(dy + off8[k]);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) g8[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       int z = cz * 2 + (k >> 2), yy = cy * 2 + ((k >> 1) & 1), xx = cx * 2 + (k & 1);
       if (z < v.D && yy < v.H && xx < v.W) {
-        int64_t off = (((b * v.D + z) * v.H + yy) * v.W + xx) * v.C + q * 4;
-        float4 a = *reinterpret_cast<const float4 *>(x + off);
-        float4 g = dy ? *reinterpret_cast<const float4 *>(dy + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const int64_t off = off8[k];
+        const float4 a = a8[k];
+        float4 g = g8[k];
         if ((am & 0xff) == (uint32_t)k) g.x += dp.x;
         if (((am >> 8) & 0xff) == (uint32_t)k) g.y += dp.y;
         if (((am >> 16) & 0xff) == (uint32_t)k) g.z += dp.z;
