@@ -28,10 +28,25 @@ __global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float *__re
   int64_t r = r0 + rl;
   while (r < r1) {
     float fs[4] = {0, 0, 0, 0}, fss[4] = {0, 0, 0, 0};
-    for (int it = 0; it < 16 && r < r1; ++it, r += RL) {
-      float4 v = *reinterpret_cast<const float4 *>(x + r * C + q * 4);
-      fs[0] += v.x; fs[1] += v.y; fs[2] += v.z; fs[3] += v.w;
-      fss[0] += v.x * v.x; fss[1] += v.y * v.y; fss[2] += v.z * v.z; fss[3] += v.w * v.w;
+    // f32 runs of 16 rows, as two batches of 8 loads issued together (clamped rows, masked afterwards): a load per
+    // loop iteration behind the `r < r1` branch would be waited for before the next one is issued
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      float4 v[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int64_t rr = r + (int64_t)i * RL;
+        v[i] = *reinterpret_cast<const float4 *>(x + (rr < r1 ? rr : r1 - 1) * C + q * 4);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        if (r + (int64_t)i * RL < r1) {
+          fs[0] += v[i].x; fs[1] += v[i].y; fs[2] += v[i].z; fs[3] += v[i].w;
+          fss[0] += v[i].x * v[i].x; fss[1] += v[i].y * v[i].y; fss[2] += v[i].z * v[i].z; fss[3] += v[i].w * v[i].w;
+        }
+      }
+      r += 8 * (int64_t)RL;
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) { s[i] += (double)fs[i]; ss[i] += (double)fss[i]; }

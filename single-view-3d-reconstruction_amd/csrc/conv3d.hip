@@ -65,11 +65,22 @@ __global__ __launch_bounds__(256) void conv3d_c1_mfma_kernel(const float *__rest
   const int64_t b = q / nbz;
   const int z0 = bz * C1B, y0 = by * C1B, x0 = bx * C1B;
   const float *inb = in + b * (int64_t)s.D * s.H * s.W;
-  for (int idx = t; idx < C1H * C1H * C1H; idx += 256) {
-    const int hx = idx % C1H, hy = (idx / C1H) % C1H, hz = idx / (C1H * C1H);
-    const int gz = z0 + hz - 1, gy = y0 + hy - 1, gx = x0 + hx - 1;
-    tile[idx] = (gz >= 0 && gz < s.D && gy >= 0 && gy < s.H && gx >= 0 && gx < s.W)
-                    ? inb[((int64_t)gz * s.H + gy) * s.W + gx] : 0.f;
+  {  // halo tile: the four loads of a thread are issued together (clamped coordinates), zero padding applied after
+    constexpr int NH = C1H * C1H * C1H, HIT = (NH + 255) / 256;
+    float hv[HIT];
+    uint32_t hok = 0;
+#pragma unroll
+    for (int i = 0; i < HIT; ++i) {
+      const int idx = min(t + 256 * i, NH - 1);
+      const int hx = idx % C1H, hy = (idx / C1H) % C1H, hz = idx / (C1H * C1H);
+      const int gz = z0 + hz - 1, gy = y0 + hy - 1, gx = x0 + hx - 1;
+      if (gz >= 0 && gz < s.D && gy >= 0 && gy < s.H && gx >= 0 && gx < s.W) hok |= 1u << i;
+      hv[i] = inb[((int64_t)min(max(gz, 0), s.D - 1) * s.H + min(max(gy, 0), s.H - 1)) * s.W + min(max(gx, 0), s.W - 1)];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < HIT; ++i)
+      if (t + 256 * i < NH) tile[t + 256 * i] = ((hok >> i) & 1u) ? hv[i] : 0.f;
   }
   float bw[14];
   int toff[14];
