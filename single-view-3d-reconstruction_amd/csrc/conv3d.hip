@@ -56,6 +56,7 @@ __global__ __launch_bounds__(256) void conv3d_c1_mfma_kernel(const float *__rest
                                                              const float *__restrict__ bias, float *__restrict__ out,
                                                              ConvShape s, int nbz, int nby, int nbx, int mode) {
   __shared__ float tile[C1H * C1H * C1H];
+  __shared__ __attribute__((aligned(16))) float otile[4 * 32 * (CO + 4)];  // per-wave output staging, rows padded by 16 B
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int l31 = lane & 31, lh = lane >> 5;
   int64_t q = blockIdx.x;
@@ -102,19 +103,33 @@ __global__ __launch_bounds__(256) void conv3d_c1_mfma_kernel(const float *__rest
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
     for (int kp = 0; kp < 14; ++kp) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(tile[hb + toff[kp]], bw[kp], acc, 0, 0, 0);
+    // epilogue through LDS: the MFMA layout would store 64-byte pieces (16 channels of one voxel per half wave, 16
+    // instructions per tile); restaged as [voxel][co], every lane writes one float4 and a wave-instruction covers
+    // two 512-byte x-rows of the brick
+    float *ot = otile + wave * (32 * (CO + 4));
     if (l31 < CO) {
-      const int gz = z0 + vz;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int i = (r & 3) + 8 * (r >> 2) + 4 * lh;
-        const int gy = y0 + yh * 4 + i / C1B, gx = x0 + i % C1B;
-        if (gz < s.D && gy < s.H && gx < s.W) {
-          float v = acc[r] + bv;
-          if (mode == SVR_EPI_BIAS_RELU) v = fmaxf(v, 0.f);
-          out[((((int64_t)b * s.D + gz) * s.H + gy) * s.W + gx) * CO + l31] = v;
-        }
+        float v = acc[r] + bv;
+        if (mode == SVR_EPI_BIAS_RELU) v = fmaxf(v, 0.f);
+        ot[i * (CO + 4) + l31] = v;
       }
     }
+    __syncthreads();
+    {
+      constexpr int G4 = CO / 4, VPI = 64 / G4;  // float4 groups per voxel, voxels per wave-instruction
+      const int gz = z0 + vz;
+#pragma unroll
+      for (int p = 0; p < 32 / VPI; ++p) {
+        const int i = p * VPI + lane / G4, c4 = (lane % G4) * 4;
+        const int gy = y0 + yh * 4 + i / C1B, gx = x0 + i % C1B;
+        if (gz < s.D && gy < s.H && gx < s.W)
+          *reinterpret_cast<float4 *>(out + ((((int64_t)b * s.D + gz) * s.H + gy) * s.W + gx) * CO + c4) =
+              *reinterpret_cast<const float4 *>(ot + i * (CO + 4) + c4);
+      }
+    }
+    __syncthreads();
   }
 }
 
