@@ -254,13 +254,20 @@ __global__ __launch_bounds__(NT) void conv3d_bwd_weight_x3_kernel(const float *_
   }
 }
 
-// db[co] = ordered f64 sum of the workgroups' partial bias gradients
-__global__ void db_reduce_kernel(const float *__restrict__ dbpart, float *__restrict__ db, int Co, int parts) {
-  const int co = blockIdx.x * blockDim.x + threadIdx.x;
-  if (co >= Co) return;
+// db[co] = f64 tree (fixed order) over the workgroups' partial bias gradients; one workgroup per channel
+__global__ __launch_bounds__(256) void db_reduce_kernel(const float *__restrict__ dbpart, float *__restrict__ db, int Co,
+                                                        int parts) {
+  __shared__ double red[256];
+  const int co = blockIdx.x;
   double sum = 0.0;
-  for (int p = 0; p < parts; ++p) sum += (double)dbpart[(int64_t)p * Co + co];
-  db[co] = (float)sum;
+  for (int p = threadIdx.x; p < parts; p += 256) sum += (double)dbpart[(int64_t)p * Co + co];
+  red[threadIdx.x] = sum;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) db[co] = (float)red[0];
 }
 
 // persistent workgroups per channel-tile pair: one workgroup per CU in total (LDS bound)
@@ -299,6 +306,6 @@ extern "C" int svr_conv3d_k3_bwd_weight_bf16x3(const float *in, const float *dou
   hipLaunchKernelGGL(conv3d_bwd_weight_x3_kernel, dim3((unsigned)parts, (unsigned)(cit * cot)), dim3(NT), 0, s, in, dout,
                      slab, sh, nbz, nby, nbx, cot, dbpart);
   conv3d_bwd_weight_reduce_launch(slab, dWp, Ci, Co, cit, cot, parts * 2, s);
-  if (db) hipLaunchKernelGGL(db_reduce_kernel, dim3((unsigned)cdiv(Co, 64)), dim3(64), 0, s, dbpart, db, Co, parts);
+  if (db) hipLaunchKernelGGL(db_reduce_kernel, dim3((unsigned)Co), dim3(256), 0, s, dbpart, db, Co, parts);
   return launch_status("conv3d_bwd_weight_bf16x3");
 }

@@ -340,7 +340,11 @@ __global__ __launch_bounds__(256, 3) void linear_nn_x3_kernel(const float *__res
 // workgroups per CU keep enough loads in flight (the 256 x 128 / 8-wave variant read X only once but ran one
 // workgroup per CU and was parked on memory 55 % of the time).
 constexpr int TN_TM = 128, TN_TN = 128;
-__global__ __launch_bounds__(256) void linear_tn_x3_kernel(const float *__restrict__ dY, int64_t lddy,
+// dY is transposed and split ONCE per call into bf16 planes [n][m] (dy_planes_kernel below): every one of the K/128
+// workgroups that share an N-tile then reads its A operand with four 8-byte loads per thread and plain LDS stores
+// instead of sixteen dword loads + a transposing store.
+__global__ __launch_bounds__(256) void linear_tn_x3_kernel(const uint16_t *__restrict__ dYh,
+                                                           const uint16_t *__restrict__ dYm, int64_t Mpad,
                                                            const float *__restrict__ X, int64_t ldx,
                                                            float *__restrict__ slab, int64_t M, int64_t N, int64_t K,
                                                            int64_t rows_per_split, int splits) {
@@ -356,7 +360,7 @@ __global__ __launch_bounds__(256) void linear_tn_x3_kernel(const float *__restri
   const int64_t i0 = (tile % tn) * TN_TM, j0 = (tile / tn) * TN_TN;
   const int64_t kbeg = split * rows_per_split;
   const int64_t kend = min(M, kbeg + rows_per_split);
-  TransLoader<TN_TM, 256> al(dY, lddy, i0, N);
+  PlaneLoader<TN_TM, 256> al(dYh, dYm, Mpad, i0, N);   // zero padded to Mpad: no tail handling needed
   TransLoader<TN_TN, 256> bl(X, ldx, j0, K);
   f32x16 acc[2][2];
   mainloop<2, 2>(al, bl, lds, kbeg, kend, acc);
@@ -365,6 +369,71 @@ __global__ __launch_bounds__(256) void linear_tn_x3_kernel(const float *__restri
     int64_t i = i0 + row, j = j0 + col;
     if (i < N && j < K) out[i * K + j] = v;
   });
+}
+
+// dY[M][N] f32 -> planes hi/mid [N][Mpad] bf16 (m contiguous, zero padded) + per-workgroup column sums for db.
+// One workgroup = 64 rows x all columns, 64 columns at a time through an LDS tile.
+__global__ __launch_bounds__(256) void dy_planes_kernel(const float *__restrict__ dY, int64_t lddy,
+                                                        uint16_t *__restrict__ hi, uint16_t *__restrict__ mid,
+                                                        int64_t Mpad, int64_t M, int64_t N, float *__restrict__ dbpart) {
+  __shared__ float tile[64][65];
+  const int t = threadIdx.x;
+  const int64_t m0 = (int64_t)blockIdx.x * 64;
+  for (int64_t n0 = 0; n0 < N; n0 += 64) {
+    float4 v[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {  // 16 rows x 64 columns per pass, float4 per thread (clamped, masked below)
+      const int r = p * 16 + (t >> 4), c = (t & 15) * 4;
+      const int64_t m = min(m0 + r, M - 1), n = min(n0 + c, N - 4);
+      v[p] = *reinterpret_cast<const float4 *>(dY + m * lddy + n);
+    }
+    __syncthreads();  // previous column chunk consumed
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int r = p * 16 + (t >> 4), c = (t & 15) * 4;
+      const bool ok = m0 + r < M && n0 + c < N;
+      tile[r][c] = ok ? v[p].x : 0.f; tile[r][c + 1] = ok ? v[p].y : 0.f;
+      tile[r][c + 2] = ok ? v[p].z : 0.f; tile[r][c + 3] = ok ? v[p].w : 0.f;
+    }
+    __syncthreads();
+    const int mq = t & 3, nl = t >> 2;  // 4 threads x 16 rows = 128 contiguous bytes of one plane row
+    uint32_t h[8], md[8];
+    float csum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float a = tile[mq * 16 + 2 * i][nl], b = tile[mq * 16 + 2 * i + 1][nl];
+      csum += a + b;
+      split2(a, b, h[i], md[i]);
+    }
+    if (n0 + nl < N) {
+      uint16_t *ph = hi + (n0 + nl) * Mpad + m0 + mq * 16, *pm = mid + (n0 + nl) * Mpad + m0 + mq * 16;
+      *reinterpret_cast<uint4 *>(ph) = make_uint4(h[0], h[1], h[2], h[3]);
+      *reinterpret_cast<uint4 *>(ph + 8) = make_uint4(h[4], h[5], h[6], h[7]);
+      *reinterpret_cast<uint4 *>(pm) = make_uint4(md[0], md[1], md[2], md[3]);
+      *reinterpret_cast<uint4 *>(pm + 8) = make_uint4(md[4], md[5], md[6], md[7]);
+      if (dbpart) {
+        csum += __shfl_xor(csum, 1);
+        csum += __shfl_xor(csum, 2);
+        if (mq == 0) dbpart[(int64_t)blockIdx.x * N + n0 + nl] = csum;
+      }
+    }
+  }
+}
+
+// db[n] = f64 tree over the row-tile partials [parts][N]
+__global__ __launch_bounds__(256) void dy_db_reduce_kernel(const float *__restrict__ dbpart, float *__restrict__ db, int64_t N,
+                                                           int64_t parts) {
+  __shared__ double red[256];
+  const int64_t n = blockIdx.x;
+  double s = 0.0;
+  for (int64_t p = threadIdx.x; p < parts; p += 256) s += (double)dbpart[p * N + n];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) db[n] = (float)red[0];
 }
 
 __global__ void slab_reduce_x3_kernel(const float *__restrict__ slab, float *__restrict__ out, int64_t rows, int64_t cols,
@@ -416,24 +485,40 @@ extern "C" int svr_linear_bwd_data_bf16x3(const float *dY, int64_t lddy, const f
   return launch_status("linear_bwd_data_bf16x3");
 }
 
+namespace {
+int64_t tn_mpad(int64_t M) { return cdiv(M, 64) * 64; }
+int64_t align256b(int64_t x) { return (x + 255) / 256 * 256; }
+}  // namespace
+
 extern "C" int64_t svr_linear_bwd_weight_bf16x3_workspace(int64_t M, int64_t N, int64_t K) {
   int64_t rps;
   int splits = tn_splits(M, N, K, &rps);
-  return ((int64_t)splits * N * K + colsum_workspace_floats(M, N)) * (int64_t)sizeof(float);
+  // slabs | dY planes (hi, mid) | per-row-tile column sums
+  return align256b((int64_t)splits * N * K * 4) + 2 * align256b(N * tn_mpad(M) * 2) + align256b(cdiv(M, 64) * N * 4) + 256;
 }
 
 extern "C" int svr_linear_bwd_weight_bf16x3(const float *dY, int64_t lddy, const float *X, int64_t ldx, float *dW,
                                             int64_t lddw, float *db, int64_t M, int64_t N, int64_t K, void *workspace,
                                             void *stream) {
   SVR_CHECK(dY && X && dW && workspace, SVR_E_BADARG, "linear_bwd_weight_bf16x3: null pointer");
-  SVR_CHECK(M > 0 && N > 0 && K > 0, SVR_E_BADSHAPE, "linear_bwd_weight_bf16x3: M=%ld N=%ld K=%ld", (long)M, (long)N, (long)K);
+  SVR_CHECK(M > 0 && N > 0 && K > 0 && N % 4 == 0, SVR_E_BADSHAPE, "linear_bwd_weight_bf16x3: M=%ld N=%ld K=%ld (N %% 4)", (long)M, (long)N, (long)K);
+  SVR_CHECK(lddy % 4 == 0 && ((uintptr_t)dY & 15) == 0, SVR_E_ALIGN, "linear_bwd_weight_bf16x3: dY must be 16-byte aligned");
   hipStream_t s = (hipStream_t)stream;
   int64_t rps;
   int splits = tn_splits(M, N, K, &rps);
-  float *slab = (float *)workspace;
+  const int64_t Mpad = tn_mpad(M), parts = cdiv(M, 64);
+  char *w = (char *)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+  float *slab = (float *)w;
+  w += align256b((int64_t)splits * N * K * 4);
+  uint16_t *ph = (uint16_t *)w;
+  w += align256b(N * Mpad * 2);
+  uint16_t *pm = (uint16_t *)w;
+  w += align256b(N * Mpad * 2);
+  float *dbpart = (float *)w;
+  hipLaunchKernelGGL(dy_planes_kernel, dim3((unsigned)parts), dim3(256), 0, s, dY, lddy, ph, pm, Mpad, M, N, db ? dbpart : nullptr);
   dim3 grid(xcd_grid(cdiv(K, TN_TN) * cdiv(N, TN_TM) * splits));
-  hipLaunchKernelGGL(linear_tn_x3_kernel, grid, dim3(256), 0, s, dY, lddy, X, ldx, slab, M, N, K, rps, splits);
+  hipLaunchKernelGGL(linear_tn_x3_kernel, grid, dim3(256), 0, s, ph, pm, Mpad, X, ldx, slab, M, N, K, rps, splits);
   hipLaunchKernelGGL(slab_reduce_x3_kernel, dim3((unsigned)cdiv(N * K, 256)), dim3(256), 0, s, slab, dW, N, K, lddw, splits);
-  if (db) colsum_launch(dY, lddy, db, slab + (int64_t)splits * N * K, M, N, s);
+  if (db) hipLaunchKernelGGL(dy_db_reduce_kernel, dim3((unsigned)N), dim3(256), 0, s, dbpart, db, N, parts);
   return launch_status("linear_bwd_weight_bf16x3");
 }
