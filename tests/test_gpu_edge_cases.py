@@ -118,3 +118,21 @@ def test_baseline_config2_gather_plus_mlp_only():
     h = ops.linear_fwd(h, st["fc_2.weight"].squeeze(2).contiguous().cuda(), st["fc_2.bias"].cuda(), relu=True)
     z = ops.fc_out_fwd(h, st["fc_out.weight"].reshape(-1).contiguous().cuda(), st["fc_out.bias"].cuda()).view(B, N)
     assert G.rel_err(z.cpu().numpy(), ref.numpy()) < 1e-4
+
+
+def test_f16x3_domain_is_loud_and_bf16x6_covers_it():
+    """The f16-split forward is specified for |x| < 65504 (f16 range): beyond it the result must be non-finite (never a
+    silently wrong number), and the bf16x6 forward (any f32 range) must still be right."""
+    import svr_amd  # noqa: F401
+    from svr_amd import ops
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(256, 64, generator=g)
+    x[5, 3] = 1.0e6                                   # outside the f16 range
+    w = torch.randn(32, 64, generator=g) / 8
+    ref = x.double() @ w.double().t()
+    y16 = ops.linear_fwd(x.cuda(), w.cuda(), None, relu=False, mode="f16x3").cpu()
+    assert not torch.isfinite(y16[5]).all()           # loud: inf / nan in the affected row
+    ok_rows = [r for r in range(256) if r != 5]
+    assert G.rel_err(y16[ok_rows].numpy(), ref[ok_rows].numpy()) < 2e-6   # the other rows are unaffected
+    y6 = ops.linear_fwd(x.cuda(), w.cuda(), None, relu=False, mode="bf16x6").cpu()
+    assert G.rel_err(y6.numpy(), ref.numpy()) < 2e-6
