@@ -115,20 +115,23 @@ __global__ void pack_fwd_planes_kernel(const float *__restrict__ W, uint16_t *__
 // NP = 2: products mid*hi + hi*mid + hi*hi (bf16x3);  NP = 3: the six products of bf16x6;
 // F16 (NP = 2): the f16 split of gemm_f16x3.hip -- planes hi / lo*2^11 of the input, hi / lo of the normalised
 // weights, products lo'(x) wq + hi(x) lo(w) + hi(x) hi(w) with wq = hi(w) 2^-11 made in registers, epilogue * 2^-s.
-template <int CK, int TNB, int NP, bool F16 = false>
+// VT = z-slices (32-voxel row tiles) per wave: with VT = 2 the brick is 8x4x8 and every weight fragment read from LDS
+// feeds two MFMA tiles (these kernels are LDS-bandwidth bound: 1.33 -> 1.0 KB of fragment reads per MFMA at Co = 32).
+template <int CK, int TNB, int NP, bool F16 = false, int VT = 1>
 __global__ __launch_bounds__(256) void conv3d_brick_x3_kernel(const float *__restrict__ in,
                                                               const uint16_t *__restrict__ P0,
                                                               int64_t plane_stride, const float *__restrict__ bias,
                                                               float *__restrict__ out, const float *__restrict__ mask,
                                                               ConvShape s, int nbz, int nby, int nbx, int mode,
                                                               const uint32_t *__restrict__ amax = nullptr) {
+  constexpr int BZ = BRZ * VT, HV = (BZ + 2) * HLY * HLX;  // brick depth and halo voxels of this instantiation
   constexpr int XW = (CK + 4) / 2;           // dwords per LDS row (CK bf16 + 8 B pad)
   constexpr int NC = TNB * 32;               // output columns of this workgroup
   constexpr int TG = TNB == 1 ? 3 : 1;       // taps per barrier
   constexpr int KS = CK / 16;                // MFMA k sub-steps per chunk
   constexpr int PIECES = TG * NP * NC * (CK / 8);  // 16-byte pieces per weight group
   constexpr int WPT = (PIECES + 255) / 256;
-  __shared__ uint32_t sh[NP][HLV * XW];       // halo tile, hi / mid (/ lo) planes: [voxel][k]
+  __shared__ uint32_t sh[NP][HV * XW];       // halo tile, hi / mid (/ lo) planes: [voxel][k]
   __shared__ uint32_t sw[2][TG][NP][NC * XW]; // weight slices: [buffer][tap][plane][n][k]
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int l31 = lane & 31, lh = lane >> 5;
@@ -137,15 +140,17 @@ __global__ __launch_bounds__(256) void conv3d_brick_x3_kernel(const float *__res
   const int by = (int)(q % nby); q /= nby;
   const int bz = (int)(q % nbz);
   const int64_t b = q / nbz;
-  const int z0 = bz * BRZ, y0 = by * BRY, x0 = bx * BRX;
+  const int z0 = bz * BZ, y0 = by * BRY, x0 = bx * BRX;
   const int n0 = blockIdx.y * NC;
   const float *inb = in + b * (int64_t)s.D * s.H * s.W * s.Ci;
   const int hrow = ((wave + 1) * HLY + l31 / BRX + 1) * HLX + l31 % BRX + 1;  // this lane's voxel in the halo tile
-  f32x16 acc[TNB];
+  f32x16 acc[VT][TNB];  // tile v of this wave = z-slice wave + 4 v
 #pragma unroll
-  for (int j = 0; j < TNB; ++j)
+  for (int v = 0; v < VT; ++v)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    for (int j = 0; j < TNB; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[v][j][r] = 0.f;
 
   // weight slices travel global -> registers -> LDS two steps ahead of their use (two register sets, two LDS
   // buffers): one step of MFMAs (0.2-0.3 us at Co = 32) is shorter than an L2 round trip
@@ -182,25 +187,25 @@ __global__ __launch_bounds__(256) void conv3d_brick_x3_kernel(const float *__res
     if (k0 > 0) __syncthreads();  // previous chunk's tiles are no longer read
     // Halo tile: all loads of the chunk are issued first, unconditionally and from clamped coordinates (a load inside
     // a branch is waited for at the end of the branch, one full memory latency per iteration), zeroed afterwards.
-    constexpr int HIT = (HLV * (CK / 4) + 255) / 256;
+    constexpr int HIT = (HV * (CK / 4) + 255) / 256;
     float4 hreg[HIT];
-    uint32_t hok = 0;
+    uint64_t hok = 0;
 #pragma unroll
     for (int i = 0; i < HIT; ++i) {
-      const int idx = min(t + 256 * i, HLV * (CK / 4) - 1);
+      const int idx = min(t + 256 * i, HV * (CK / 4) - 1);
       const int hv = idx / (CK / 4), c4 = (idx % (CK / 4)) * 4;
       const int hx = hv % HLX, hy = (hv / HLX) % HLY, hz = hv / (HLX * HLY);
       const int gz = z0 + hz - 1, gy = y0 + hy - 1, gx = x0 + hx - 1;
-      if (gz >= 0 && gz < s.D && gy >= 0 && gy < s.H && gx >= 0 && gx < s.W) hok |= 1u << i;
+      if (gz >= 0 && gz < s.D && gy >= 0 && gy < s.H && gx >= 0 && gx < s.W) hok |= 1ull << i;
       const int cz = min(max(gz, 0), s.D - 1), cy = min(max(gy, 0), s.H - 1), cx = min(max(gx, 0), s.W - 1);
       hreg[i] = *reinterpret_cast<const float4 *>(inb + (((int64_t)cz * s.H + cy) * s.W + cx) * s.Ci + k0 + c4);
     }
 #pragma unroll
     for (int i = 0; i < HIT; ++i) {
       const int idx = t + 256 * i;
-      if (idx >= HLV * (CK / 4)) break;
+      if (idx >= HV * (CK / 4)) break;
       const int hv = idx / (CK / 4), c4 = (idx % (CK / 4)) * 4;
-      const bool ok = (hok >> i) & 1u;
+      const bool ok = (hok >> i) & 1ull;
       const float4 v = make_float4(ok ? hreg[i].x : 0.f, ok ? hreg[i].y : 0.f, ok ? hreg[i].z : 0.f, ok ? hreg[i].w : 0.f);
       uint32_t h0, m0, l0 = 0, h1, m1, l1 = 0;
       if constexpr (NP == 3) {
@@ -231,34 +236,49 @@ __global__ __launch_bounds__(256) void conv3d_brick_x3_kernel(const float *__res
         for (int ks = 0; ks < KS; ++ks) {
           const int kw = ks * 8 + lh * 4;
           if constexpr (F16) {
-            const f16x8 xh = read_frag_h(&sh[0][arow * XW + kw]);
-            const f16x8 xl = read_frag_h(&sh[1][arow * XW + kw]);
+            f16x8 xh[VT], xl[VT];
+#pragma unroll
+            for (int v = 0; v < VT; ++v) {
+              xh[v] = read_frag_h(&sh[0][(arow + v * BRZ * HLY * HLX) * XW + kw]);
+              xl[v] = read_frag_h(&sh[1][(arow + v * BRZ * HLY * HLX) * XW + kw]);
+            }
 #pragma unroll
             for (int j = 0; j < TNB; ++j) {
               const f16x8 wh = read_frag_h(&sw[buf][tg][0][(j * 32 + l31) * XW + kw]);
               const f16x8 wl = read_frag_h(&sw[buf][tg][1][(j * 32 + l31) * XW + kw]);
-              acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xl, scale_2m11(wh), acc[j], 0, 0, 0);
-              acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, wl, acc[j], 0, 0, 0);
-              acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh, wh, acc[j], 0, 0, 0);
+              const f16x8 wq = scale_2m11(wh);
+#pragma unroll
+              for (int v = 0; v < VT; ++v) {
+                acc[v][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xl[v], wq, acc[v][j], 0, 0, 0);
+                acc[v][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh[v], wl, acc[v][j], 0, 0, 0);
+                acc[v][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh[v], wh, acc[v][j], 0, 0, 0);
+              }
             }
             continue;
           }
-          const bf16x8 ah = read_frag(&sh[0][arow * XW + kw]);
-          const bf16x8 am = read_frag(&sh[1][arow * XW + kw]);
+          bf16x8 ah[VT], am[VT];
+#pragma unroll
+          for (int v = 0; v < VT; ++v) {
+            ah[v] = read_frag(&sh[0][(arow + v * BRZ * HLY * HLX) * XW + kw]);
+            am[v] = read_frag(&sh[1][(arow + v * BRZ * HLY * HLX) * XW + kw]);
+          }
 #pragma unroll
           for (int j = 0; j < TNB; ++j) {
             const bf16x8 bh = read_frag(&sw[buf][tg][0][(j * 32 + l31) * XW + kw]);
             const bf16x8 bm = read_frag(&sw[buf][tg][1][(j * 32 + l31) * XW + kw]);
-            if constexpr (NP == 3) {
-              const bf16x8 al = read_frag(&sh[NP - 1][arow * XW + kw]);
-              const bf16x8 bl = read_frag(&sw[buf][tg][NP - 1][(j * 32 + l31) * XW + kw]);
-              acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[j], 0, 0, 0);
-              acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[j], 0, 0, 0);
-              acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc[j], 0, 0, 0);
+#pragma unroll
+            for (int v = 0; v < VT; ++v) {
+              if constexpr (NP == 3) {
+                const bf16x8 al = read_frag(&sh[NP - 1][(arow + v * BRZ * HLY * HLX) * XW + kw]);
+                const bf16x8 bl = read_frag(&sw[buf][tg][NP - 1][(j * 32 + l31) * XW + kw]);
+                acc[v][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[v][j], 0, 0, 0);
+                acc[v][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[v], bl, acc[v][j], 0, 0, 0);
+                acc[v][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[v], bm, acc[v][j], 0, 0, 0);
+              }
+              acc[v][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[v], bh, acc[v][j], 0, 0, 0);
+              acc[v][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[v], bm, acc[v][j], 0, 0, 0);
+              acc[v][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[v], bh, acc[v][j], 0, 0, 0);
             }
-            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc[j], 0, 0, 0);
-            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc[j], 0, 0, 0);
-            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[j], 0, 0, 0);
           }
         }
       }
@@ -271,12 +291,14 @@ __global__ __launch_bounds__(256) void conv3d_brick_x3_kernel(const float *__res
     }
   }
 #pragma unroll
+  for (int v = 0; v < VT; ++v)
+#pragma unroll
   for (int j = 0; j < TNB; ++j) {
     const int n = n0 + j * 32 + l31;
     const int nc = min(n, s.Co - 1);
     const float bv = (mode == SVR_EPI_BIAS || mode == SVR_EPI_BIAS_RELU) ? bias[nc] : 0.f;
     const float inv = F16 ? w_scale(amax[0], true) : 1.f;
-    const int gz = z0 + wave;
+    const int gz = z0 + wave + BRZ * v;
     // the ReLU mask of the whole tile is fetched up front from clamped coordinates: loads inside the bounds
     // branch would be waited for one at a time
     float mk[16];
@@ -294,10 +316,10 @@ __global__ __launch_bounds__(256) void conv3d_brick_x3_kernel(const float *__res
       const int gy = y0 + i / BRX, gx = x0 + i % BRX;
       if (n < s.Co && gz < s.D && gy < s.H && gx < s.W) {
         const int64_t o = ((((int64_t)b * s.D + gz) * s.H + gy) * s.W + gx) * s.Co + n;
-        float v = (F16 ? acc[j][r] * inv : acc[j][r]) + bv;
-        if (mode == SVR_EPI_BIAS_RELU) v = fmaxf(v, 0.f);
-        if (mode == SVR_EPI_MASK) v = mk[r] > 0.f ? v : 0.f;
-        out[o] = v;
+        float val = (F16 ? acc[v][j][r] * inv : acc[v][j][r]) + bv;
+        if (mode == SVR_EPI_BIAS_RELU) val = fmaxf(val, 0.f);
+        if (mode == SVR_EPI_MASK) val = mk[r] > 0.f ? val : 0.f;
+        out[o] = val;
       }
     }
   }
@@ -327,7 +349,11 @@ extern "C" int svr_conv3d_k3_bwd_data_bf16x3(const float *dout, const float *W, 
   hipLaunchKernelGGL((conv3d_brick_x3_kernel<CKV, TNV, 2>), dim3(bricks, (unsigned)cdiv(Ci, TNV * 32)), dim3(256), 0, s, dout, \
                      hi, (int64_t)27 * Ci * Co, (const float *)nullptr, din, mask, sh, nbz, nby, nbx, epilogue)
   const int tn = Ci <= 32 ? 1 : (Ci <= 64 ? 2 : 4);
-  if (Co % 32 == 0) {
+  if (tn == 1 && Co % 16 == 0) {  // 32 output columns: two z-slices per wave (8x4x8 bricks, 16-channel chunks)
+    const int nbz2 = (int)cdiv(D, 2 * BRZ);
+    hipLaunchKernelGGL((conv3d_brick_x3_kernel<16, 1, 2, false, 2>), dim3((unsigned)((int64_t)B * nbz2 * nby * nbx), 1), dim3(256), 0,
+                       s, dout, hi, (int64_t)27 * Ci * Co, (const float *)nullptr, din, mask, sh, nbz2, nby, nbx, epilogue);
+  } else if (Co % 32 == 0) {
     if (tn == 1) LAUNCH_X3(32, 1); else if (tn == 2) LAUNCH_X3(32, 2); else LAUNCH_X3(32, 4);
   } else {
     if (tn == 1) LAUNCH_X3(16, 1); else if (tn == 2) LAUNCH_X3(16, 2); else LAUNCH_X3(16, 4);
@@ -388,10 +414,14 @@ extern "C" int svr_conv3d_k3_fwd_f16x3(const float *in, const float *W, const fl
   hipLaunchKernelGGL((conv3d_brick_x3_kernel<CKV, TNV, 2, true>), dim3(bricks, (unsigned)cdiv(Co, TNV * 32)), dim3(256), 0, s, \
                      in, p0, ps, bias, out, (const float *)nullptr, sh, nbz, nby, nbx, epilogue, amax)
   const int tn = Co <= 32 ? 1 : (Co <= 64 ? 2 : 4);
-  if (Ci % 32 == 0) {
-    if (tn == 1) LAUNCH_H3(32, 1); else if (tn == 2) LAUNCH_H3(32, 2); else LAUNCH_H3(32, 4);
+  if (tn == 1) {  // Co <= 32: two z-slices per wave (8x4x8 bricks, 16-channel chunks)
+    const int nbz2 = (int)cdiv(D, 2 * BRZ);
+    hipLaunchKernelGGL((conv3d_brick_x3_kernel<16, 1, 2, true, 2>), dim3((unsigned)((int64_t)B * nbz2 * nby * nbx), 1), dim3(256), 0, s,
+                       in, p0, ps, bias, out, (const float *)nullptr, sh, nbz2, nby, nbx, epilogue, amax);
+  } else if (Ci % 32 == 0) {
+    if (tn == 2) LAUNCH_H3(32, 2); else LAUNCH_H3(32, 4);
   } else {
-    if (tn == 1) LAUNCH_H3(16, 1); else if (tn == 2) LAUNCH_H3(16, 2); else LAUNCH_H3(16, 4);
+    if (tn == 2) LAUNCH_H3(16, 2); else LAUNCH_H3(16, 4);
   }
 #undef LAUNCH_H3
   return launch_status("conv3d_fwd_f16x3");
