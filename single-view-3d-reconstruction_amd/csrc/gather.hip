@@ -84,7 +84,7 @@ struct FusedArgs {
   int pad_start;  // forward: columns [pad_start, row_stride) of every row are zero-filled by the last level
 };
 
-template <int C>
+template <int C, bool JMAJOR = false>
 __device__ __forceinline__ void gather_fwd_body(const LevelArgs L, const float *__restrict__ points,
                                                 float *__restrict__ feat, const int32_t *__restrict__ order,
                                                 int64_t gid, int64_t total, int N, int row_stride, float disp,
@@ -92,8 +92,16 @@ __device__ __forceinline__ void gather_fwd_body(const LevelArgs L, const float *
   constexpr int V = (C >= 4) ? C / 4 : 1;
   if (gid >= total) return;
   int q = (int)(gid % V);
-  int j = (int)((gid / V) % 7);
-  int64_t pn = gid / (7 * V);
+  int j;
+  int64_t pn;
+  if (JMAJOR) {  // wide levels: a wave walks consecutive (Morton-sorted) points for ONE displacement -> shared cache lines
+    const int64_t bn = total / (7 * V);
+    pn = (gid / V) % bn;
+    j = (int)(gid / (V * bn));
+  } else {
+    j = (int)((gid / V) % 7);
+    pn = gid / (7 * V);
+  }
   if (order) pn = order[pn];
   int b = (int)(pn / N);
   Corner c = sample_corner(points + pn * 3, j, disp, L.D, L.H, L.W, ac);
@@ -164,8 +172,8 @@ __global__ __launch_bounds__(256) void gather_fwd_fused_kernel(FusedArgs A, cons
     case 1: gather_fwd_body<1>(L, points, feat, order, gid, total, N, row_stride, disp, ac); break;
     case 16: gather_fwd_body<16>(L, points, feat, order, gid, total, N, row_stride, disp, ac); break;
     case 32: gather_fwd_body<32>(L, points, feat, order, gid, total, N, row_stride, disp, ac); break;
-    case 64: gather_fwd_body<64>(L, points, feat, order, gid, total, N, row_stride, disp, ac); break;
-    case 128: gather_fwd_body<128>(L, points, feat, order, gid, total, N, row_stride, disp, ac); break;
+    case 64: gather_fwd_body<64, true>(L, points, feat, order, gid, total, N, row_stride, disp, ac); break;
+    case 128: gather_fwd_body<128, true>(L, points, feat, order, gid, total, N, row_stride, disp, ac); break;
   }
 }
 
