@@ -348,11 +348,15 @@ extern "C" int svr_conv3d_k3_bwd_data_bf16x3(const float *dout, const float *W, 
 #define LAUNCH_X3(CKV, TNV)                                                                                               \
   hipLaunchKernelGGL((conv3d_brick_x3_kernel<CKV, TNV, 2>), dim3(bricks, (unsigned)cdiv(Ci, TNV * 32)), dim3(256), 0, s, dout, \
                      hi, (int64_t)27 * Ci * Co, (const float *)nullptr, din, mask, sh, nbz, nby, nbx, epilogue)
-  const int tn = Ci <= 32 ? 1 : (Ci <= 64 ? 2 : 4);
-  if (tn == 1 && Co % 16 == 0) {  // 32 output columns: two z-slices per wave (8x4x8 bricks, 16-channel chunks)
-    const int nbz2 = (int)cdiv(D, 2 * BRZ);
-    hipLaunchKernelGGL((conv3d_brick_x3_kernel<16, 1, 2, false, 2>), dim3((unsigned)((int64_t)B * nbz2 * nby * nbx), 1), dim3(256), 0,
-                       s, dout, hi, (int64_t)27 * Ci * Co, (const float *)nullptr, din, mask, sh, nbz2, nby, nbx, epilogue);
+  // output-column tiles per workgroup: as wide as the layer allows (fragment reuse), but narrower on the small volumes
+  // so that the grid still has >= 512 workgroups (the 8^3 / 16^3 layers ran 32 / 256 workgroups of 108 barrier steps)
+  int tn = Ci <= 32 ? 1 : (Ci <= 64 ? 2 : 4);
+  while (tn > 1 && (int64_t)bricks * cdiv(Ci, tn * 32) < 512) tn /= 2;
+  const int nbz2 = (int)cdiv(D, 2 * BRZ);
+  if (tn == 1 && Co % 16 == 0 && (int64_t)B * nbz2 * nby * nbx * cdiv(Ci, 32) >= 512) {
+    // 32 output columns: two z-slices per wave (8x4x8 bricks, 16-channel chunks)
+    hipLaunchKernelGGL((conv3d_brick_x3_kernel<16, 1, 2, false, 2>), dim3((unsigned)((int64_t)B * nbz2 * nby * nbx), (unsigned)cdiv(Ci, 32)),
+                       dim3(256), 0, s, dout, hi, (int64_t)27 * Ci * Co, (const float *)nullptr, din, mask, sh, nbz2, nby, nbx, epilogue);
   } else if (Co % 32 == 0) {
     if (tn == 1) LAUNCH_X3(32, 1); else if (tn == 2) LAUNCH_X3(32, 2); else LAUNCH_X3(32, 4);
   } else {
@@ -413,15 +417,16 @@ extern "C" int svr_conv3d_k3_fwd_f16x3(const float *in, const float *W, const fl
 #define LAUNCH_H3(CKV, TNV)                                                                                                 \
   hipLaunchKernelGGL((conv3d_brick_x3_kernel<CKV, TNV, 2, true>), dim3(bricks, (unsigned)cdiv(Co, TNV * 32)), dim3(256), 0, s, \
                      in, p0, ps, bias, out, (const float *)nullptr, sh, nbz, nby, nbx, epilogue, amax)
-  const int tn = Co <= 32 ? 1 : (Co <= 64 ? 2 : 4);
-  if (tn == 1) {  // Co <= 32: two z-slices per wave (8x4x8 bricks, 16-channel chunks)
-    const int nbz2 = (int)cdiv(D, 2 * BRZ);
-    hipLaunchKernelGGL((conv3d_brick_x3_kernel<16, 1, 2, true, 2>), dim3((unsigned)((int64_t)B * nbz2 * nby * nbx), 1), dim3(256), 0, s,
-                       in, p0, ps, bias, out, (const float *)nullptr, sh, nbz2, nby, nbx, epilogue, amax);
+  int tn = Co <= 32 ? 1 : (Co <= 64 ? 2 : 4);
+  while (tn > 1 && (int64_t)bricks * cdiv(Co, tn * 32) < 512) tn /= 2;   // see svr_conv3d_k3_bwd_data_bf16x3
+  const int nbz2 = (int)cdiv(D, 2 * BRZ);
+  if (tn == 1 && (int64_t)B * nbz2 * nby * nbx * cdiv(Co, 32) >= 512) {  // two z-slices per wave (8x4x8 bricks, 16-channel chunks)
+    hipLaunchKernelGGL((conv3d_brick_x3_kernel<16, 1, 2, true, 2>), dim3((unsigned)((int64_t)B * nbz2 * nby * nbx), (unsigned)cdiv(Co, 32)),
+                       dim3(256), 0, s, in, p0, ps, bias, out, (const float *)nullptr, sh, nbz2, nby, nbx, epilogue, amax);
   } else if (Ci % 32 == 0) {
-    if (tn == 2) LAUNCH_H3(32, 2); else LAUNCH_H3(32, 4);
+    if (tn == 1) LAUNCH_H3(32, 1); else if (tn == 2) LAUNCH_H3(32, 2); else LAUNCH_H3(32, 4);
   } else {
-    if (tn == 2) LAUNCH_H3(16, 2); else LAUNCH_H3(16, 4);
+    if (tn == 1) LAUNCH_H3(16, 1); else if (tn == 2) LAUNCH_H3(16, 2); else LAUNCH_H3(16, 4);
   }
 #undef LAUNCH_H3
   return launch_status("conv3d_fwd_f16x3");
