@@ -12,6 +12,7 @@
 //   conv3d_c1_* / conv3d_to1       Ci == 1 (conv_in): forward as a [voxels x 27] x [27 x Co] MFMA product from a
 //                                  scalar halo tile, weight gradient as a 27 x Co outer product, data gradient direct.
 #include "common.h"
+#include <algorithm>
 #include "gemm_core.h"
 
 using namespace svr;
@@ -538,6 +539,109 @@ __global__ __launch_bounds__(256) void conv3d_c1_bwd_weight_co16_kernel(const fl
   }
 }
 
+// ---- Ci == 1, Co == 16, W <= 128: the same product with the A operand served from LDS.  A workgroup owns 16 x-rows
+// (one y block of one z plane); the 3 x 18 input rows it can touch sit in LDS with their zero padding, so
+// A[tap][voxel] = in[voxel + tap] is one ds_read_b32 at a lane-constant offset (no bounds checks, no scattered
+// global loads: the texture addresser was the limit of the kernel above: 16 scattered dword loads per 32 voxels).
+constexpr int C1L_ROWS = 16, C1L_WP = 135, C1L_PS = 2453;  // row stride = 7, plane stride = 21 (mod 64): the 9 (dz,dy)
+                                                           // rows of a tap tile x 6 columns land in distinct banks
+__global__ __launch_bounds__(256) void conv3d_c1_bwd_weight_co16_lds_kernel(const float *__restrict__ in,
+                                                                            const float *__restrict__ dout,
+                                                                            float *__restrict__ slab, ConvShape s, int nyb,
+                                                                            float *__restrict__ dbpart) {
+  __shared__ float tile[3 * C1L_PS];
+  __shared__ float red[4 * 1024];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int l15 = lane & 15, kq = lane >> 4;
+  const int chunk = blockIdx.x;
+  const int yb = chunk % nyb, z = (chunk / nyb) % s.D;
+  const int64_t b = chunk / ((int64_t)nyb * s.D);
+  const int y0 = yb * C1L_ROWS;
+  const float *inb = in + b * (int64_t)s.D * s.H * s.W;
+  for (int e = t; e < 4096; e += 256) red[e] = 0.f;
+  // ---- stage the 3 x 18 x (W + 2) input window, zero padded; 8 loads in flight per thread
+  const int WW = s.W + 2, total = 3 * 18 * WW;
+  for (int base = 0; base < total; base += 256 * 8) {
+    float v[8];
+    uint32_t okm = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int idx = min(base + t + 256 * i, total - 1);
+      const int r = idx / WW, xx = idx % WW;
+      const int gz = z + r / 18 - 1, gy = y0 + r % 18 - 1, gx = xx - 1;
+      if (gz >= 0 && gz < s.D && gy >= 0 && gy < s.H && gx >= 0 && gx < s.W) okm |= 1u << i;
+      v[i] = inb[((int64_t)min(max(gz, 0), s.D - 1) * s.H + min(max(gy, 0), s.H - 1)) * s.W + min(max(gx, 0), s.W - 1)];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int idx = base + t + 256 * i;
+      if (idx < total) {
+        const int r = idx / WW, xx = idx % WW;
+        tile[(r / 18) * C1L_PS + (r % 18) * C1L_WP + xx] = ((okm >> i) & 1u) ? v[i] : 0.f;
+      }
+    }
+  }
+  __syncthreads();
+  // ---- lane constants: tap of each of the two 16-row A tiles -> LDS offset of (dz, dy, dx)
+  int aoff[2];
+  uint32_t amask[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int tap = 16 * h + l15, tc = tap < 27 ? tap : 26;
+    aoff[h] = (tc / 9) * C1L_PS + ((tc / 3) % 3) * C1L_WP + (tc % 3);
+    amask[h] = tap < 27 ? 0xffffffffu : 0u;
+  }
+  f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  float dbs = 0.f;
+  for (int yl = wave; yl < C1L_ROWS; yl += 4) {
+    const int gy = y0 + yl;
+    if (gy >= s.H) break;
+    const float *dob = dout + ((((int64_t)b * s.D + z) * s.H + gy) * s.W) * 16;
+    const int rowoff = yl * C1L_WP;  // (yl + dy + 1 - 1 ... ) : dy index 0..2 is already in aoff, window row 0 = gy - 1
+    for (int x0 = 0; x0 < s.W; x0 += 32) {
+      float br[8];
+      uint32_t bm[8];
+      const bool full = x0 + 32 <= s.W;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int x = x0 + 4 * u + kq;
+        const bool bok = full || x < s.W;
+        br[u] = dob[(bok ? x : 0) * 16 + l15];
+        bm[u] = bok ? 0xffffffffu : 0u;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int x = min(x0 + 4 * u + kq, s.W - 1);
+        const float bv = __uint_as_float(__float_as_uint(br[u]) & bm[u]);
+        dbs += bv;
+        const float a0 = __uint_as_float(__float_as_uint(tile[aoff[0] + rowoff + x]) & amask[0] & bm[u]);
+        const float a1 = __uint_as_float(__float_as_uint(tile[aoff[1] + rowoff + x]) & amask[1] & bm[u]);
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, bv, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bv, acc[1], 0, 0, 0);
+      }
+    }
+  }
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[wave * 1024 + (16 * h + 4 * kq + r) * 32 + l15] = acc[h][r];
+  __syncthreads();
+  float *o = slab + (int64_t)chunk * 1024;
+  for (int e = threadIdx.x; e < 1024; e += 256) o[e] = ((red[e] + red[1024 + e]) + red[2048 + e]) + red[3072 + e];
+  if (dbpart) {
+    __syncthreads();
+    red[threadIdx.x] = dbs;
+    __syncthreads();
+    if (threadIdx.x < 16) {
+      float sum = 0.f;
+      for (int i = 0; i < 16; ++i) sum += red[i * 16 + threadIdx.x];
+      dbpart[(int64_t)chunk * 16 + threadIdx.x] = sum;
+    }
+  }
+}
+
 // db[co] = ordered f64 sum of the per-workgroup partial bias gradients [parts][Co]
 __global__ void conv3d_db_reduce_kernel(const float *__restrict__ dbpart, float *__restrict__ db, int Co, int parts) {
   __shared__ double red[256];
@@ -660,7 +764,10 @@ extern "C" int64_t svr_conv3d_k3_bwd_weight_workspace(int32_t B, int32_t D, int3
   int64_t chunks = cdiv(nrows, BW_ROWS);
   int64_t M = nrows * W;
   int64_t cs = colsum_workspace_floats(M, Co);
-  if (Ci == 1) return (chunks * 1024 + (cs > chunks * 16 ? cs : chunks * 16)) * (int64_t)sizeof(float);
+  if (Ci == 1) {  // slabs of the widest variant: one per 16-row y block (conv3d_c1_bwd_weight_co16_lds_kernel)
+    const int64_t parts = std::max<int64_t>(chunks, (int64_t)B * D * cdiv(H, C1L_ROWS));
+    return (parts * 1024 + (cs > parts * 16 ? cs : parts * 16)) * (int64_t)sizeof(float);
+  }
   int64_t tiles = cdiv(Ci, 32) * cdiv(Co, 32);
   return ((int64_t)bw_brick_parts(B, D, H, W, Ci, Co) * 27 * tiles * 1024 + cs) * (int64_t)sizeof(float);
 }
@@ -677,7 +784,17 @@ extern "C" int svr_conv3d_k3_bwd_weight(const float *in, const float *dout, floa
   int64_t slab_floats;
   if (Ci == 1) {
     SVR_CHECK(Co <= 32, SVR_E_UNSUPPORTED, "conv3d_bwd_weight: Ci=1 needs Co<=32 (got %d)", Co);
-    if (Co == 16) {
+    int parts = chunks;
+    if (Co == 16 && W <= 128) {
+      const int nyb = (int)cdiv(H, C1L_ROWS);
+      parts = B * D * nyb;
+      float *dbpart = db ? slab + (int64_t)parts * 1024 : nullptr;
+      hipLaunchKernelGGL(conv3d_c1_bwd_weight_co16_lds_kernel, dim3(parts), dim3(256), 0, s, in, dout, slab, sh, nyb, dbpart);
+      if (db) {
+        hipLaunchKernelGGL(conv3d_db_reduce_kernel, dim3(16), dim3(256), 0, s, dbpart, db, 16, parts);
+        db = nullptr;  // done
+      }
+    } else if (Co == 16) {
       float *dbpart = db ? slab + (int64_t)chunks * 1024 : nullptr;  // the colsum scratch is at least chunks * 16 floats
       hipLaunchKernelGGL(conv3d_c1_bwd_weight_co16_kernel, dim3(chunks), dim3(256), 0, s, in, dout, slab, sh, dbpart);
       if (db) {
@@ -686,8 +803,8 @@ extern "C" int svr_conv3d_k3_bwd_weight(const float *in, const float *dout, floa
       }
     } else
       hipLaunchKernelGGL(conv3d_c1_bwd_weight_kernel, dim3(chunks), dim3(256), 0, s, in, dout, slab, sh);
-    hipLaunchKernelGGL(conv3d_c1_bwd_weight_reduce_kernel, dim3(27 * Co), dim3(256), 0, s, slab, dWp, Co, chunks);
-    slab_floats = (int64_t)chunks * 1024;
+    hipLaunchKernelGGL(conv3d_c1_bwd_weight_reduce_kernel, dim3(27 * Co), dim3(256), 0, s, slab, dWp, Co, parts);
+    slab_floats = (int64_t)parts * 1024;
   } else {
     SVR_CHECK(Ci % 4 == 0 && Co % 4 == 0, SVR_E_UNSUPPORTED, "conv3d_bwd_weight: need Ci, Co %% 4 == 0 (Ci=%d Co=%d)", Ci, Co);
     int cit = (int)cdiv(Ci, 32), cot = (int)cdiv(Co, 32);
