@@ -82,6 +82,7 @@ struct FusedArgs {
   unsigned block_start[SVR_MAX_LEVELS + 1];
   int n;
   int pad_start;  // forward: columns [pad_start, row_stride) of every row are zero-filled by the last level
+  int shared;     // forward: levels with C >= 16 use gather_fwd_shared_body (sizes fit 32-bit element offsets)
 };
 
 template <int C, bool JMAJOR = false>
@@ -154,6 +155,86 @@ __device__ __forceinline__ void gather_fwd_body(const LevelArgs L, const float *
   }
 }
 
+// Forward body for C >= 16 with the sample geometry computed ONCE per (point, displacement) item.  The plain body
+// above recomputes the unnormalise / floor / clamp / 8-corner bounds and 64-bit address arithmetic in every one of the
+// C/4 lanes that share an item (~350 VALU instructions per lane against 8 loads: the kernel was VALU bound, 2.7 ms).
+// Here a wave owns 64 consecutive items: phase 1, lane l evaluates item l (corner (0,0,0) element offset, validity
+// bits of the 8 corners, the six 1-D weights, the output row offset); phase 2, C/4 iterations of 64/(C/4) items each,
+// the owning lane's values are broadcast with ds_bpermute, the 8 float4 corner loads go out together (wave-uniform
+// base + 32-bit offsets) and are summed in ATen's order (same arithmetic as above -> still bit-exact).
+template <int C, bool JMAJOR>
+__device__ __forceinline__ void gather_fwd_shared_body(const LevelArgs L, const float *__restrict__ points,
+                                                       float *__restrict__ feat, const int32_t *__restrict__ order,
+                                                       int64_t wave_id, int64_t BN, int N, int row_stride, float disp,
+                                                       int ac, int pad_start) {
+  constexpr int V = C / 4, IPI = 64 / V;  // lanes per item, items per iteration
+  const int lane = threadIdx.x & 63;
+  const int64_t items = BN * 7, first = wave_id * 64;
+  if (first >= items) return;
+  // ---- phase 1: one item per lane
+  const int64_t item = min(first + lane, items - 1);
+  int j;
+  int64_t pidx;
+  if (JMAJOR) { pidx = item % BN; j = (int)(item / BN); } else { j = (int)(item % 7); pidx = item / 7; }
+  const int64_t pn = order ? (int64_t)order[pidx] : pidx;
+  const int b = (int)(pn / N);
+  const Corner c = sample_corner(points + pn * 3, j, disp, L.D, L.H, L.W, ac);
+  const Weights w = corner_weights(c);
+  int vmask = 0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int z = w.z0 + (k >> 2), y = w.y0 + ((k >> 1) & 1), x = w.x0 + (k & 1);
+    if (z >= 0 && z < L.D && y >= 0 && y < L.H && x >= 0 && x < L.W) vmask |= 1 << k;
+  }
+  if (first + lane < items) vmask |= 0x100;  // live
+  if (pad_start >= 0 && j == 0) vmask |= 0x200;  // this item also writes its row's padding columns
+  // element offset of corner (0,0,0); garbage when that corner is out of range (never used then: every valid corner's
+  // own offset is in range, and int32 wrap-around cannot happen for in-range corners -- host-checked sizes)
+  const int ebase = (int)((((int64_t)b * L.D + w.z0) * L.H + w.y0) * L.W * C + (int64_t)w.x0 * C);  // wraps only for invalid corners
+  const int rowoff = (int)(pn * row_stride) + L.col + j * C;
+  // ---- phase 2
+  const int q4 = (lane % V) * 4;
+  const int cz = L.H * L.W * C, cy = L.W * C;
+#pragma unroll 1
+  for (int it = 0; it < V; ++it) {
+    const int src = (it * IPI + lane / V) << 2;  // byte index for ds_bpermute
+    const int e = __builtin_amdgcn_ds_bpermute(src, ebase);
+    const int m = __builtin_amdgcn_ds_bpermute(src, vmask);
+    const int ro = __builtin_amdgcn_ds_bpermute(src, rowoff);
+    const float wx0 = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(w.wx[0])));
+    const float wx1 = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(w.wx[1])));
+    const float wy0 = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(w.wy[0])));
+    const float wy1 = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(w.wy[1])));
+    const float wz0 = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(w.wz[0])));
+    const float wz1 = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(w.wz[1])));
+    float4 v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int off = e + (k >> 2) * cz + ((k >> 1) & 1) * cy + (k & 1) * C + q4;
+      v[k] = *reinterpret_cast<const float4 *>(L.vol + (((m >> k) & 1) ? off : q4));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      if ((m >> k) & 1) {
+        const float wt = (((k & 1) ? wx1 : wx0) * (((k >> 1) & 1) ? wy1 : wy0)) * ((k >> 2) ? wz1 : wz0);
+        acc.x = acc.x + v[k].x * wt;
+        acc.y = acc.y + v[k].y * wt;
+        acc.z = acc.z + v[k].z * wt;
+        acc.w = acc.w + v[k].w * wt;
+      }
+    }
+    if (m & 0x100) {
+      *reinterpret_cast<float4 *>(feat + ro + q4) = acc;
+      if ((m & 0x200) && q4 == 0) {
+        float *row = feat + (ro - L.col);  // j == 0: ro = row start + L.col
+        for (int cc = pad_start; cc < row_stride; ++cc) row[cc] = 0.f;
+      }
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void gather_fwd_fused_kernel(FusedArgs A, const float *__restrict__ points,
                                                                float *__restrict__ feat,
                                                                const int32_t *__restrict__ order, int64_t BN, int N,
@@ -161,6 +242,17 @@ __global__ __launch_bounds__(256) void gather_fwd_fused_kernel(FusedArgs A, cons
   int l = 0;
   while (l + 1 < A.n && blockIdx.x >= A.block_start[l + 1]) ++l;
   const LevelArgs L = A.L[l];  // by value: read from the kernel arguments once, then lives in SGPRs
+  if (A.shared && L.C >= 16) {  // one wave = 64 items
+    const int64_t wave_id = (int64_t)(blockIdx.x - A.block_start[l]) * 4 + (threadIdx.x >> 6);
+    const int pad = (l == A.n - 1) ? A.pad_start : -1;
+    switch (L.C) {
+      case 16: gather_fwd_shared_body<16, false>(L, points, feat, order, wave_id, BN, N, row_stride, disp, ac, pad); break;
+      case 32: gather_fwd_shared_body<32, false>(L, points, feat, order, wave_id, BN, N, row_stride, disp, ac, pad); break;
+      case 64: gather_fwd_shared_body<64, true>(L, points, feat, order, wave_id, BN, N, row_stride, disp, ac, pad); break;
+      case 128: gather_fwd_shared_body<128, true>(L, points, feat, order, wave_id, BN, N, row_stride, disp, ac, pad); break;
+    }
+    return;
+  }
   const int64_t gid = (int64_t)(blockIdx.x - A.block_start[l]) * 256 + threadIdx.x;
   const int V = L.C >= 4 ? L.C / 4 : 1;
   const int64_t total = BN * 7 * V;
@@ -500,6 +592,11 @@ extern "C" int svr_gather_trilinear_fwd(const svr_gather_desc *d, const float *p
   FusedArgs A;
   A.n = 0;
   unsigned blocks = 0;
+  // 32-bit element / row offsets in the shared-geometry body: every volume and the feature matrix below 2^31 elements
+  bool shared = BN * (int64_t)d->row_stride < (1LL << 31);
+  for (int l = 0; l < d->n_levels; ++l)
+    if ((int64_t)d->B * d->level[l].D * d->level[l].H * d->level[l].W * d->level[l].C >= (1LL << 31)) shared = false;
+  A.shared = shared ? 1 : 0;
   for (int pass = 0; pass < 2; ++pass)
     for (int l = d->n_levels - 1; l >= 0; --l) {
       if ((d->level[l].C >= 4) != (pass == 0)) continue;
@@ -507,7 +604,7 @@ extern "C" int svr_gather_trilinear_fwd(const svr_gather_desc *d, const float *p
       int V = L.C >= 4 ? L.C / 4 : 1;
       A.L[A.n] = L;
       A.block_start[A.n] = blocks;
-      blocks += (unsigned)svr::cdiv(BN * 7 * V, 256);
+      blocks += (unsigned)((shared && L.C >= 16) ? svr::cdiv(BN * 7, 256) : svr::cdiv(BN * 7 * V, 256));
       ++A.n;
     }
   A.block_start[A.n] = blocks;
