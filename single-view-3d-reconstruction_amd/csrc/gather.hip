@@ -195,43 +195,59 @@ __device__ __forceinline__ void gather_fwd_shared_body(const LevelArgs L, const 
   // ---- phase 2
   const int q4 = (lane % V) * 4;
   const int cz = L.H * L.W * C, cy = L.W * C;
-#pragma unroll 1
-  for (int it = 0; it < V; ++it) {
+  struct Iter {
+    float4 v[8];
+    int m, ro;
+    float wx0, wx1, wy0, wy1, wz0, wz1;
+  };
+  auto fetch = [&](Iter &I, int it) {  // broadcast the owning lane's geometry, issue the 8 corner loads
     const int src = (it * IPI + lane / V) << 2;  // byte index for ds_bpermute
     const int e = __builtin_amdgcn_ds_bpermute(src, ebase);
-    const int m = __builtin_amdgcn_ds_bpermute(src, vmask);
-    const int ro = __builtin_amdgcn_ds_bpermute(src, rowoff);
-    const float wx0 = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(w.wx[0])));
-    const float wx1 = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(w.wx[1])));
-    const float wy0 = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(w.wy[0])));
-    const float wy1 = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(w.wy[1])));
-    const float wz0 = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(w.wz[0])));
-    const float wz1 = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(w.wz[1])));
-    float4 v[8];
+    I.m = __builtin_amdgcn_ds_bpermute(src, vmask);
+    I.ro = __builtin_amdgcn_ds_bpermute(src, rowoff);
+    I.wx0 = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(w.wx[0])));
+    I.wx1 = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(w.wx[1])));
+    I.wy0 = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(w.wy[0])));
+    I.wy1 = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(w.wy[1])));
+    I.wz0 = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(w.wz[0])));
+    I.wz1 = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(w.wz[1])));
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       const int off = e + (k >> 2) * cz + ((k >> 1) & 1) * cy + (k & 1) * C + q4;
-      v[k] = *reinterpret_cast<const float4 *>(L.vol + (((m >> k) & 1) ? off : q4));
+      I.v[k] = *reinterpret_cast<const float4 *>(L.vol + (((I.m >> k) & 1) ? off : q4));
     }
-    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto finish = [&](const Iter &I) {  // sum in ATen's corner order (out-of-range corners skipped), store
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      if ((m >> k) & 1) {
-        const float wt = (((k & 1) ? wx1 : wx0) * (((k >> 1) & 1) ? wy1 : wy0)) * ((k >> 2) ? wz1 : wz0);
-        acc.x = acc.x + v[k].x * wt;
-        acc.y = acc.y + v[k].y * wt;
-        acc.z = acc.z + v[k].z * wt;
-        acc.w = acc.w + v[k].w * wt;
+      if ((I.m >> k) & 1) {
+        const float wt = (((k & 1) ? I.wx1 : I.wx0) * (((k >> 1) & 1) ? I.wy1 : I.wy0)) * ((k >> 2) ? I.wz1 : I.wz0);
+        acc.x = acc.x + I.v[k].x * wt;
+        acc.y = acc.y + I.v[k].y * wt;
+        acc.z = acc.z + I.v[k].z * wt;
+        acc.w = acc.w + I.v[k].w * wt;
       }
     }
-    if (m & 0x100) {
-      *reinterpret_cast<float4 *>(feat + ro + q4) = acc;
-      if ((m & 0x200) && q4 == 0) {
-        float *row = feat + (ro - L.col);  // j == 0: ro = row start + L.col
+    if (I.m & 0x100) {
+      *reinterpret_cast<float4 *>(feat + I.ro + q4) = acc;
+      if ((I.m & 0x200) && q4 == 0) {
+        float *row = feat + (I.ro - L.col);  // j == 0: ro = row start + L.col
         for (int cc = pad_start; cc < row_stride; ++cc) row[cc] = 0.f;
       }
     }
+  };
+  // two iterations in flight: the loads of it+1 are issued before the sums of it (V is even)
+  Iter A, B;
+  fetch(A, 0);
+#pragma unroll 1
+  for (int it = 0; it < V; it += 2) {
+    fetch(B, it + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    finish(A);
+    if (it + 2 < V) fetch(A, it + 2);
+    __builtin_amdgcn_sched_barrier(0);
+    finish(B);
   }
 }
 
