@@ -129,12 +129,15 @@ __global__ __launch_bounds__(256) void bn_apply_pool_kernel(const float *__restr
   const int Q = v.C / 4;
   const int Dc = (v.D + 1) / 2, Hc = (v.H + 1) / 2, Wc = (v.W + 1) / 2;
   const int Dp = v.D / 2, Hp = v.H / 2, Wp = v.W / 2;
-  int q = (int)(gid % Q);
-  int64_t cell = gid / Q;
-  int cx = (int)(cell % Wc); cell /= Wc;
-  int cy = (int)(cell % Hc); cell /= Hc;
-  int cz = (int)(cell % Dc);
-  int64_t b = cell / Dc;
+  // 32-bit index arithmetic (64-bit divisions by run-time values cost ~100 instructions each; the kernel was spending
+  // ~700 VALU instructions per thread on 8 loads).  total < 2^32 is checked on the host.
+  const uint32_t g32 = (uint32_t)gid;
+  int q = (int)(g32 % (uint32_t)Q);
+  uint32_t cell = g32 / (uint32_t)Q;
+  int cx = (int)(cell % (uint32_t)Wc); cell /= (uint32_t)Wc;
+  int cy = (int)(cell % (uint32_t)Hc); cell /= (uint32_t)Hc;
+  int cz = (int)(cell % (uint32_t)Dc);
+  int64_t b = cell / (uint32_t)Dc;
   float4 sc = *reinterpret_cast<const float4 *>(ss + q * 4);
   float4 sh = *reinterpret_cast<const float4 *>(ss + v.C + q * 4);
   float4 best = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -144,11 +147,15 @@ __global__ __launch_bounds__(256) void bn_apply_pool_kernel(const float *__restr
   // branch would be waited for one at a time); the scheduling barrier keeps the compiler from re-serialising them
   float4 in8[8];
   int64_t off8[8];
+  {  // corner k = base + per-axis strides (0 where the cell is cut by an odd extent: the clamped load is discarded)
+    const int64_t base = (((b * v.D + cz * 2) * v.H + cy * 2) * v.W + cx * 2) * v.C + q * 4;
+    const int64_t sz = (cz * 2 + 1 < v.D) ? (int64_t)v.H * v.W * v.C : 0, sy = (cy * 2 + 1 < v.H) ? (int64_t)v.W * v.C : 0;
+    const int64_t sx = (cx * 2 + 1 < v.W) ? v.C : 0;
 #pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    const int z = min(cz * 2 + (k >> 2), v.D - 1), yy = min(cy * 2 + ((k >> 1) & 1), v.H - 1), xx = min(cx * 2 + (k & 1), v.W - 1);
-    off8[k] = (((b * v.D + z) * v.H + yy) * v.W + xx) * v.C + q * 4;
-    in8[k] = *reinterpret_cast<const float4 *>(x + off8[k]);
+    for (int k = 0; k < 8; ++k) {
+      off8[k] = base + (k >> 2) * sz + ((k >> 1) & 1) * sy + (k & 1) * sx;
+      in8[k] = *reinterpret_cast<const float4 *>(x + off8[k]);
+    }
   }
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -204,11 +211,11 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(const float *__restrict__ x
   }
   double s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
   for (int64_t cell = (int64_t)blockIdx.x * CL + cl; cell < cells; cell += (int64_t)gridDim.x * CL) {
-    int64_t t = cell;
-    int cx = (int)(t % Wc); t /= Wc;
-    int cy = (int)(t % Hc); t /= Hc;
-    int cz = (int)(t % Dc);
-    int64_t b = t / Dc;
+    uint32_t t = (uint32_t)cell;  // cells < 2^32 (host-checked): 32-bit divisions
+    int cx = (int)(t % (uint32_t)Wc); t /= (uint32_t)Wc;
+    int cy = (int)(t % (uint32_t)Hc); t /= (uint32_t)Hc;
+    int cz = (int)(t % (uint32_t)Dc);
+    int64_t b = t / (uint32_t)Dc;
     float4 dp = make_float4(0.f, 0.f, 0.f, 0.f);
     uint32_t am = 0xffffffffu;
     if (dpooled && cz < Dp && cy < Hp && cx < Wp) {
@@ -220,11 +227,15 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(const float *__restrict__ x
     // all 16 loads of the cell first (see bn_apply_pool_kernel)
     float4 a8[8], g8[8];
     int64_t off8[8];
+    {  // corner k = base + per-axis strides (0 where the cell is cut by an odd extent: the clamped load is discarded)
+      const int64_t base = (((b * v.D + cz * 2) * v.H + cy * 2) * v.W + cx * 2) * v.C + q * 4;
+      const int64_t sz = (cz * 2 + 1 < v.D) ? (int64_t)v.H * v.W * v.C : 0, sy = (cy * 2 + 1 < v.H) ? (int64_t)v.W * v.C : 0;
+      const int64_t sx = (cx * 2 + 1 < v.W) ? v.C : 0;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const int z = min(cz * 2 + (k >> 2), v.D - 1), yy = min(cy * 2 + ((k >> 1) & 1), v.H - 1), xx = min(cx * 2 + (k & 1), v.W - 1);
-      off8[k] = (((b * v.D + z) * v.H + yy) * v.W + xx) * v.C + q * 4;
-      a8[k] = *reinterpret_cast<const float4 *>(x + off8[k]);
+      for (int k = 0; k < 8; ++k) {
+        off8[k] = base + (k >> 2) * sz + ((k >> 1) & 1) * sy + (k & 1) * sx;
+        a8[k] = *reinterpret_cast<const float4 *>(x + off8[k]);
+      }
     }
     if (dy) {  // wave-uniform
 #pragma unroll
@@ -362,6 +373,7 @@ extern "C" int svr_bn_apply_pool(const float *x, const float *scale_shift, float
   Vol v{B, D, H, W, C};
   int64_t total = (int64_t)B * ((D + 1) / 2) * ((H + 1) / 2) * ((W + 1) / 2) * (C / 4);
   if (total == 0) return SVR_OK;
+  SVR_CHECK(total < (1LL << 32), SVR_E_UNSUPPORTED, "bn_apply_pool: %ld work items (32-bit index arithmetic)", (long)total);
   hipLaunchKernelGGL(bn_apply_pool_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, x,
                      scale_shift, y, pooled, argmax, v, total);
   return launch_status("bn_apply_pool");
@@ -376,6 +388,7 @@ extern "C" int svr_bn_bwd_reduce(const float *x, const float *dy, const float *d
   hipStream_t s = (hipStream_t)stream;
   Vol v{B, D, H, W, C};
   int64_t cells = (int64_t)B * ((D + 1) / 2) * ((H + 1) / 2) * ((W + 1) / 2);
+  SVR_CHECK(cells < (1LL << 32), SVR_E_UNSUPPORTED, "bn_bwd: %ld cells (32-bit index arithmetic)", (long)cells);
   int blocks = bwd_blocks(cells, C);
   hipLaunchKernelGGL(bn_bwd_kernel<false>, dim3(blocks), dim3(256), 0, s, x, dy, dpooled, argmax, mean_f32, scale_shift,
                      (const double *)nullptr, (double *)workspace, (float *)nullptr, v, cells, 0);
@@ -394,6 +407,7 @@ extern "C" int svr_bn_bwd_apply(const float *x, const float *dy, const float *dp
   hipStream_t s = (hipStream_t)stream;
   Vol v{B, D, H, W, C};
   int64_t cells = (int64_t)B * ((D + 1) / 2) * ((H + 1) / 2) * ((W + 1) / 2);
+  SVR_CHECK(cells < (1LL << 32), SVR_E_UNSUPPORTED, "bn_bwd: %ld cells (32-bit index arithmetic)", (long)cells);
   int CL = 256 / (C / 4);
   int64_t blocks = cdiv(cells, CL);
   if (blocks > 65535 * 16) blocks = 65535 * 16;
