@@ -61,7 +61,7 @@ def _level_orders_async(pts, D, H, W, n_levels, align):
     with torch.cuda.stream(side):
         for l in range(1, n_levels):
             dhw = (max(D >> (l - 1), 1), max(H >> (l - 1), 1), max(W >> (l - 1), 1))
-            if N >= 0.5 * dhw[0] * dhw[1] * dhw[2] and N > 64:
+            if N >= 0.15 * dhw[0] * dhw[1] * dhw[2] and N > 64:
                 orders[l] = ops.voxel_order(pts, dhw, align)
                 orders[l].record_stream(main)
                 launched = True
