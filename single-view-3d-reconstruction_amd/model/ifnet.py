@@ -42,6 +42,13 @@ def _displacements(d):
 _side_stream = None
 
 
+def _get_side_stream(device):
+    global _side_stream
+    if _side_stream is None or _side_stream.device != device:
+        _side_stream = torch.cuda.Stream(device=device)
+    return _side_stream
+
+
 def _level_orders_async(pts, D, H, W, n_levels, align):
     """Visiting orders for the backward scatter, computed on a side stream; returns (orders per level, ready event).
 
@@ -49,13 +56,10 @@ def _level_orders_async(pts, D, H, W, n_levels, align):
     register runs, few atomics); finer levels keep the natural (Morton) order.  Level l has the pyramid's resolution
     (D, H, W) >> (l - 1) for l >= 1 (level 0 is the input grid, one channel: no order).  (Reusing level 4's order for
     level 5 saved a sort but cost 0.65 ms in the scatter: every level keeps its own.)"""
-    global _side_stream
     N = pts.shape[1]
     orders = [None] * n_levels
     main = torch.cuda.current_stream()
-    if _side_stream is None or _side_stream.device != pts.device:
-        _side_stream = torch.cuda.Stream(device=pts.device)
-    side = _side_stream
+    side = _get_side_stream(pts.device)
     side.wait_stream(main)          # pts may have just been produced on the main stream
     launched = False
     with torch.cuda.stream(side):
@@ -110,6 +114,17 @@ class _EncoderGatherFn(torch.autograd.Function):
             saved.append((inp, acts, argmax, ss, mean))
             inp = pooled
         feat = ops.gather_fwd(levels, pts, ext._layout, ext._disp, ext._align)
+        # the zero-initialised gradient volumes of the backward scatter (1.45 GB of memset at config 3) are prepared on
+        # the side stream too, beside the point MLP, instead of in front of the scatter
+        ctx.gvols = None
+        if ctx.orders_ready is not None or (training and x.is_cuda):
+            main, side = torch.cuda.current_stream(), _get_side_stream(x.device)
+            with torch.cuda.stream(side):
+                ctx.gvols = [None] + [torch.zeros_like(v) for v in levels[1:]]
+                for g in ctx.gvols[1:]:
+                    g.record_stream(main)
+                ctx.orders_ready = torch.cuda.Event()
+                ctx.orders_ready.record(side)
         ctx.ext, ctx.saved, ctx.levels, ctx.pts = ext, saved, levels, pts
         ctx.x_shape = x.shape
         ctx.training = training
@@ -122,7 +137,11 @@ class _EncoderGatherFn(torch.autograd.Function):
             raise RuntimeError("IF-Net HIP path: backward through eval-mode BatchNorm is not implemented")
         need_x, need_pts = ctx.needs_input_grad[1], ctx.needs_input_grad[2]
         gfeat = gfeat.contiguous()
-        gvols = [torch.zeros_like(levels[0]) if need_x else None] + [torch.zeros_like(v) for v in levels[1:]]
+        if ctx.gvols is not None:
+            gvols = [torch.zeros_like(levels[0]) if need_x else None] + ctx.gvols[1:]
+            ctx.gvols = None
+        else:
+            gvols = [torch.zeros_like(levels[0]) if need_x else None] + [torch.zeros_like(v) for v in levels[1:]]
         level_orders = ctx.level_orders
         if level_orders is None:
             level_orders, ready = _level_orders_async(pts, *levels[0].shape[1:4], len(levels), ext._align)
