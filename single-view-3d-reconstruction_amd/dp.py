@@ -20,14 +20,36 @@ class GradBucket:
         dev = device if device is not None else self.params[0].device
         self.numel = sum(p.numel() for p in self.params)
         self.flat = torch.zeros(self.numel, device=dev, dtype=dtype)
+        self.views = []
         off = 0
         for p in self.params:
             n = p.numel()
-            p.grad = self.flat[off:off + n].view_as(p)
+            self.views.append(self.flat[off:off + n].view_as(p))
+            p.grad = self.views[-1]
             off += n
 
     def zero(self):
         self.flat.zero_()
+
+    def detach_grads(self):
+        """Before backward: let autograd hand over fresh gradient tensors (no accumulate kernel per parameter)."""
+        for p in self.params:
+            p.grad = None
+
+    def collect_grads(self):
+        """After backward: one multi-tensor copy of the parameters' gradients into the flat bucket (instead of a
+        zero fill + one accumulate launch per parameter); .grad points into the bucket again afterwards."""
+        src, dst = [], []
+        for p, v in zip(self.params, self.views):
+            if p.grad is None:
+                v.zero_()
+            else:
+                src.append(p.grad)
+                dst.append(v)
+        if src:
+            torch._foreach_copy_(dst, src)
+        for p, v in zip(self.params, self.views):
+            p.grad = v
 
     def all_reduce_mean(self, group=None):
         """Sum over ranks then divide by the world size (mean of per-rank batch means = global
@@ -62,9 +84,10 @@ class DataParallelTrainer:
         self.optimizer = optimizer if optimizer is not None else trainer.configure_optimizers()[0][0]
 
     def step(self, batch, batch_idx=0):
-        self.bucket.zero()
+        self.bucket.detach_grads()
         out = self.trainer.training_step(batch, batch_idx)
         out["loss"].backward()
+        self.bucket.collect_grads()
         self.bucket.all_reduce_mean(self.group)
         self.optimizer.step()
         return out
