@@ -242,6 +242,7 @@ __device__ __forceinline__ void mainloop(AL &al, BL &bl, uint32_t *lds, int64_t 
       al.load(k0 + XK, kend);
       bl.load(k0 + XK, kend);
     }
+    __builtin_amdgcn_sched_barrier(0);  // the loads stay in front of the MFMAs (the scheduler would sink them to the stores)
     compute_step<WR, WC>(lds, acc);
     __syncthreads();  // every wave has read its fragments
     if (more) {
