@@ -9,12 +9,14 @@
 // exact-f32 MFMA.  It is used ONLY for the two backward products of the MLP layers,
 //     dX = dY W        (svr_linear_bwd_data_bf16x3)
 //     dW = dY^T X      (svr_linear_bwd_weight_bf16x3)
-// never in the forward pass: logits, ReLU masks and everything the 1e-4 parity gate sees stay exact f32.
+// never in the forward pass: logits, ReLU masks and everything the 1e-4 parity gate sees come from the f32-level
+// forward kernels (gemm_f16x3.hip / gemm_bf16x6.hip / gemm.hip).
 //
-// Structure: 128x128 block tile, 4 waves x (2x2) tiles of v_mfma_f32_32x32x16_bf16, k-step 32, two LDS
-// stages.  LDS holds hi/mid planes as [row][k] bf16 with a 72-byte row stride: the transposing store of
-// the dW operands (two consecutive k packed per dword, lane <-> row) is then 2-way conflict at worst and
-// the fragment reads (ds_read_b64, lane <-> row) are conflict free.
+// Structure: 128x128 block tile, 4 waves x (2x2) tiles of v_mfma_f32_32x32x16_bf16, k-step 32, ONE LDS stage
+// (two barriers per step, three workgroups per CU).  LDS holds hi/mid planes as [row][k] bf16 with an 80-byte
+// row stride: rows are 16-byte aligned and 16 consecutive rows cover all 64 banks with their 16-byte pieces,
+// so the fragment reads (ds_read_b128, lane <-> row) and the transposing stores (ds_write_b128) are conflict free.
+// Tiles that share an operand panel are dispatched to one XCD (common.h: xcd_logical).
 #include "common.h"
 
 using namespace svr;
