@@ -8,8 +8,9 @@
 //   x = hi + mid, products hi*hi + hi*mid + mid*hi, f32 accumulation in v_mfma_f32_32x32x16_bf16:
 //   ~1.5e-5 relative per product (see gemm_bf16x3.hip for why that is harmless in the BACKWARD pass), at a
 //   fraction of the exact-f32 MFMA cycles (6 x 32 cycles per 32x32x32 block instead of 16 x 64).
-// bf16x3 is used only for dIn = conv^T(dOut); the forward uses bf16x6 (three planes, six products, 16-channel
-// chunks so the three halo planes still fit two workgroups per CU) and is held to the exact-f32 kernel's gate.
+// bf16x3 is used only for dIn = conv^T(dOut).  The production forward is the f16 split (F16 = true: f16x3.h /
+// gemm_f16x3.hip, f32-level accuracy for |x| < 65504 at three products); bf16x6 (three planes, six products, any
+// f32 range) stays selectable.  Both forwards are held to the exact-f32 kernel's gate.
 #include "common.h"
 #include "f16x3.h"
 

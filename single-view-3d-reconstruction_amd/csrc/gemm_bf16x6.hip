@@ -1,4 +1,5 @@
-// Forward GEMMs of the point MLP at f32 accuracy on the bf16 matrix cores ("bf16x6"), gfx950.
+// Forward GEMMs of the point MLP at f32 accuracy on the bf16 matrix cores ("bf16x6"), gfx950: the range-safe
+// alternative (any f32 magnitude) to the production f16x3 forward (gemm_f16x3.hip), at twice its matrix-core work.
 //
 //   x = hi + mid + lo exactly to 2^-24 |x|   (three round-to-nearest bf16 terms carry 24 mantissa bits)
 //   a*b ~= a_hi b_hi + a_hi b_mid + a_mid b_hi + a_mid b_mid + a_hi b_lo + a_lo b_hi     (f32 accumulate)

@@ -170,7 +170,7 @@ def linear_fwd(x, w, bias, relu=True, out=None, mode=None):
 
 
 # Arithmetic of the two backward GEMMs of the point MLP: "bf16x3" (3-term bf16 split on the bf16 matrix cores,
-# ~1.5e-5 relative per product, see gemm_bf16x3.hip) or "f32" (exact-f32 MFMA).  The forward is always exact f32.
+# ~1.5e-5 relative per product, see gemm_bf16x3.hip) or "f32" (exact-f32 MFMA).  The forward never uses it.
 BACKWARD_GEMM = "bf16x3"
 
 
