@@ -374,6 +374,136 @@ __global__ __launch_bounds__(256) void linear_tn_x3_kernel(const uint16_t *__res
   });
 }
 
+// ---- dW with the X operand staged ROW-MAJOR and read back with gfx950's transposing LDS read.
+// The B operand of the MFMA wants, per lane, 8 consecutive rows m of one X column.  linear_tn_x3_kernel gets that by
+// transposing on the way IN (16 dword loads per thread and k-step, lane <-> column).  Here X rows go in as they lie
+// in memory -- float4 loads, a wave covers two full 512-byte rows per instruction, 4 loads per thread and k-step --
+// into a [32 m][128 columns] bf16 image per plane (256-byte rows, 16-byte chunks XOR-swizzled), and
+// ds_read_b64_tr_b16 hands every lane its column's 4 consecutive rows (two reads = one 8-k fragment).
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+constexpr int TR_XPLANE = 32 * 64;  // dwords per X plane: 32 rows x 256 B
+
+// byte offset of 16-byte chunk ch (0..15) of row r in the swizzled [32][256 B] image
+__device__ __forceinline__ int tr_off(int r, int ch) { return 256 * r + 16 * (ch ^ (((r & 3) << 2) | ((r >> 2) & 3))); }
+
+__device__ __forceinline__ bf16x8 tr_frag(const uint32_t *plane, int byte0, int byte1) {
+  typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+  const char *b = reinterpret_cast<const char *>(plane);
+  const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4 *)(b + byte0));
+  const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4 *)(b + byte1));
+  return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+__global__ __launch_bounds__(256) void linear_tn_x3_tr_kernel(const uint16_t *__restrict__ dYh,
+                                                              const uint16_t *__restrict__ dYm, int64_t Mpad,
+                                                              const float *__restrict__ X, int64_t ldx,
+                                                              float *__restrict__ slab, int64_t M, int64_t N, int64_t K,
+                                                              int64_t rows_per_split, int splits) {
+  constexpr int APL = TN_TM * XLW;                 // dwords per dY plane [128 n][32 m], 80-byte rows
+  __shared__ __attribute__((aligned(16))) uint32_t lds[2 * APL + 2 * TR_XPLANE];
+  uint32_t *la = lds, *lx = lds + 2 * APL;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wr = wave >> 1, wc = wave & 1, l31 = lane & 31, lh = lane >> 5;
+  const int64_t tk = cdiv(K, TN_TN), tiles = tk * cdiv(N, TN_TM), lidx = xcd_logical(blockIdx.x, gridDim.x);
+  if (lidx >= tiles * splits) return;
+  const int64_t split = lidx / tiles, tile = lidx % tiles;
+  const int64_t tn = cdiv(N, TN_TM);
+  const int64_t i0 = (tile % tn) * TN_TM, j0 = (tile / tn) * TN_TN;
+  const int64_t kbeg = split * rows_per_split;
+  const int64_t kend = min(M, kbeg + rows_per_split);
+  PlaneLoader<TN_TM, 256> al(dYh, dYm, Mpad, i0, N);   // zero padded to Mpad: no tail handling needed
+  // X loader: float4 idx = t + 256 i -> (row = idx >> 5, columns 4 (idx & 31) .. +3)
+  float4 xv[4];
+  const int64_t xcol = min(j0 + 4 * (int64_t)(t & 31), K - 4);  // columns past K are clamped: never stored
+  auto xload = [&](int64_t k0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int64_t m = min(k0 + (t >> 5) + 8 * i, kend - 1);   // rows past the range are clamped, zeroed in xstore
+      xv[i] = *reinterpret_cast<const float4 *>(X + m * ldx + xcol);
+    }
+  };
+  auto xstore = [&](int64_t k0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = (t >> 5) + 8 * i;
+      const bool ok = k0 + r < kend;
+      uint32_t h0, m0, h1, m1;
+      split2(ok ? xv[i].x : 0.f, ok ? xv[i].y : 0.f, h0, m0);
+      split2(ok ? xv[i].z : 0.f, ok ? xv[i].w : 0.f, h1, m1);
+      const int off = (tr_off(r, (t & 31) >> 1) + 8 * (t & 1)) >> 2;  // dwords
+      *reinterpret_cast<uint2 *>(lx + off) = make_uint2(h0, h1);
+      *reinterpret_cast<uint2 *>(lx + TR_XPLANE + off) = make_uint2(m0, m1);
+    }
+  };
+  // transposed-read addresses of this lane: group g = 16-lane group inside the half, lane 4q+p supplies row q, chunk p>>1
+  const int g = (lane >> 4) & 1, q = (lane & 15) >> 2, p = lane & 3;
+  int boff[2][2][2];  // [ks][j][read] byte offsets into an X plane
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int rr = 0; rr < 2; ++rr)
+        boff[ks][j][rr] = tr_off(ks * 16 + lh * 8 + rr * 4 + q, wc * 8 + j * 4 + 2 * g + (p >> 1)) + 8 * (p & 1);
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  if (kbeg < kend) {
+    al.load(kbeg, kend);
+    xload(kbeg);
+    al.store(la);
+    xstore(kbeg);
+    __syncthreads();
+    for (int64_t k0 = kbeg; k0 < kend; k0 += XK) {
+      const bool more = k0 + XK < kend;
+      if (more) {
+        al.load(k0 + XK, kend);
+        xload(k0 + XK);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const int kw = ks * 8 + lh * 4;
+        bf16x8 ah[2], am[2], bh[2], bm[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          ah[i] = read_frag(la, wr * 64 + i * 32 + l31, kw);
+          am[i] = read_frag(la + APL, wr * 64 + i * 32 + l31, kw);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          bh[j] = tr_frag(lx, boff[ks][j][0], boff[ks][j][1]);
+          bm[j] = tr_frag(lx + TR_XPLANE, boff[ks][j][0], boff[ks][j][1]);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[i], bh[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bm[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+          }
+      }
+      __syncthreads();  // every wave has read its fragments
+      if (more) {
+        al.store(la);
+        xstore(k0 + XK);
+      }
+      __syncthreads();
+    }
+  }
+  float *out = slab + split * N * K;
+  foreach_acc<2, 2>(acc, [&](int row, int col, float v) {
+    int64_t i = i0 + row, j = j0 + col;
+    if (i < N && j < K) out[i * K + j] = v;
+  });
+}
+
 // dY[M][N] f32 -> planes hi/mid [N][Mpad] bf16 (m contiguous, zero padded) + per-workgroup column sums for db.
 // One workgroup = 64 rows x all columns, 64 columns at a time through an LDS tile.
 __global__ __launch_bounds__(256) void dy_planes_kernel(const float *__restrict__ dY, int64_t lddy,
@@ -520,7 +650,10 @@ extern "C" int svr_linear_bwd_weight_bf16x3(const float *dY, int64_t lddy, const
   float *dbpart = (float *)w;
   hipLaunchKernelGGL(dy_planes_kernel, dim3((unsigned)parts), dim3(256), 0, s, dY, lddy, ph, pm, Mpad, M, N, db ? dbpart : nullptr);
   dim3 grid(xcd_grid(cdiv(K, TN_TN) * cdiv(N, TN_TM) * splits));
-  hipLaunchKernelGGL(linear_tn_x3_kernel, grid, dim3(256), 0, s, ph, pm, Mpad, X, ldx, slab, M, N, K, rps, splits);
+  if (K % 4 == 0 && ldx % 4 == 0 && ((uintptr_t)X & 15) == 0)
+    hipLaunchKernelGGL(linear_tn_x3_tr_kernel, grid, dim3(256), 0, s, ph, pm, Mpad, X, ldx, slab, M, N, K, rps, splits);
+  else
+    hipLaunchKernelGGL(linear_tn_x3_kernel, grid, dim3(256), 0, s, ph, pm, Mpad, X, ldx, slab, M, N, K, rps, splits);
   hipLaunchKernelGGL(slab_reduce_x3_kernel, dim3((unsigned)cdiv(N * K, 256)), dim3(256), 0, s, slab, dW, N, K, lddw, splits);
   if (db) hipLaunchKernelGGL(dy_db_reduce_kernel, dim3((unsigned)N), dim3(256), 0, s, dbpart, db, N, parts);
   return launch_status("linear_bwd_weight_bf16x3");
