@@ -394,16 +394,17 @@ __device__ __forceinline__ bf16x8 tr_frag(const uint32_t *plane, int byte0, int 
   return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
-__global__ __launch_bounds__(256) void linear_tn_x3_tr_kernel(const uint16_t *__restrict__ dYh,
-                                                              const uint16_t *__restrict__ dYm, int64_t Mpad,
+// Both operands row-major through the transposing read: dY needs no pre-pass either (ATR); the bias gradient is the
+// column sum of the dY rows the K-tile-0 workgroups load anyway.
+__global__ __launch_bounds__(256) void linear_tn_x3_tr_kernel(const float *__restrict__ dY, int64_t lddy,
                                                               const float *__restrict__ X, int64_t ldx,
-                                                              float *__restrict__ slab, int64_t M, int64_t N, int64_t K,
-                                                              int64_t rows_per_split, int splits) {
-  constexpr int APL = TN_TM * XLW;                 // dwords per dY plane [128 n][32 m], 80-byte rows
-  __shared__ __attribute__((aligned(16))) uint32_t lds[2 * APL + 2 * TR_XPLANE];
-  uint32_t *la = lds, *lx = lds + 2 * APL;
+                                                              float *__restrict__ slab, float *__restrict__ dbpart,
+                                                              int64_t M, int64_t N, int64_t K, int64_t rows_per_split,
+                                                              int splits) {
+  __shared__ __attribute__((aligned(16))) uint32_t lds[4 * TR_XPLANE];  // dY hi, dY mid, X hi, X mid: [32 m][128 cols]
+  uint32_t *la = lds, *lx = lds + 2 * TR_XPLANE;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int wr = wave >> 1, wc = wave & 1, l31 = lane & 31, lh = lane >> 5;
+  const int wr = wave >> 1, wc = wave & 1, lh = lane >> 5;
   const int64_t tk = cdiv(K, TN_TN), tiles = tk * cdiv(N, TN_TM), lidx = xcd_logical(blockIdx.x, gridDim.x);
   if (lidx >= tiles * splits) return;
   const int64_t split = lidx / tiles, tile = lidx % tiles;
@@ -411,40 +412,52 @@ __global__ __launch_bounds__(256) void linear_tn_x3_tr_kernel(const uint16_t *__
   const int64_t i0 = (tile % tn) * TN_TM, j0 = (tile / tn) * TN_TN;
   const int64_t kbeg = split * rows_per_split;
   const int64_t kend = min(M, kbeg + rows_per_split);
-  PlaneLoader<TN_TM, 256> al(dYh, dYm, Mpad, i0, N);   // zero padded to Mpad: no tail handling needed
-  // X loader: float4 idx = t + 256 i -> (row = idx >> 5, columns 4 (idx & 31) .. +3)
-  float4 xv[4];
-  const int64_t xcol = min(j0 + 4 * (int64_t)(t & 31), K - 4);  // columns past K are clamped: never stored
-  auto xload = [&](int64_t k0) {
+  // loaders: float4 idx = t + 256 i -> (row = idx >> 5, columns 4 (idx & 31) .. +3); columns past the extent are
+  // clamped (they only feed outputs that are never stored), rows past the range are clamped and zeroed on the way in
+  float4 av[4], xv[4];
+  const int64_t acol = min(i0 + 4 * (int64_t)(t & 31), N - 4), xcol = min(j0 + 4 * (int64_t)(t & 31), K - 4);
+  auto gload = [&](int64_t k0) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int64_t m = min(k0 + (t >> 5) + 8 * i, kend - 1);   // rows past the range are clamped, zeroed in xstore
+      const int64_t m = min(k0 + (t >> 5) + 8 * i, kend - 1);
+      av[i] = *reinterpret_cast<const float4 *>(dY + m * lddy + acol);
       xv[i] = *reinterpret_cast<const float4 *>(X + m * ldx + xcol);
     }
   };
-  auto xstore = [&](int64_t k0) {
+  const bool want_db = dbpart != nullptr && j0 == 0;
+  float4 dbs = make_float4(0.f, 0.f, 0.f, 0.f);
+  auto lstore = [&](int64_t k0) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int r = (t >> 5) + 8 * i;
       const bool ok = k0 + r < kend;
-      uint32_t h0, m0, h1, m1;
-      split2(ok ? xv[i].x : 0.f, ok ? xv[i].y : 0.f, h0, m0);
-      split2(ok ? xv[i].z : 0.f, ok ? xv[i].w : 0.f, h1, m1);
       const int off = (tr_off(r, (t & 31) >> 1) + 8 * (t & 1)) >> 2;  // dwords
+      const float4 a = ok ? av[i] : make_float4(0.f, 0.f, 0.f, 0.f), x = ok ? xv[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+      if (want_db) { dbs.x += a.x; dbs.y += a.y; dbs.z += a.z; dbs.w += a.w; }
+      uint32_t h0, m0, h1, m1;
+      split2(a.x, a.y, h0, m0);
+      split2(a.z, a.w, h1, m1);
+      *reinterpret_cast<uint2 *>(la + off) = make_uint2(h0, h1);
+      *reinterpret_cast<uint2 *>(la + TR_XPLANE + off) = make_uint2(m0, m1);
+      split2(x.x, x.y, h0, m0);
+      split2(x.z, x.w, h1, m1);
       *reinterpret_cast<uint2 *>(lx + off) = make_uint2(h0, h1);
       *reinterpret_cast<uint2 *>(lx + TR_XPLANE + off) = make_uint2(m0, m1);
     }
   };
   // transposed-read addresses of this lane: group g = 16-lane group inside the half, lane 4q+p supplies row q, chunk p>>1
   const int g = (lane >> 4) & 1, q = (lane & 15) >> 2, p = lane & 3;
-  int boff[2][2][2];  // [ks][j][read] byte offsets into an X plane
+  int aoff[2][2][2], boff[2][2][2];  // [ks][tile][read] byte offsets into a plane
 #pragma unroll
   for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int rr = 0; rr < 2; ++rr)
-        boff[ks][j][rr] = tr_off(ks * 16 + lh * 8 + rr * 4 + q, wc * 8 + j * 4 + 2 * g + (p >> 1)) + 8 * (p & 1);
+      for (int rr = 0; rr < 2; ++rr) {
+        const int row = ks * 16 + lh * 8 + rr * 4 + q;
+        aoff[ks][j][rr] = tr_off(row, wr * 8 + j * 4 + 2 * g + (p >> 1)) + 8 * (p & 1);
+        boff[ks][j][rr] = tr_off(row, wc * 8 + j * 4 + 2 * g + (p >> 1)) + 8 * (p & 1);
+      }
 
   f32x16 acc[2][2];
 #pragma unroll
@@ -454,29 +467,20 @@ __global__ __launch_bounds__(256) void linear_tn_x3_tr_kernel(const uint16_t *__
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   if (kbeg < kend) {
-    al.load(kbeg, kend);
-    xload(kbeg);
-    al.store(la);
-    xstore(kbeg);
+    gload(kbeg);
+    lstore(kbeg);
     __syncthreads();
     for (int64_t k0 = kbeg; k0 < kend; k0 += XK) {
       const bool more = k0 + XK < kend;
-      if (more) {
-        al.load(k0 + XK, kend);
-        xload(k0 + XK);
-      }
+      if (more) gload(k0 + XK);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
-        const int kw = ks * 8 + lh * 4;
         bf16x8 ah[2], am[2], bh[2], bm[2];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          ah[i] = read_frag(la, wr * 64 + i * 32 + l31, kw);
-          am[i] = read_frag(la + APL, wr * 64 + i * 32 + l31, kw);
-        }
-#pragma unroll
         for (int j = 0; j < 2; ++j) {
+          ah[j] = tr_frag(la, aoff[ks][j][0], aoff[ks][j][1]);
+          am[j] = tr_frag(la + TR_XPLANE, aoff[ks][j][0], aoff[ks][j][1]);
           bh[j] = tr_frag(lx, boff[ks][j][0], boff[ks][j][1]);
           bm[j] = tr_frag(lx + TR_XPLANE, boff[ks][j][0], boff[ks][j][1]);
         }
@@ -490,10 +494,7 @@ __global__ __launch_bounds__(256) void linear_tn_x3_tr_kernel(const uint16_t *__
           }
       }
       __syncthreads();  // every wave has read its fragments
-      if (more) {
-        al.store(la);
-        xstore(k0 + XK);
-      }
+      if (more) lstore(k0 + XK);
       __syncthreads();
     }
   }
@@ -502,6 +503,16 @@ __global__ __launch_bounds__(256) void linear_tn_x3_tr_kernel(const uint16_t *__
     int64_t i = i0 + row, j = j0 + col;
     if (i < N && j < K) out[i * K + j] = v;
   });
+  if (want_db) {  // fixed-order sum over the 8 row groups that share a column quad
+    float *red = reinterpret_cast<float *>(lds);
+    red[t * 4 + 0] = dbs.x; red[t * 4 + 1] = dbs.y; red[t * 4 + 2] = dbs.z; red[t * 4 + 3] = dbs.w;
+    __syncthreads();
+    if (t < 128) {
+      float sum = 0.f;
+      for (int rg = 0; rg < 8; ++rg) sum += red[(rg * 32 + (t >> 2)) * 4 + (t & 3)];
+      if (i0 + t < N) dbpart[split * N + i0 + t] = sum;
+    }
+  }
 }
 
 // dY[M][N] f32 -> planes hi/mid [N][Mpad] bf16 (m contiguous, zero padded) + per-workgroup column sums for db.
@@ -627,7 +638,8 @@ extern "C" int64_t svr_linear_bwd_weight_bf16x3_workspace(int64_t M, int64_t N, 
   int64_t rps;
   int splits = tn_splits(M, N, K, &rps);
   // slabs | dY planes (hi, mid) | per-row-tile column sums
-  return align256b((int64_t)splits * N * K * 4) + 2 * align256b(N * tn_mpad(M) * 2) + align256b(cdiv(M, 64) * N * 4) + 256;
+  const int64_t dbparts = cdiv(M, 64) > splits ? cdiv(M, 64) : splits;  // row tiles (pre-pass) or splits (tr kernel)
+  return align256b((int64_t)splits * N * K * 4) + 2 * align256b(N * tn_mpad(M) * 2) + align256b(dbparts * N * 4) + 256;
 }
 
 extern "C" int svr_linear_bwd_weight_bf16x3(const float *dY, int64_t lddy, const float *X, int64_t ldx, float *dW,
@@ -648,12 +660,17 @@ extern "C" int svr_linear_bwd_weight_bf16x3(const float *dY, int64_t lddy, const
   uint16_t *pm = (uint16_t *)w;
   w += align256b(N * Mpad * 2);
   float *dbpart = (float *)w;
-  hipLaunchKernelGGL(dy_planes_kernel, dim3((unsigned)parts), dim3(256), 0, s, dY, lddy, ph, pm, Mpad, M, N, db ? dbpart : nullptr);
   dim3 grid(xcd_grid(cdiv(K, TN_TN) * cdiv(N, TN_TM) * splits));
-  if (K % 4 == 0 && ldx % 4 == 0 && ((uintptr_t)X & 15) == 0)
-    hipLaunchKernelGGL(linear_tn_x3_tr_kernel, grid, dim3(256), 0, s, ph, pm, Mpad, X, ldx, slab, M, N, K, rps, splits);
-  else
-    hipLaunchKernelGGL(linear_tn_x3_kernel, grid, dim3(256), 0, s, ph, pm, Mpad, X, ldx, slab, M, N, K, rps, splits);
+  if (K % 4 == 0 && ldx % 4 == 0 && ((uintptr_t)X & 15) == 0 && N >= 4 && K >= 4) {
+    // both operands row-major, transposing LDS reads: no pre-pass over dY; db from the K-tile-0 workgroups
+    hipLaunchKernelGGL(linear_tn_x3_tr_kernel, grid, dim3(256), 0, s, dY, lddy, X, ldx, slab, db ? dbpart : nullptr, M, N, K, rps,
+                       splits);
+    hipLaunchKernelGGL(slab_reduce_x3_kernel, dim3((unsigned)cdiv(N * K, 256)), dim3(256), 0, s, slab, dW, N, K, lddw, splits);
+    if (db) hipLaunchKernelGGL(dy_db_reduce_kernel, dim3((unsigned)N), dim3(256), 0, s, dbpart, db, N, (int64_t)splits);
+    return launch_status("linear_bwd_weight_bf16x3");
+  }
+  hipLaunchKernelGGL(dy_planes_kernel, dim3((unsigned)parts), dim3(256), 0, s, dY, lddy, ph, pm, Mpad, M, N, db ? dbpart : nullptr);
+  hipLaunchKernelGGL(linear_tn_x3_kernel, grid, dim3(256), 0, s, ph, pm, Mpad, X, ldx, slab, M, N, K, rps, splits);
   hipLaunchKernelGGL(slab_reduce_x3_kernel, dim3((unsigned)cdiv(N * K, 256)), dim3(256), 0, s, slab, dW, N, K, lddw, splits);
   if (db) hipLaunchKernelGGL(dy_db_reduce_kernel, dim3((unsigned)N), dim3(256), 0, s, dbpart, db, N, parts);
   return launch_status("linear_bwd_weight_bf16x3");
