@@ -174,6 +174,14 @@ int svr_conv3d_unpack_wgrad(const float *dWp /*[tap][ci][co]*/, float *dW /*(Co,
 int svr_conv3d_k3(const float *in, const float *Wp, const float *bias, float *out, int32_t B,
                   int32_t D, int32_t H, int32_t W, int32_t Ci, int32_t Co, int epilogue,
                   const float *mask, void *stream);
+/* conv_in (Ci == 1, model/ifnet.py:126,165) forward with the statistics of the following BatchNorm3d fused in:
+ * out(B,D,H,W,Co) = epi(conv(in(B,D,H,W,1), Wp[27][1][Co]) + bias), stats[0:Co] = mean, stats[Co:2Co] = biased variance
+ * of `out` (float64: what svr_bn_stats(out) returns) without re-reading the output.  Co in {16, 32}.
+ * workspace: svr_conv3d_c1_fwd_stats_workspace(B, D, H, W, Co) bytes.                                       */
+int64_t svr_conv3d_c1_fwd_stats_workspace(int32_t B, int32_t D, int32_t H, int32_t W, int32_t Co);
+int svr_conv3d_c1_fwd_stats(const float *in, const float *Wp, const float *bias, float *out, double *stats,
+                            int32_t B, int32_t D, int32_t H, int32_t W, int32_t Co, int epilogue,
+                            void *workspace, void *stream);
 /* Forward at f32 accuracy on the bf16 matrix cores (bf16x6, see svr_linear_fwd_bf16x6): takes the UNPACKED
  * weights W(Co,Ci,3,3,3); epilogue NONE / BIAS / BIAS_RELU; Ci % 16 == 0.
  * workspace: svr_conv3d_fwd_bf16x6_workspace(Ci, Co) bytes.                                              */

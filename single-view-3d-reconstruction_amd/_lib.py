@@ -60,6 +60,8 @@ SIGNATURES = {
     "svr_conv3d_k3_fwd_f16x3": (C.c_int, [P, P, P, P, I32, I32, I32, I32, I32, I32, C.c_int, P, P]),
     "svr_conv3d_bwd_data_bf16x3_workspace": (I64, [I32, I32]),
     "svr_conv3d_k3_bwd_data_bf16x3": (C.c_int, [P, P, P, I32, I32, I32, I32, I32, I32, C.c_int, P, P, P]),
+    "svr_conv3d_c1_fwd_stats_workspace": (I64, [I32, I32, I32, I32, I32]),
+    "svr_conv3d_c1_fwd_stats": (C.c_int, [P, P, P, P, P, I32, I32, I32, I32, I32, C.c_int, P, P]),
     "svr_conv3d_k3_bwd_weight_workspace": (I64, [I32, I32, I32, I32, I32, I32]),
     "svr_conv3d_k3_bwd_weight": (C.c_int, [P, P, P, P, I32, I32, I32, I32, I32, I32, P, P]),
     "svr_conv3d_k3_bwd_weight_bf16x3_workspace": (I64, [I32, I32, I32, I32, I32, I32]),

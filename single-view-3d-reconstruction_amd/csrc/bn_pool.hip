@@ -341,6 +341,13 @@ int bwd_blocks(int64_t cells, int C) {
 
 }  // namespace
 
+namespace svr {
+// mean / biased variance from per-block partial sums [blocks][2C] (f64): shared with conv3d.hip's fused conv_in forward
+void bn_stats_final_launch(const double *part, double *stats, int64_t rows, int C, int blocks, hipStream_t s) {
+  hipLaunchKernelGGL(bn_stats_final_kernel, dim3(C), dim3(256), 0, s, part, stats, rows, C, blocks);
+}
+}  // namespace svr
+
 extern "C" int64_t svr_bn_stats_workspace(int64_t rows, int32_t C) {
   (void)rows;
   return (int64_t)STAT_BLOCKS_MAX * 2 * C * (int64_t)sizeof(double);

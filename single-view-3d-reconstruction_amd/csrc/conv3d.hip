@@ -21,6 +21,8 @@ namespace svr {
 // defined in gemm.hip
 void colsum_launch(const float *Y, int64_t ldy, float *out, float *part, int64_t M, int64_t N, hipStream_t s);
 int64_t colsum_workspace_floats(int64_t M, int64_t N);
+// defined in bn_pool.hip
+void bn_stats_final_launch(const double *part, double *stats, int64_t rows, int C, int blocks, hipStream_t s);
 }  // namespace svr
 
 namespace {
@@ -55,7 +57,8 @@ constexpr int C1B = 8, C1H = C1B + 2;
 template <int CO>
 __global__ __launch_bounds__(256) void conv3d_c1_mfma_kernel(const float *__restrict__ in, const float *__restrict__ Wp,
                                                              const float *__restrict__ bias, float *__restrict__ out,
-                                                             ConvShape s, int nbz, int nby, int nbx, int mode) {
+                                                             ConvShape s, int nbz, int nby, int nbx, int mode,
+                                                             double *__restrict__ spart) {
   __shared__ float tile[C1H * C1H * C1H];
   __shared__ __attribute__((aligned(16))) float otile[4 * 32 * (CO + 4)];  // per-wave output staging, rows padded by 16 B
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -94,6 +97,7 @@ __global__ __launch_bounds__(256) void conv3d_c1_mfma_kernel(const float *__rest
     toff[kp] = ((tc / 9 - 1) * C1H + ((tc / 3) % 3 - 1)) * C1H + (tc % 3 - 1);
   }
   const float bv = (mode != SVR_EPI_NONE && l31 < CO) ? bias[l31] : 0.f;
+  float ls[4] = {0.f, 0.f, 0.f, 0.f}, lq[4] = {0.f, 0.f, 0.f, 0.f};  // this lane's channel quad: sum, sum of squares
   __syncthreads();
 #pragma unroll
   for (int rt = 0; rt < 4; ++rt) {  // wave w: z-slices 2w, 2w+1, two 32-voxel row tiles each
@@ -125,12 +129,31 @@ __global__ __launch_bounds__(256) void conv3d_c1_mfma_kernel(const float *__rest
       for (int p = 0; p < 32 / VPI; ++p) {
         const int i = p * VPI + lane / G4, c4 = (lane % G4) * 4;
         const int gy = y0 + yh * 4 + i / C1B, gx = x0 + i % C1B;
-        if (gz < s.D && gy < s.H && gx < s.W)
-          *reinterpret_cast<float4 *>(out + ((((int64_t)b * s.D + gz) * s.H + gy) * s.W + gx) * CO + c4) =
-              *reinterpret_cast<const float4 *>(ot + i * (CO + 4) + c4);
+        if (gz < s.D && gy < s.H && gx < s.W) {
+          const float4 o4 = *reinterpret_cast<const float4 *>(ot + i * (CO + 4) + c4);
+          *reinterpret_cast<float4 *>(out + ((((int64_t)b * s.D + gz) * s.H + gy) * s.W + gx) * CO + c4) = o4;
+          if (spart) {  // BatchNorm statistics of what was just written (the following BN would re-read all of it)
+            ls[0] += o4.x; ls[1] += o4.y; ls[2] += o4.z; ls[3] += o4.w;
+            lq[0] += o4.x * o4.x; lq[1] += o4.y * o4.y; lq[2] += o4.z * o4.z; lq[3] += o4.w * o4.w;
+          }
+        }
       }
     }
     __syncthreads();
+  }
+  if (spart) {  // per-workgroup sums in f64 (f32 partials of <= 8 values per lane), fixed order
+    constexpr int G4 = CO / 4;
+    float *red = otile;  // 256 x 8 floats <= 4 * 32 * (CO + 4)
+    static_assert(256 * 8 <= 4 * 32 * (CO + 4), "staging buffer too small for the statistics reduction");
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { red[t * 8 + e] = ls[e]; red[t * 8 + 4 + e] = lq[e]; }
+    __syncthreads();
+    if (t < 2 * CO) {
+      const int ch = t % CO, which = t / CO;  // 0: sum, 1: sum of squares
+      double acc = 0.0;
+      for (int k = 0; k < 256 / G4; ++k) acc += (double)red[(k * G4 + ch / 4) * 8 + which * 4 + (ch & 3)];
+      spart[(int64_t)blockIdx.x * 2 * CO + which * CO + ch] = acc;
+    }
   }
 }
 
@@ -727,8 +750,8 @@ extern "C" int svr_conv3d_k3(const float *in, const float *Wp, const float *bias
     SVR_CHECK(epilogue != SVR_EPI_MASK, SVR_E_UNSUPPORTED, "conv3d: Ci=1 with mask epilogue");
     const int nbz = (int)cdiv(D, C1B), nby = (int)cdiv(H, C1B), nbx = (int)cdiv(W, C1B);
     const unsigned grid = (unsigned)((int64_t)B * nbz * nby * nbx);
-    if (Co == 16) hipLaunchKernelGGL(conv3d_c1_mfma_kernel<16>, dim3(grid), dim3(256), 0, s, in, Wp, bias, out, sh, nbz, nby, nbx, epilogue);
-    else if (Co == 32) hipLaunchKernelGGL(conv3d_c1_mfma_kernel<32>, dim3(grid), dim3(256), 0, s, in, Wp, bias, out, sh, nbz, nby, nbx, epilogue);
+    if (Co == 16) hipLaunchKernelGGL(conv3d_c1_mfma_kernel<16>, dim3(grid), dim3(256), 0, s, in, Wp, bias, out, sh, nbz, nby, nbx, epilogue, (double *)nullptr);
+    else if (Co == 32) hipLaunchKernelGGL(conv3d_c1_mfma_kernel<32>, dim3(grid), dim3(256), 0, s, in, Wp, bias, out, sh, nbz, nby, nbx, epilogue, (double *)nullptr);
     else SVR_CHECK(false, SVR_E_UNSUPPORTED, "conv3d: Ci=1 supports Co in {16,32}, got %d", Co);
     return launch_status("conv3d_c1_fwd");
   }
@@ -818,4 +841,30 @@ extern "C" int svr_conv3d_k3_bwd_weight(const float *in, const float *dout, floa
   }
   if (db) colsum_launch(dout, Co, db, slab + slab_floats, nrows * W, Co, s);
   return launch_status("conv3d_bwd_weight");
+}
+
+extern "C" int64_t svr_conv3d_c1_fwd_stats_workspace(int32_t B, int32_t D, int32_t H, int32_t W, int32_t Co) {
+  return (int64_t)B * cdiv(D, C1B) * cdiv(H, C1B) * cdiv(W, C1B) * 2 * Co * (int64_t)sizeof(double) + 256;
+}
+
+// conv_in (Ci == 1) forward with the BatchNorm statistics of its output fused in: out = epi(conv(in, Wp) + bias) and
+// stats[0:Co] = mean, stats[Co:2Co] = biased variance of `out` over (B,D,H,W), in f64 -- what svr_bn_stats(out) returns,
+// without re-reading the 1 GB output.  Wp: packed forward weights [27][1][Co]; Co in {16, 32}.
+extern "C" int svr_conv3d_c1_fwd_stats(const float *in, const float *Wp, const float *bias, float *out, double *stats,
+                                       int32_t B, int32_t D, int32_t H, int32_t W, int32_t Co, int epilogue, void *workspace,
+                                       void *stream) {
+  SVR_CHECK(in && Wp && out && stats && workspace, SVR_E_BADARG, "conv3d_c1_fwd_stats: null pointer");
+  SVR_CHECK(B > 0 && D > 0 && H > 0 && W > 0, SVR_E_BADSHAPE, "conv3d_c1_fwd_stats: empty volume");
+  SVR_CHECK(epilogue == SVR_EPI_NONE || ((epilogue == SVR_EPI_BIAS || epilogue == SVR_EPI_BIAS_RELU) && bias), SVR_E_BADARG,
+            "conv3d_c1_fwd_stats: epilogue %d", epilogue);
+  hipStream_t s = (hipStream_t)stream;
+  ConvShape sh{B, D, H, W, 1, Co};
+  const int nbz = (int)cdiv(D, C1B), nby = (int)cdiv(H, C1B), nbx = (int)cdiv(W, C1B);
+  const unsigned grid = (unsigned)((int64_t)B * nbz * nby * nbx);
+  double *part = (double *)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+  if (Co == 16) hipLaunchKernelGGL(conv3d_c1_mfma_kernel<16>, dim3(grid), dim3(256), 0, s, in, Wp, bias, out, sh, nbz, nby, nbx, epilogue, part);
+  else if (Co == 32) hipLaunchKernelGGL(conv3d_c1_mfma_kernel<32>, dim3(grid), dim3(256), 0, s, in, Wp, bias, out, sh, nbz, nby, nbx, epilogue, part);
+  else SVR_CHECK(false, SVR_E_UNSUPPORTED, "conv3d_c1_fwd_stats: Co in {16,32}, got %d", Co);
+  bn_stats_final_launch(part, stats, (int64_t)B * D * H * W, Co, (int)grid, s);
+  return launch_status("conv3d_c1_fwd_stats");
 }

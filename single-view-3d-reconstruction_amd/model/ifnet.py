@@ -102,12 +102,17 @@ class _EncoderGatherFn(torch.autograd.Function):
         for si, (convs, bn) in enumerate(ext._stages):
             acts = []
             cur = inp
+            stats = None
             for conv in convs:
-                cur = ops.conv3d_k3_fwd(cur, conv.weight.detach(), conv.bias.detach(), relu=True)
+                if training and len(convs) == 1 and conv.weight.shape[1] == 1 and conv.weight.shape[0] in (16, 32):
+                    # conv_in: the statistics of the BatchNorm that follows come out of the conv kernel's epilogue
+                    cur, stats = ops.conv3d_c1_fwd_stats(cur, conv.weight.detach(), conv.bias.detach(), relu=True)
+                else:
+                    cur = ops.conv3d_k3_fwd(cur, conv.weight.detach(), conv.bias.detach(), relu=True)
                 acts.append(cur)
             y, pooled, argmax, ss, mean = ops.bn_forward(
                 cur, bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var, training,
-                eps=bn.eps, momentum=bn.momentum, want_pool=(si + 1 < nst))
+                eps=bn.eps, momentum=bn.momentum, want_pool=(si + 1 < nst), stats=stats)
             if training:
                 bn.num_batches_tracked += 1
             levels.append(y)

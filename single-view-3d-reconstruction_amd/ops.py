@@ -317,6 +317,22 @@ def conv3d_k3_fwd(x, w, bias, relu=True, mode=None):
     return conv3d_k3(x, wf, bias, relu=relu)
 
 
+def conv3d_c1_fwd_stats(x, w, bias, relu=True):
+    """conv_in (Ci == 1) forward + the BatchNorm statistics of its output: (out, stats float64 [mean | biased var])."""
+    _f32(x, w, bias)
+    B, D, H, W, Ci = x.shape
+    Co = w.shape[0]
+    assert Ci == 1 and Co in (16, 32)
+    wf, _ = conv3d_pack_weight(w, want_bwd=False)
+    l = _lib.lib()
+    out = torch.empty(B, D, H, W, Co, device=x.device, dtype=torch.float32)
+    stats = torch.empty(2 * Co, device=x.device, dtype=torch.float64)
+    ws = torch.empty(l.svr_conv3d_c1_fwd_stats_workspace(B, D, H, W, Co), device=x.device, dtype=torch.uint8)
+    check(l.svr_conv3d_c1_fwd_stats(_p(x), _p(wf), _p(bias), _p(out), _p(stats), B, D, H, W, Co,
+                                    EPI_BIAS_RELU if relu else EPI_BIAS, _p(ws), _stream()), "conv3d_c1_fwd_stats")
+    return out, stats
+
+
 def conv3d_k3_bwd_data(dout, w, mask=None, mode=None):
     """din (B,D,H,W,Ci) = conv^T(dout (B,D,H,W,Co), w (Co,Ci,3,3,3)) [* (mask > 0)]."""
     _f32(dout, w, mask)
@@ -360,8 +376,9 @@ def conv3d_k3_bwd_weight(x, dout, want_bias=True, mode=None):
     return dwp, db
 
 
-def bn_forward(x, gamma, beta, running_mean, running_var, training, eps=1e-5, momentum=0.1, want_pool=True):
-    """x (B,D,H,W,C) -> y, pooled, argmax, scale_shift(3C), mean(C)."""
+def bn_forward(x, gamma, beta, running_mean, running_var, training, eps=1e-5, momentum=0.1, want_pool=True, stats=None):
+    """x (B,D,H,W,C) -> y, pooled, argmax, scale_shift(3C), mean(C).  `stats` (float64 [mean | biased var]): statistics
+    of x already computed by the producer (conv3d_c1_fwd_stats); the statistics pass over x is then skipped."""
     _f32(x, gamma, beta, running_mean, running_var)
     B, D, H, W, Cc = x.shape
     rows = B * D * H * W
@@ -371,8 +388,9 @@ def bn_forward(x, gamma, beta, running_mean, running_var, training, eps=1e-5, mo
                          f"torch.Size([{B}, {Cc}, {D}, {H}, {W}])")
     l = _lib.lib()
     dev = x.device
-    stats = None
-    if training:
+    if not training:
+        stats = None
+    elif stats is None:
         stats = torch.empty(2 * Cc, device=dev, dtype=torch.float64)
         ws = torch.empty(l.svr_bn_stats_workspace(rows, Cc), device=dev, dtype=torch.uint8)
         check(l.svr_bn_stats(_p(x), _p(stats), rows, Cc, _p(ws), _stream()), "bn_stats")

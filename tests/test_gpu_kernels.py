@@ -292,3 +292,20 @@ def test_morton_order_is_a_permutation_and_gather_is_order_independent():
     ops.gather_bwd(vols_g, g2, pts_g, gf, layout, float(np.float32(0.0722)), False, order=order)
     for x1, x2 in zip(g1, g2):
         assert G.rel_err(x2.cpu().numpy(), x1.cpu().numpy()) < 1e-5
+
+
+def test_conv_in_fused_bn_statistics():
+    """svr_conv3d_c1_fwd_stats: same output as the plain conv_in forward, and the statistics svr_bn_stats would compute."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(11)
+    for B, dims, Co in ((2, (9, 7, 11), 16), (1, (16, 16, 16), 16), (1, (8, 8, 8), 32)):
+        x = (torch.rand(B, *dims, 1, generator=g) < 0.3).float()
+        w = torch.randn(Co, 1, 3, 3, 3, generator=g) * 0.3
+        b = torch.randn(Co, generator=g) * 0.1
+        ref = ops.conv3d_k3_fwd(x.cuda(), w.cuda(), b.cuda(), relu=True)
+        out, stats = ops.conv3d_c1_fwd_stats(x.cuda(), w.cuda(), b.cuda(), relu=True)
+        assert torch.equal(out, ref)
+        flat = ref.double().view(-1, Co)
+        mean, var = flat.mean(0), flat.var(0, unbiased=False)
+        assert G.rel_err(stats[:Co].cpu().numpy(), mean.cpu().numpy()) < 1e-6
+        assert G.rel_err(stats[Co:].cpu().numpy(), var.cpu().numpy()) < 1e-6
