@@ -27,7 +27,7 @@ __device__ __forceinline__ uint64_t spread3_10(uint32_t v) {  // 10 bits -> ever
   return x;
 }
 
-// mode 0: Morton code of the position on a 64^3 lattice.  mode 1: Morton code of the base voxel
+// mode 0: Morton code of the position on a 64^3 lattice.  mode 1: row-major index (x fastest) of the base voxel
 // floor(source index)+1 of the undisplaced sample in a D x H x W volume (same arithmetic as gather.hip;
 // a last-bit difference would only cost a run split, never correctness).
 __global__ void sort_key_kernel(const float *__restrict__ points, uint64_t *__restrict__ keys, int32_t *__restrict__ vals,
@@ -53,8 +53,11 @@ __global__ void sort_key_kernel(const float *__restrict__ points, uint64_t *__re
     f = fminf(fmaxf(f, 0.f), (float)hi);
     q[a] = (p == p) ? (uint32_t)f : 0u;
   }
-  // points[...,0] walks the slowest volume axis (z), [...,2] the fastest (x): x in the low bit
-  uint64_t m = spread3_10(q[2]) | (spread3_10(q[1]) << 1) | (spread3_10(q[0]) << 2);
+  // points[...,0] walks the slowest volume axis (z), [...,2] the fastest (x): x in the low bit.
+  // mode 1 orders the base voxels ROW-MAJOR (x fastest): consecutive occupied cells are then x neighbours most of
+  // the time, which is what the scatter's face hand-over between neighbouring runs needs (Morton order: about half).
+  uint64_t m = mode == 1 ? ((uint64_t)q[0] * (uint64_t)(H + 1) + q[1]) * (uint64_t)(W + 1) + q[2]
+                         : (spread3_10(q[2]) | (spread3_10(q[1]) << 1) | (spread3_10(q[0]) << 2));
   keys[i] = ((uint64_t)(i / N) << code_bits) | m;  // only the occupied bits are sorted: fewer radix passes
   vals[i] = (int32_t)i;
 }
@@ -71,10 +74,14 @@ __global__ void permute_points_kernel(const float *__restrict__ points, const in
 
 // bits of the interleaved cell code: 3 x (bits of the largest per-axis cell index)
 int code_bits(int mode, int D, int H, int W) {
-  int hi = (1 << MORTON_BITS) - 1;
-  if (mode == 1) hi = D > H ? (D > W ? D : W) : (H > W ? H : W);
+  if (mode == 1) {  // row-major cell index < (D+1)(H+1)(W+1)
+    const int64_t cells = (int64_t)(D + 1) * (H + 1) * (W + 1);
+    int nb = 1;
+    while ((1LL << nb) < cells) ++nb;
+    return nb;
+  }
   int nb = 1;
-  while ((1 << nb) <= hi) ++nb;
+  while ((1 << nb) <= (1 << MORTON_BITS) - 1) ++nb;
   return 3 * nb;
 }
 

@@ -12,6 +12,8 @@ Every arithmetic step runs in the HIP kernels of libsvr_hip.so (include/svr_hip.
 nn.Conv3d / nn.BatchNorm3d / nn.Conv1d submodules only HOLD the parameters and buffers; their
 torch forward is never called.  There is no CPU fallback.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -44,6 +46,8 @@ _side_stream = None
 
 def _get_side_stream(device):
     global _side_stream
+    if os.environ.get("SVR_NO_SIDE_STREAM"):      # measurement switch: everything on the caller's stream
+        return torch.cuda.current_stream(device)
     if _side_stream is None or _side_stream.device != device:
         _side_stream = torch.cuda.Stream(device=device)
     return _side_stream

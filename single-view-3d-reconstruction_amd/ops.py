@@ -73,7 +73,7 @@ def morton_order(points, want_sorted=False):
 
 
 def voxel_order(points, dims, align_corners=False):
-    """(B*N,) int32: points ordered by the Morton code of their base voxel in a volume of `dims` (D,H,W)."""
+    """(B*N,) int32: points ordered by the row-major index (x fastest) of their base voxel in a volume of `dims` (D,H,W)."""
     _f32(points)
     B, N, _ = points.shape
     l = _lib.lib()
