@@ -65,7 +65,7 @@ typedef struct svr_gather_desc {
  * reference op: it only changes the order in which the gather / scatter kernels visit points
  * (L2 locality, run-combining of atomics); outputs keep the caller's point order.
  * workspace: svr_points_morton_order_workspace() bytes.                                      */
-/* order[i] = index of the i-th point in (sample, Morton code of the BASE VOXEL of its undisplaced
+/* order[i] = index of the i-th point in (sample, row-major index, x fastest, of the BASE VOXEL of its undisplaced
  * trilinear sample in a D x H x W volume) order: points that scatter into the same 8 corners of that
  * level become consecutive, which is what the backward run-combining needs (the base-voxel lattice is
  * shifted by half a voxel, differently at every level, so one global order cannot serve all levels).
