@@ -1,25 +1,45 @@
 #!/usr/bin/env python
 """Headline benchmark: query-points/sec, forward+backward(+Adam), IF-Net 128^3 grid x 50k points.
 
-    python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
 
-One "step" = one full training step of the hot path on one synthetic batch per GPU: 3D conv
-encoder + 6-level trilinear gather + point MLP + BCE loss, backward of all of it, gradient
-all-reduce (N>1) and the Adam update.  Workload at every N: BASELINE.json configs[2] per GPU
-(128^3 grid, 50 000 points, batch 8; configs[3] is the same per-GPU shard x 8 GPUs) -> weak
-scaling.  Inputs are resident in HBM before the timed region.  Prints ONE JSON line on rank 0.
+N = 1 runs in this process.  N > 1: either launched by `python -m torch.distributed.run --nproc-per-node N ...
+bench.py --gpus N` (RANK / WORLD_SIZE in the environment; WORLD_SIZE must equal N), or -- without a launcher
+environment -- this process starts that launcher itself as a CHILD (before anything touches the GPU) and exits with
+its code, so `python bench.py --gpus 8` can never silently measure one GPU.
+
+One "step" = one full training step of the hot path on one synthetic batch per GPU: 3D conv encoder + 6-level
+trilinear gather + point MLP + BCE loss, backward of all of it, gradient all-reduce (N>1) and the Adam update.
+Workload at every N: BASELINE.json configs[2] per GPU (128^3 grid, 50 000 points, batch 8; configs[3] is the same
+per-GPU shard x 8 GPUs) -> weak scaling.  Inputs are resident in HBM before the timed region.  Prints ONE JSON line
+on rank 0.
+
+Roofline block: `roofline` is the north-star kernel, the fused forward gather.  `achieved` /
+`frac` are HBM bytes actually moved per launch (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/gather_traffic.json,
+measured on this workload) / the live HIP-event time of the launch, against the 8 TB/s HBM peak -- a fraction <= 1.
+The ALGORITHMIC rate (93 000 B per query point, most of it cache hits) is reported beside it against the
+L2 roof, and the compulsory-traffic fraction too.  `roofline_kernels` carries the other dominant kernels: the
+backward scatter against the float-atomic roof and the point-MLP GEMMs against the f16 / bf16 MFMA peak.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-GATHER_BYTES_PER_POINT_F32 = 93000          # SURVEY.md §8(d): 7*8*369 reads + 7*369 writes + 12 B coords
-HBM_PEAK_GBPS = 8000.0                       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+GATHER_BYTES_PER_POINT_F32 = 93000          # SURVEY.md 8(d): 7*8*369 reads + 7*369 writes + 12 B coords
+GATHER_BWD_BYTES_PER_POINT_F32 = 92776      # 2583 gradient reads + 12 B + 7*8*368 RMW (counted once)
+HBM_PEAK_GBPS = 8000.0                       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured achievable)
+HBM_ACHIEVABLE_GBPS = 6290.0
+L2_PEAK_GBPS = 34500.0                       # MI355X_MICROARCH.md section L2: ~34.5 TB/s aggregate
+ATOMIC_PEAK_GBPS = 1300.0                    # MI355X_MICROARCH.md "Global float atomics": ~1.3 TB/s of added bytes
+MFMA_F16_PEAK_TFLOPS = 2500.0                # dense f16 / bf16 MFMA peak (spec)
+MLP_FLOP_PER_POINT = 1585152                 # forward FLOP per query point of fc_0..fc_out (f32-equivalent)
+SPLIT_PRODUCTS = 3                           # f16x3 / bf16x3: three MFMA products per f32-equivalent product
 
 
 def synth_batch(seed, B, D, N, device, dist="uniform"):
@@ -44,30 +64,93 @@ def synth_batch(seed, B, D, N, device, dist="uniform"):
     return {"input": x.to(device), "points": pts.to(device), "occupancies": occ.to(device)}
 
 
-def cpu_baseline(D, N, max_seconds=40.0):
-    """The CPU oracle (= the reference's op sequence in stock torch CPU ops) on ONE sample of the
-    same workload, fwd+bwd, on this host's cores.  Bounded: one warm-up-free repetition."""
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(D, N, reps=3):
+    """The CPU oracle (= the reference's op sequence in stock torch CPU ops, oracle/ifnet_oracle.py) on ONE sample
+    of the same workload on this host's cores: 1 warm-up + `reps` timed repetitions, forward and backward timed
+    separately, min and median reported.  ~8 s per repetition on the GPU box."""
+    import statistics
+
     import torch
     from oracle import ifnet_oracle as O
     threads = torch.get_num_threads()
     b = synth_batch(103, 1, D, N, "cpu")
     st = O.make_leaf_state(O.name_seeded_state(128))
-    times = []
-    t_all = time.perf_counter()
-    for rep in range(3):                                  # first repetition doubles as the warm-up
+    fwd, tot = [], []
+    for rep in range(reps + 1):
         for v in st.values():
             v.grad = None
         t0 = time.perf_counter()
         out = O.training_step(st, b, 128)
+        t1 = time.perf_counter()
         out["loss"].backward()
-        times.append(time.perf_counter() - t0)
-        if time.perf_counter() - t_all > max_seconds:
-            break
-    dt = min(times)
-    return {"value": N / dt, "unit": "query-points/s", "cores": threads, "kind": "port",
-            "sample": f"1 sample of the workload (B=1, {D}^3 grid, {N} points), fwd+bwd, best of {len(times)} "
-                      f"repetitions ({', '.join(f'{t:.1f}' for t in times)} s), torch CPU ops with {threads} threads "
-                      "(oracle/ifnet_oracle.py)"}
+        t2 = time.perf_counter()
+        if rep > 0:                                       # repetition 0 is the warm-up
+            fwd.append(t1 - t0)
+            tot.append(t2 - t0)
+    return {"value": N / min(tot), "unit": "query-points/s", "cores": threads, "kind": "port",
+            "value_median": N / statistics.median(tot),
+            "fwd_only": {"value": N / min(fwd), "value_median": N / statistics.median(fwd), "unit": "query-points/s"},
+            "cpu_model": _cpu_model(),
+            "sample": f"1 sample of the workload (B=1, {D}^3 grid, {N} points; x B = one GPU batch), 1 warm-up + {reps} timed "
+                      f"repetitions: fwd+bwd {', '.join(f'{t:.2f}' for t in tot)} s, fwd {', '.join(f'{t:.2f}' for t in fwd)} s; "
+                      f"value = best, value_median = median; torch {torch.__version__} CPU ops with {threads} threads "
+                      "(oracle/ifnet_oracle.py, the reference's op sequence)"}
+
+
+def _relaunch_under_torchrun(a):
+    """`python bench.py --gpus N` without a launcher environment: start N ranks as a child process (nothing in THIS
+    process has touched the GPU yet) and pass its exit code on."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+class _KernelTimer:
+    """HIP-event brackets around selected ops on the stream they are enqueued on (torch's current stream)."""
+
+    def __init__(self, torch):
+        self.torch = torch
+        self.ev = {}
+
+    def wrap(self, mod, name, key=None):
+        orig = getattr(mod, name)
+        torch = self.torch
+
+        def timed(*args, **kw):
+            k = key(*args, **kw) if key else name
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = orig(*args, **kw)
+            e1.record()
+            self.ev.setdefault(k, []).append((e0, e1))
+            return r
+
+        setattr(mod, name, timed)
+        return orig
+
+    def ms_per_step(self, k, steps):
+        return sum(e0.elapsed_time(e1) for e0, e1 in self.ev.get(k, [])) / max(steps, 1)
+
+    def ms_per_launch(self, k):
+        v = self.ev.get(k, [])
+        return sum(e0.elapsed_time(e1) for e0, e1 in v) / max(len(v), 1)
 
 
 def main():
@@ -79,9 +162,19 @@ def main():
     ap.add_argument("--grid", type=int, default=128)
     ap.add_argument("--points", type=int, default=50000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fwd-only", action="store_true")
     ap.add_argument("--dist", choices=["uniform", "surface"], default="uniform",
                     help="query-point distribution; uniform (default) is the reported worst case")
     a = ap.parse_args()
+
+    launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ     # under torch.distributed.run
+    if a.gpus > 1 and not launched:
+        sys.exit(_relaunch_under_torchrun(a))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        sys.exit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {a.gpus}")
 
     import torch
     import torch.distributed as dist
@@ -91,11 +184,7 @@ def main():
     from svr_amd.trainer import ImplicitRefinementTrainer
     from oracle import ifnet_oracle as O            # name-seeded weights only (checker-side helper)
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     torch.cuda.set_device(local_rank)
-    launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ     # under torch.distributed.run
     if launched:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
@@ -109,21 +198,6 @@ def main():
     dp = DataParallelTrainer(trainer, optimizer=opt)
     batch = synth_batch(103 + rank, a.batch, a.grid, a.points, dev, a.dist)
 
-    # live HIP-event timing of the roofline kernel (forward gather) on the stream it runs on
-    ev = []
-    orig_gather = ops.gather_fwd
-
-    def timed_gather(*args, **kw):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        r = orig_gather(*args, **kw)
-        e1.record()
-        ev.append((e0, e1))
-        return r
-
-    import importlib
-    ifnet_mod = importlib.import_module("single-view-3d-reconstruction_amd.model.ifnet")
-
     def sync():
         if launched:
             dist.barrier()
@@ -131,35 +205,79 @@ def main():
 
     for _ in range(a.warmup):
         dp.step(batch)
-    ifnet_mod.ops.gather_fwd = timed_gather
+    # live HIP-event timing of the roofline kernels on the stream they run on (installed after the warm-up)
+    kt = _KernelTimer(torch)
+    restore = [(ops, "gather_fwd", kt.wrap(ops, "gather_fwd")), (ops, "gather_bwd", kt.wrap(ops, "gather_bwd")),
+               (ops, "linear_fwd", kt.wrap(ops, "linear_fwd")), (ops, "linear_bwd_data", kt.wrap(ops, "linear_bwd_data")),
+               (ops, "linear_bwd_weight", kt.wrap(ops, "linear_bwd_weight"))]
     sync()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         out = dp.step(batch)
     sync()
     dt = time.perf_counter() - t0
-    ifnet_mod.ops.gather_fwd = orig_gather
+    for mod, name, orig in restore:
+        setattr(mod, name, orig)
     loss = float(out["loss"].detach())
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
     if launched:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax)
-    gather_ms = sum(e0.elapsed_time(e1) for e0, e1 in ev) / max(len(ev), 1)
+
+    # forward only (no_grad, training-mode BatchNorm: the same kernels as the step's forward half), same batch
+    fwd_ms = None
+    if not a.no_fwd_only:
+        with torch.no_grad():
+            trainer.training_step(batch, 0)
+            sync()
+            t1 = time.perf_counter()
+            for _ in range(a.steps):
+                trainer.training_step(batch, 0)
+            sync()
+            fwd_ms = (time.perf_counter() - t1) / a.steps * 1e3
 
     if rank == 0:
-        pts_per_step = world * a.batch * a.points
+        npts = a.batch * a.points
+        pts_per_step = world * npts
         value = pts_per_step * a.steps / dt
-        alg_bytes = a.batch * a.points * GATHER_BYTES_PER_POINT_F32
-        achieved = alg_bytes / (gather_ms * 1e-3) / 1e9 if gather_ms > 0 else 0.0
-        traffic = None
-        tfile = os.path.join(ROOT, "profiles", "gather_fwd_traffic.json")
+        gather_ms = kt.ms_per_launch("gather_fwd")
+        alg_bytes = npts * GATHER_BYTES_PER_POINT_F32
+        alg_rate = alg_bytes / (gather_ms * 1e-3) / 1e9 if gather_ms > 0 else None
+        # compulsory traffic: every pyramid volume once + coordinates + the feature rows once
+        chans, d = [1, 16, 32, 64, 128, 128], a.grid
+        vol_elems = 0
+        for i, c in enumerate(chans):
+            vol_elems += c * d ** 3
+            if i >= 1:
+                d = max(d // 2, 1)
+        compulsory = a.batch * (vol_elems * 4 + a.points * 12 + a.points * 2583 * 4)
+        traffic, bwd_atomic_bytes, tsrc = None, None, None
+        tfile = os.path.join(ROOT, "profiles", "gather_traffic.json")
         if os.path.exists(tfile):
             try:
                 t = json.load(open(tfile))
-                if t.get("batch") == a.batch and t.get("grid") == a.grid and t.get("points") == a.points:
+                if t.get("batch") == a.batch and t.get("grid") == a.grid and t.get("points") == a.points \
+                        and t.get("dist", "uniform") == a.dist:
                     traffic = t.get("hbm_bytes_per_launch")
+                    bwd_atomic_bytes = t.get("gather_bwd_write_bytes")
+                    tsrc = t.get("source")
             except Exception:
                 traffic = None
+        hbm_rate = traffic / (gather_ms * 1e-3) / 1e9 if (traffic and gather_ms > 0) else None
+        roofline = {
+            "kernel": "gather_fwd_fused_kernel (svr_gather_trilinear_fwd, all 6 levels in one launch)",
+            "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBPS,
+            # HBM bytes actually moved (PMC) / live kernel time: a true fraction of the 8 TB/s roof (null without counters)
+            "achieved": hbm_rate, "frac": (hbm_rate / HBM_PEAK_GBPS) if hbm_rate else None,
+            "frac_of_achievable_6290": (hbm_rate / HBM_ACHIEVABLE_GBPS) if hbm_rate else None,
+            "traffic": traffic, "traffic_source": tsrc, "ms_per_launch": gather_ms,
+            "algorithmic_bytes_per_launch": alg_bytes, "algorithmic_GBps": alg_rate,
+            "algorithmic_frac_of_l2_peak_34500": (alg_rate / L2_PEAK_GBPS) if alg_rate else None,
+            "compulsory_bytes_per_launch": compulsory,
+            "compulsory_frac_of_hbm_peak": (compulsory / (gather_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if gather_ms > 0 else None,
+            "traffic_over_compulsory": (traffic / compulsory) if traffic else None,
+            "note": "algorithmic bytes (93 000 B/point) are mostly L1/L2/Infinity-Cache hits, so they are priced against "
+                    "the L2 roof; frac is counter-measured HBM traffic against the HBM roof"}
         res = {
             "metric": "query-points/sec fwd+bwd (128^3 grid, 50k pts)", "value": value, "unit": "query-points/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
@@ -171,10 +289,36 @@ def main():
                        "arithmetic": "f32 storage everywhere; forward GEMMs/convs: 3-product f16 split on the f16 MFMA "
                                      "(f32-level, ~3e-7 of f64); backward dX/dW GEMMs, conv backward-data and conv weight "
                                      "gradients: bf16x3 split (~1.5e-5 per product); conv_in, BN, gather/scatter: exact f32"},
-            "roofline": {"kernel": "gather_fwd_fused_kernel (svr_gather_trilinear_fwd, all 6 levels in one launch)", "bound": "hbm", "achieved": achieved,
-                         "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                         "ms_per_launch": gather_ms, "algorithmic_bytes_per_launch": alg_bytes, "traffic": traffic},
+            "roofline": roofline,
         }
+        if fwd_ms is not None:
+            res["fwd_only"] = {"value": npts / (fwd_ms * 1e-3), "unit": "query-points/s", "ms_per_step": fwd_ms,
+                               "note": "rank 0, forward + loss under no_grad, training-mode BatchNorm"}
+        kernels = []
+        bwd_ms = kt.ms_per_launch("gather_bwd")
+        if bwd_ms > 0:
+            rate = bwd_atomic_bytes / (bwd_ms * 1e-3) / 1e9 if bwd_atomic_bytes else None
+            kernels.append({"kernel": "gather_bwd (svr_gather_trilinear_bwd: the backward scatter)", "bound": "atomics",
+                            "unit": "GB/s", "peak": ATOMIC_PEAK_GBPS, "achieved": rate,
+                            "frac": (rate / ATOMIC_PEAK_GBPS) if rate else None, "ms_per_launch": bwd_ms,
+                            "traffic": bwd_atomic_bytes,
+                            "algorithmic_bytes_per_launch": npts * GATHER_BWD_BYTES_PER_POINT_F32,
+                            "note": "achieved = float-atomic bytes issued per launch (PMC WRITE_SIZE) / live time, against "
+                                    "the ~1.3 TB/s global-float-atomic rate; null when the scatter issues no atomics or "
+                                    "no counter file matches"})
+        flop_fwd = npts * MLP_FLOP_PER_POINT
+        for key, mult, what in (("linear_fwd", 1, "fc_0..fc_2 forward (f16x3)"),
+                                ("linear_bwd_data", 1, "fc_0..fc_2 dX (bf16x3)"),
+                                ("linear_bwd_weight", 1, "fc_0..fc_2 dW (bf16x3)")):
+            ms = kt.ms_per_step(key, a.steps)
+            if ms > 0:
+                tf = flop_fwd * mult * SPLIT_PRODUCTS / (ms * 1e-3) / 1e12
+                kernels.append({"kernel": f"point-MLP GEMMs: {what}", "bound": "mfma", "unit": "TFLOP/s",
+                                "peak": MFMA_F16_PEAK_TFLOPS, "achieved": tf, "frac": tf / MFMA_F16_PEAK_TFLOPS,
+                                "ms_per_step": ms, "f32_equivalent_TFLOPs": tf / SPLIT_PRODUCTS,
+                                "note": "achieved counts the 3 split products actually issued on the f16/bf16 matrix "
+                                        "cores (f32-equivalent rate = a third); HIP-event bracket of the three calls"})
+        res["roofline_kernels"] = kernels
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(a.grid, a.points)
         print(json.dumps(res), flush=True)

@@ -59,7 +59,22 @@ typedef struct svr_gather_desc {
   float displacement;     /* 0.0722 / 0.035 (model/ifnet.py:144,82)                    */
   const int32_t *order;   /* optional (B*N) processing order from svr_points_morton_order, or NULL */
   svr_level level[SVR_MAX_LEVELS];
+  int32_t flags;          /* SVR_GATHER_* bits, 0 = production defaults                */
 } svr_gather_desc;
+
+/* flags: test / measurement switches; results are the same with or without them.
+ *   WIDE_OFFSETS   forward: take the 64-bit-offset gather body that is otherwise only selected when a
+ *                  volume or the feature matrix has >= 2^31 elements (so tests can reach it at small sizes);
+ *   DETERMINISTIC  backward: scatter without float atomics in a fixed summation order (one wave per
+ *                  (sample, level), serial over the points like ATen's CPU grid_sampler_3d_backward):
+ *                  bit-reproducible run to run, orders of magnitude slower -- for tests only.          */
+#define SVR_GATHER_WIDE_OFFSETS 1
+#define SVR_GATHER_DETERMINISTIC 2
+
+/* Layout pin for bindings in other languages: sizeof(svr_level) / sizeof(svr_gather_desc) as this library was
+ * compiled; a binding asserts its own struct sizes against these before the first call.                   */
+int64_t svr_sizeof_level(void);
+int64_t svr_sizeof_gather_desc(void);
 
 /* order[i] = index (b*N+n) of the i-th point in (sample, Morton code at 64^3) order.  Not a
  * reference op: it only changes the order in which the gather / scatter kernels visit points
@@ -238,8 +253,11 @@ int svr_bn_apply_pool(const float *x, const float *scale_shift, float *y, float 
 /* Backward of [ReLU ->] BN -> {sample, pool}:
  *   dy_total = dy (may be NULL = 0) + unpool(dpooled via argmax) (dpooled may be NULL)
  *   sums[0:C] = sum dy_total, sums[C:2C] = sum dy_total*xhat   (float64, step 1)
- *   dx = gamma*invstd*(dy_total - sum1/n - xhat*sum2/n) * (x > 0 if relu_mask)     (step 2)
- *   dgamma = sum2, dbeta = sum1.                                                            */
+ *   dx = gamma*invstd*(dy_total - sum1/n - xhat*sum2/n) * (x > 0 if relu_mask & 1)  (step 2)
+ *   dgamma = sum2, dbeta = sum1.
+ * relu_mask bit 1 (value 2): the forward used FROZEN statistics (eval mode, running mean / var from
+ * svr_bn_finalize(training = 0)): autograd of F.batch_norm(training=False) is dx = gamma*invstd*dy_total;
+ * dgamma / dbeta are the same sums.                                                          */
 int svr_bn_bwd_reduce(const float *x, const float *dy, const float *dpooled, const uint8_t *argmax,
                       const float *mean_f32, const float *scale_shift, double *sums, int32_t B,
                       int32_t D, int32_t H, int32_t W, int32_t C, void *workspace, void *stream);

@@ -22,13 +22,18 @@ class Level(C.Structure):
 
 class GatherDesc(C.Structure):
     _fields_ = [("n_levels", I32), ("B", I32), ("N", I32), ("row_stride", I32), ("align_corners", I32),
-                ("displacement", F32), ("order", P), ("level", Level * SVR_MAX_LEVELS)]
+                ("displacement", F32), ("order", P), ("level", Level * SVR_MAX_LEVELS), ("flags", I32)]
+
+
+GATHER_WIDE_OFFSETS, GATHER_DETERMINISTIC = 1, 2
 
 
 # name -> (restype, argtypes): exactly the declarations of include/svr_hip.h
 SIGNATURES = {
     "svr_version": (C.c_int, []),
     "svr_last_error": (C.c_char_p, []),
+    "svr_sizeof_level": (I64, []),
+    "svr_sizeof_gather_desc": (I64, []),
     "svr_points_morton_order_workspace": (I64, [I32, I32]),
     "svr_points_morton_order": (C.c_int, [P, P, P, I32, I32, P, P]),
     "svr_points_voxel_order": (C.c_int, [P, P, I32, I32, I32, I32, I32, I32, P, P]),
@@ -102,6 +107,10 @@ def lib():
             fn = getattr(l, name)          # AttributeError here = header/library mismatch
             fn.restype = res
             fn.argtypes = args
+        # layout pin: the ctypes mirrors above against the structs the library was compiled with
+        if l.svr_sizeof_level() != C.sizeof(Level) or l.svr_sizeof_gather_desc() != C.sizeof(GatherDesc):
+            raise RuntimeError(f"svr_level / svr_gather_desc layout mismatch: library {l.svr_sizeof_level()} / "
+                               f"{l.svr_sizeof_gather_desc()} bytes, binding {C.sizeof(Level)} / {C.sizeof(GatherDesc)}")
         _lib = l
     return _lib
 

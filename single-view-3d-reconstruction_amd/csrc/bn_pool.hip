@@ -202,7 +202,7 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(const float *__restrict__ x
   float4 sc = *reinterpret_cast<const float4 *>(ss + q * 4);          // gamma*invstd
   float4 is = *reinterpret_cast<const float4 *>(ss + 2 * v.C + q * 4);  // invstd
   float m1[4] = {0, 0, 0, 0}, m2[4] = {0, 0, 0, 0};
-  if (APPLY) {
+  if (APPLY && !(relu_mask & 2)) {  // bit 1: frozen (running) statistics -> no batch-mean terms, dx = scale * dy
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       m1[i] = (float)(sums[q * 4 + i] / n);
@@ -265,7 +265,7 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(const float *__restrict__ x
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             o[i] = scv[i] * (gg[i] - m1[i] - xh[i] * m2[i]);
-            if (relu_mask && !(av[i] > 0.f)) o[i] = 0.f;
+            if ((relu_mask & 1) && !(av[i] > 0.f)) o[i] = 0.f;
           }
           *reinterpret_cast<float4 *>(dx + off) = make_float4(o[0], o[1], o[2], o[3]);
         } else {

@@ -14,3 +14,5 @@ void set_error(const char *fmt, ...) {
 
 extern "C" int svr_version(void) { return 100; }
 extern "C" const char *svr_last_error(void) { return svr::g_err; }
+extern "C" int64_t svr_sizeof_level(void) { return (int64_t)sizeof(svr_level); }
+extern "C" int64_t svr_sizeof_gather_desc(void) { return (int64_t)sizeof(svr_gather_desc); }

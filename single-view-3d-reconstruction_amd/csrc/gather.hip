@@ -562,6 +562,33 @@ __global__ void corner_index_kernel(const float *__restrict__ points, int32_t *_
   out[gid * 3 + 2] = clamp_int(c.x0f);
 }
 
+// Deterministic scatter (SVR_GATHER_DETERMINISTIC; tests only): no atomics, one thread per (sample, channel) walks
+// j = 0..6, n = 0..N-1 and the 8 corners in ATen's order with plain read-modify-writes -- the summation order of
+// grid_sampler_3d_backward's CPU kernel (torch/include/ATen/native/GridSampler.h safe_add_3d call sequence), so the
+// gradient volumes equal the reference's CPU autograd bit for bit on identical inputs and are reproducible run to run.
+__global__ __launch_bounds__(128) void gather_bwd_serial_kernel(LevelArgs L, const float *__restrict__ points,
+                                                                const float *__restrict__ gfeat, int N,
+                                                                int row_stride, float disp, int ac) {
+  const int b = blockIdx.x, c = threadIdx.x;
+  if (c >= L.C) return;
+  float *gb = L.gvol + (size_t)b * L.D * L.H * L.W * L.C + c;
+  for (int j = 0; j < 7; ++j)
+    for (int n = 0; n < N; ++n) {
+      const int64_t pn = (int64_t)b * N + n;
+      const Corner cr = sample_corner(points + pn * 3, j, disp, L.D, L.H, L.W, ac);
+      const Weights w = corner_weights(cr);
+      const float g = gfeat[pn * row_stride + L.col + j * L.C + c];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int z = w.z0 + (k >> 2), y = w.y0 + ((k >> 1) & 1), x = w.x0 + (k & 1);
+        if (z >= 0 && z < L.D && y >= 0 && y < L.H && x >= 0 && x < L.W) {
+          volatile float *q = gb + (((size_t)z * L.H + y) * L.W + x) * L.C;
+          *q = *q + corner_w(w, k) * g;
+        }
+      }
+    }
+}
+
 int check_desc(const svr_gather_desc *d, bool bwd) {
   SVR_CHECK(d != nullptr, SVR_E_BADARG, "gather: null descriptor");
   SVR_CHECK(d->n_levels >= 1 && d->n_levels <= SVR_MAX_LEVELS, SVR_E_BADARG, "gather: n_levels=%d", d->n_levels);
@@ -609,7 +636,7 @@ extern "C" int svr_gather_trilinear_fwd(const svr_gather_desc *d, const float *p
   A.n = 0;
   unsigned blocks = 0;
   // 32-bit element / row offsets in the shared-geometry body: every volume and the feature matrix below 2^31 elements
-  bool shared = BN * (int64_t)d->row_stride < (1LL << 31);
+  bool shared = BN * (int64_t)d->row_stride < (1LL << 31) && !(d->flags & SVR_GATHER_WIDE_OFFSETS);
   for (int l = 0; l < d->n_levels; ++l)
     if ((int64_t)d->B * d->level[l].D * d->level[l].H * d->level[l].W * d->level[l].C >= (1LL << 31)) shared = false;
   A.shared = shared ? 1 : 0;
@@ -663,6 +690,11 @@ extern "C" int svr_gather_trilinear_bwd(const svr_gather_desc *d, const float *p
                                          d->align_corners));
     }
     if (!gv) continue;
+    if (d->flags & SVR_GATHER_DETERMINISTIC) {
+      hipLaunchKernelGGL(gather_bwd_serial_kernel, dim3((unsigned)d->B), dim3(128), 0, s, L, points, gfeatures, d->N,
+                         d->row_stride, d->displacement, d->align_corners);
+      continue;
+    }
     if (L.C == 1) {  // level 0 (raw grid): scalar atomics
       int64_t total = BN * 7;
       hipLaunchKernelGGL((gather_bwd_kernel<1, true, false>), dim3((unsigned)svr::cdiv(total, 256)), dim3(256), 0, s, L,

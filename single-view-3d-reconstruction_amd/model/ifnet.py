@@ -65,6 +65,7 @@ def _level_orders_async(pts, D, H, W, n_levels, align):
     main = torch.cuda.current_stream()
     side = _get_side_stream(pts.device)
     side.wait_stream(main)          # pts may have just been produced on the main stream
+    pts.record_stream(side)         # ... and must not return to the main stream's pool while the side stream reads it
     launched = False
     with torch.cuda.stream(side):
         for l in range(1, n_levels):
@@ -88,7 +89,7 @@ class _EncoderGatherFn(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, ext, x, points, *params):
+    def forward(ctx, ext, grad_mode, x, points, *params):
         B = x.shape[0]
         D, H, W = x.shape[2:]
         training = ext.training
@@ -101,7 +102,10 @@ class _EncoderGatherFn(torch.autograd.Function):
         # The per-level visiting orders of the backward scatter depend only on the points: their radix sorts (dozens
         # of ~6 us launches) run on a side stream beside the encoder instead of in front of the scatter.
         ctx.level_orders, ctx.orders_ready = None, None
-        if training and x.is_cuda:
+        # only when a backward can follow: grad mode of the CALLER (it is always off inside Function.forward, and
+        # needs_input_grad ignores no_grad) and something that requires grad
+        will_backward = bool(grad_mode) and any(ctx.needs_input_grad)
+        if will_backward and x.is_cuda:
             ctx.level_orders, ctx.orders_ready = _level_orders_async(pts, D, H, W, nst + 1, ext._align)
         for si, (convs, bn) in enumerate(ext._stages):
             acts = []
@@ -126,7 +130,7 @@ class _EncoderGatherFn(torch.autograd.Function):
         # the zero-initialised gradient volumes of the backward scatter (1.45 GB of memset at config 3) are prepared on
         # the side stream too, beside the point MLP, instead of in front of the scatter
         ctx.gvols = None
-        if ctx.orders_ready is not None or (training and x.is_cuda):
+        if will_backward and x.is_cuda:
             main, side = torch.cuda.current_stream(), _get_side_stream(x.device)
             with torch.cuda.stream(side):
                 ctx.gvols = [None] + [torch.zeros_like(v) for v in levels[1:]]
@@ -142,9 +146,7 @@ class _EncoderGatherFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gfeat):
         ext, saved, levels, pts = ctx.ext, ctx.saved, ctx.levels, ctx.pts
-        if not ctx.training:
-            raise RuntimeError("IF-Net HIP path: backward through eval-mode BatchNorm is not implemented")
-        need_x, need_pts = ctx.needs_input_grad[1], ctx.needs_input_grad[2]
+        need_x, need_pts = ctx.needs_input_grad[2], ctx.needs_input_grad[3]
         gfeat = gfeat.contiguous()
         if ctx.gvols is not None:
             gvols = [torch.zeros_like(levels[0]) if need_x else None] + ctx.gvols[1:]
@@ -167,7 +169,7 @@ class _EncoderGatherFn(torch.autograd.Function):
             convs, bn = ext._stages[si]
             inp, acts, argmax, ss, mean = saved[si]
             dout, dgamma, dbeta = ops.bn_backward(acts[-1], gvols[si + 1], dpooled, argmax if dpooled is not None else None,
-                                                  mean, ss, relu_mask=True)
+                                                  mean, ss, relu_mask=True, training=ctx.training)
             grads[bn.weight], grads[bn.bias] = dgamma, dbeta
             for k in range(len(convs) - 1, -1, -1):
                 conv = convs[k]
@@ -184,7 +186,7 @@ class _EncoderGatherFn(torch.autograd.Function):
                     gx = ops.conv3d_k3_bwd_data(dout, conv.weight.detach())
         if need_x:
             gx = (gx + gvols[0]).view(ctx.x_shape)
-        out = [None, gx, gpts]
+        out = [None, None, gx, gpts]
         for p in ext._param_list:
             out.append(grads.get(p))
         return tuple(out)
@@ -266,7 +268,7 @@ class _ExtractorBase(nn.Module):
         """(B*N, FS) rows in the internal column layout (what the point MLP consumes)."""
         if not x.is_cuda:
             raise RuntimeError("IF-Net HIP path needs GPU tensors (no CPU fallback)")
-        return _EncoderGatherFn.apply(self, x.float(), points.float(), *self._param_list)
+        return _EncoderGatherFn.apply(self, torch.is_grad_enabled(), x.float(), points.float(), *self._param_list)
 
     def forward(self, x, points):
         """Reference layout (B, sumC, 1, 7, N) -- model/ifnet.py:197; used by API-compat callers."""

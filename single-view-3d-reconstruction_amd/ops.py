@@ -84,8 +84,9 @@ def voxel_order(points, dims, align_corners=False):
     return order
 
 
-def make_gather_desc(vols, gvols, layout, B, N, displacement, align_corners, order=None, level_orders=None):
+def make_gather_desc(vols, gvols, layout, B, N, displacement, align_corners, order=None, level_orders=None, flags=0):
     d = GatherDesc()
+    d.flags = int(flags)
     d.order = _p(order)
     d.n_levels = len(vols)
     d.B, d.N = B, N
@@ -106,10 +107,16 @@ def make_gather_desc(vols, gvols, layout, B, N, displacement, align_corners, ord
     return d
 
 
-def gather_fwd(vols, points, layout, displacement, align_corners, out=None, order=None):
+# Test switches (results do not change): GATHER_FLAGS is OR-ed into every gather descriptor --
+# _lib.GATHER_WIDE_OFFSETS takes the 64-bit-offset forward body at any size, _lib.GATHER_DETERMINISTIC replaces the
+# atomic backward scatter by the serial fixed-order one (bit-reproducible; equals ATen's CPU summation order).
+GATHER_FLAGS = 0
+
+
+def gather_fwd(vols, points, layout, displacement, align_corners, out=None, order=None, flags=0):
     B, N, _ = points.shape
     _f32(points)
-    d = make_gather_desc(vols, None, layout, B, N, displacement, align_corners, order)
+    d = make_gather_desc(vols, None, layout, B, N, displacement, align_corners, order, flags=flags | GATHER_FLAGS)
     if out is None:   # the kernel writes every column (padding columns as zeros): no memset of the 4 GB buffer
         out = torch.empty(B * N, layout.row_stride, device=points.device, dtype=torch.float32)
     check(_lib.lib().svr_gather_trilinear_fwd(C.byref(d), _p(points), _p(out), _stream()), "gather_fwd")
@@ -117,9 +124,10 @@ def gather_fwd(vols, points, layout, displacement, align_corners, out=None, orde
 
 
 def gather_bwd(vols, gvols, points, gfeat, layout, displacement, align_corners, want_gpoints=False, order=None,
-               level_orders=None):
+               level_orders=None, flags=0):
     B, N, _ = points.shape
-    d = make_gather_desc(vols, gvols, layout, B, N, displacement, align_corners, order, level_orders)
+    d = make_gather_desc(vols, gvols, layout, B, N, displacement, align_corners, order, level_orders,
+                         flags=flags | GATHER_FLAGS)
     gp = torch.empty_like(points) if want_gpoints else None
     check(_lib.lib().svr_gather_trilinear_bwd(C.byref(d), _p(points), _p(gfeat), _p(gp), _stream()), "gather_bwd")
     return gp
@@ -407,8 +415,9 @@ def bn_forward(x, gamma, beta, running_mean, running_var, training, eps=1e-5, mo
     return y, pooled, argmax, ss, mean
 
 
-def bn_backward(x, dy, dpooled, argmax, mean, ss, relu_mask=True):
-    """-> dx (grad wrt the conv pre-activation when relu_mask), dgamma, dbeta."""
+def bn_backward(x, dy, dpooled, argmax, mean, ss, relu_mask=True, training=True):
+    """-> dx (grad wrt the conv pre-activation when relu_mask), dgamma, dbeta.  training=False: the forward normalised
+    with the running statistics (eval mode), so dx has no batch-mean terms."""
     _f32(x, dy, dpooled, mean, ss)
     B, D, H, W, Cc = x.shape
     l = _lib.lib()
@@ -421,7 +430,7 @@ def bn_backward(x, dy, dpooled, argmax, mean, ss, relu_mask=True):
     dgamma = torch.empty(Cc, device=dev, dtype=torch.float32)
     dbeta = torch.empty(Cc, device=dev, dtype=torch.float32)
     check(l.svr_bn_bwd_apply(_p(x), _p(dy), _p(dpooled), _p(argmax), _p(mean), _p(ss), C.c_void_p(0), _p(sums), _p(dx),
-                             _p(dgamma), _p(dbeta), B, D, H, W, Cc, int(relu_mask), _stream()), "bn_bwd_apply")
+                             _p(dgamma), _p(dbeta), B, D, H, W, Cc, int(relu_mask) | (0 if training else 2), _stream()), "bn_bwd_apply")
     return dx, dgamma, dbeta
 
 

@@ -63,3 +63,53 @@ def test_hip_path_refuses_cpu_tensors():
     from svr_amd.model import IFNet
     with pytest.raises(RuntimeError):
         IFNet()(torch.zeros(1, 1, 16, 16, 16), torch.zeros(1, 4, 3))
+
+
+def _doc_stub_namespace():
+    """Execute the ctypes struct definitions of INTEGRATION.md section 3 (the stub a maintainer would paste)."""
+    txt = open(os.path.join(REPO, "INTEGRATION.md")).read()
+    block = re.search(r"```python\nimport ctypes as C, torch\n(.*?)```", txt, flags=re.S).group(1)
+    structs = block.split("lib.svr_gather_trilinear_fwd.restype")[0]
+    structs = "\n".join(l for l in structs.splitlines() if not l.startswith("lib = "))
+    ns = {"C": ctypes}
+    exec(structs, ns)                                   # our own documentation, not reference code
+    return ns
+
+
+def test_header_structs_binding_and_doc_stub_cannot_drift(tmp_path):
+    """include/svr_hip.h is compiled on its own (plain C, gcc) and its sizeof / offsetof of svr_level and
+    svr_gather_desc are compared with (a) the ctypes mirrors in _lib.py, (b) the struct sizes the library itself
+    reports (svr_sizeof_*), (c) the stub documented in INTEGRATION.md -- a field added to one of them fails here,
+    on the CPU, instead of as a wild device read on the GPU."""
+    import subprocess
+    import svr_amd
+    L, Gd = svr_amd._lib.Level, svr_amd._lib.GatherDesc
+    src = tmp_path / "layout.c"
+    lf = [n for n, _ in L._fields_]
+    gf = [n for n, _ in Gd._fields_]
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "svr_hip.h"', 'int main(void) {',
+             '  printf("svr_level %zu\\n", sizeof(svr_level));', '  printf("svr_gather_desc %zu\\n", sizeof(svr_gather_desc));']
+    lines += [f'  printf("svr_level.{f} %zu\\n", offsetof(svr_level, {f}));' for f in lf]
+    lines += [f'  printf("svr_gather_desc.{f} %zu\\n", offsetof(svr_gather_desc, {f}));' for f in gf]
+    lines += ['  printf("SVR_MAX_LEVELS %d\\n", SVR_MAX_LEVELS);', '  return 0;', '}']
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(REPO, "include"), str(src), "-o", str(exe)],
+                   check=True)
+    out = dict(l.rsplit(" ", 1) for l in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
+    out = {k: int(v) for k, v in out.items()}
+    assert out["SVR_MAX_LEVELS"] == svr_amd._lib.SVR_MAX_LEVELS
+    assert out["svr_level"] == ctypes.sizeof(L) and out["svr_gather_desc"] == ctypes.sizeof(Gd)
+    for f in lf:
+        assert out[f"svr_level.{f}"] == getattr(L, f).offset, f
+    for f in gf:
+        assert out[f"svr_gather_desc.{f}"] == getattr(Gd, f).offset, f
+    lib = svr_amd._lib.lib()
+    assert lib.svr_sizeof_level() == out["svr_level"] and lib.svr_sizeof_gather_desc() == out["svr_gather_desc"]
+    # the documented stub
+    ns = _doc_stub_namespace()
+    for name, mirror in (("Level", L), ("GatherDesc", Gd)):
+        doc = ns[name]
+        assert ctypes.sizeof(doc) == ctypes.sizeof(mirror), name
+        assert [(n, getattr(doc, n).offset) for n, _ in doc._fields_] == \
+               [(n, getattr(mirror, n).offset) for n, _ in mirror._fields_], name

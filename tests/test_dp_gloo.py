@@ -94,3 +94,56 @@ def test_grad_bucket_views_alias_one_flat_buffer():
         off += p.numel()
     b.zero()
     assert all(float(p.grad.abs().sum()) == 0 for p in m.parameters())
+
+
+def _ifnet_worker(rank, world, port, q):
+    """The REAL IF-Net parameter list (CPU tensors: only shapes matter for the plumbing) through the same bucket /
+    broadcast / all-reduce / Adam code bench.py runs at N > 1; the gradients are synthetic (the HIP step needs a GPU)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import svr_amd  # noqa: F401
+    from svr_amd.dp import DataParallelTrainer
+    from svr_amd.trainer import ImplicitRefinementTrainer
+    torch.manual_seed(500 + rank)                       # different init + different BN buffers per rank
+    tr = ImplicitRefinementTrainer()
+    with torch.no_grad():
+        for b in tr.buffers():
+            if b.dtype.is_floating_point:
+                b.add_(float(rank))
+    opt = torch.optim.Adam(tr.ifnet.parameters(), lr=1e-3)
+    dp = DataParallelTrainer(tr, optimizer=opt)
+    params = list(tr.parameters())
+    # what a backward would leave behind: fresh gradient tensors, rank dependent
+    dp.bucket.detach_grads()
+    for i, p in enumerate(params):
+        p.grad = torch.full_like(p, float(rank + 1) * (1 + i % 3))
+    dp.bucket.collect_grads()
+    aliased = all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(params, dp.bucket.views))
+    dp.bucket.all_reduce_mean()
+    expect = torch.cat([torch.full((p.numel(),), 1.5 * (1 + i % 3)) for i, p in enumerate(params)])
+    reduced_ok = bool(torch.equal(dp.bucket.flat, expect))
+    opt.step()
+    digest = torch.cat([p.detach().reshape(-1)[:7] for p in params] + [b.detach().float().reshape(-1)[:3] for b in tr.buffers()])
+    q.put((rank, dp.bucket.numel, dp.bucket.flat.numel() * dp.bucket.flat.element_size(), aliased, reduced_ok,
+           digest.numpy().copy(), len(params)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ifnet_parameter_bucket_two_ranks():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ifnet_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=180) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, numel, nbytes, aliased, reduced_ok, digest, nparams in res:
+        assert numel == 2550881 and nbytes == 4 * 2550881        # one 10.2 MB f32 bucket = every IF-Net parameter
+        assert nparams == 36                                     # 9 convs + 5 BN + 4 fc, weight + bias each
+        assert aliased and reduced_ok, rank
+    # broadcast made parameters AND BatchNorm buffers identical, and the identical reduced gradients keep them so
+    assert (res[0][5] == res[1][5]).all()

@@ -144,3 +144,112 @@ def test_dense_grid_inference_matches_per_chunk_reference_loop():
     with torch.no_grad():
         direct = torch.sigmoid(m(x1.cuda(), lattice[:777].unsqueeze(0).cuda())).cpu().numpy().reshape(-1)
     assert G.rel_err(direct, grid.reshape(-1)[:777]) < 1e-6
+
+
+def test_gradient_arithmetic_ab_production_split_vs_exact_f32():
+    """What the production arithmetic (f16x3 forward GEMMs / convs, bf16x3 backward GEMMs / convs / weight gradients)
+    contributes to the gradients ON TOP of the mask-flip noise that the reference gates above have to allow: the same
+    cfg1 step on the GPU with the backward switches at "f32" (exact-f32 MFMA kernels) and at their production values.
+    The forward arithmetic is the production one in both runs (it is deterministic, so both backward passes see the
+    same ReLU masks / pool arg-maxes and the float atomics only differ in summation order): the difference isolates
+    the bf16x3 backward products -- every gradient tensor <= 1e-4 in L2 norm and <= 1e-3 in its largest element.  The
+    forward switches are A/B-ed on the logits: 2e-6."""
+    import svr_amd  # noqa: F401
+    from svr_amd import ops
+    from svr_amd.trainer import bce_with_logits_sum_mean
+    z = G.load("ifnet_cfg1")
+    net_res, x, pts, occ = G.ifnet_inputs(z)
+    switches = ("FORWARD_GEMM", "BACKWARD_GEMM", "FORWARD_CONV", "BACKWARD_CONV", "BACKWARD_CONV_WEIGHT")
+    saved = {k: getattr(ops, k) for k in switches}
+
+    def run():
+        m = _model(net_res, z)
+        logits = m(x.cuda(), pts.cuda())
+        bce_with_logits_sum_mean(logits, occ.cuda()).backward()
+        return logits.detach().cpu(), {n: p.grad.detach().cpu().double() for n, p in m.named_parameters()}
+
+    try:
+        assert saved["BACKWARD_GEMM"] == "bf16x3" and saved["FORWARD_GEMM"] == "f16x3"      # the production defaults
+        lz_prod, g_prod = run()
+        for k in switches:
+            if k.startswith("BACKWARD"):
+                setattr(ops, k, "f32")
+        lz_same, g_exact = run()
+        for k in switches:
+            setattr(ops, k, "f32")
+        lz_exact, _ = run()
+    finally:
+        for k, v in saved.items():
+            setattr(ops, k, v)
+    assert torch.equal(lz_prod, lz_same)                      # same forward bits -> same masks in both backward passes
+    assert G.rel_err(lz_prod.numpy(), lz_exact.numpy()) < 2e-6
+    worst = (0.0, 0.0, "")
+    for name, a in g_exact.items():
+        b = g_prod[name]
+        nrm = float((a - b).norm() / a.norm().clamp_min(1e-30))
+        mx = float((a - b).abs().max() / a.abs().max().clamp_min(1e-30))
+        worst = max(worst, (nrm, mx, name))
+        assert nrm < 1e-4 and mx < 1e-3, (name, nrm, mx)
+    print("A/B production vs exact-f32 arithmetic: worst gradient L2 diff %.2e (max-element %.2e) at %s" % worst)
+
+
+def test_eval_mode_backward_matches_oracle():
+    """Backward through eval-mode BatchNorm (running statistics; autograd of the reference's model/ifnet.py:138-142 in
+    .eval()): gradients wrt the input grid and all parameters against the CPU oracle with training=False."""
+    z = G.load("ifnet_b3")
+    net_res, x, pts, occ = G.ifnet_inputs(z)
+    st = G.state(net_res, z=z)
+    g = torch.Generator().manual_seed(77)
+    for k in st:                                              # non-trivial running statistics
+        if k.endswith("running_mean"):
+            st[k] = torch.rand(st[k].shape, generator=g) * 0.2
+        if k.endswith("running_var"):
+            st[k] = torch.rand(st[k].shape, generator=g) + 0.5
+    import svr_amd  # noqa: F401
+    from svr_amd.model import IFNet
+    m = IFNet(net_res=net_res)
+    m.load_state_dict(st, strict=False)
+    m = m.cuda().eval()
+    xg = (x * 0.7 + 0.1).cuda().requires_grad_(True)
+    logits = m(xg, pts.cuda())
+    w = torch.linspace(-1, 1, logits.numel()).view_as(logits)
+    (logits * w.cuda()).sum().backward()
+    ref_st = O.make_leaf_state(st)
+    xc = (x * 0.7 + 0.1).requires_grad_(True)
+    ref = O.ifnet_forward(ref_st, xc, pts, net_res, training=False)
+    (ref * w).sum().backward()
+    assert G.rel_err(logits.detach().cpu().numpy(), ref.detach().numpy()) < 1e-4
+    for name, b in m.named_buffers():
+        if "running" in name:
+            assert torch.equal(b.cpu(), st[name]), name      # eval mode does not touch the statistics
+    gx, rx = xg.grad.cpu().numpy().astype(np.float64), xc.grad.numpy().astype(np.float64)
+    assert G.rel_err(gx, rx) < 1e-2 and np.median(np.abs(gx - rx)) / np.abs(rx).max() < 1e-4
+    for name, p in m.named_parameters():
+        r = ref_st[name].grad.double()
+        q = p.grad.detach().cpu().double()
+        n = abs(q.norm().item() - r.norm().item()) / (r.norm().item() + 1e-30)
+        e = float((q - r).abs().max() / r.abs().max().clamp_min(1e-30))
+        assert n < 5e-3 and e < 1e-2, (name, n, e)
+        if name.startswith("fc_out"):
+            assert e < 1e-5, (name, e)
+
+
+def test_no_grad_forward_does_not_prepare_the_backward():
+    """The side-stream sorts / 1.45 GB gradient-volume memsets are only queued when a backward can follow."""
+    import importlib
+    ifn = importlib.import_module("single-view-3d-reconstruction_amd.model.ifnet")
+    z = G.load("ifnet_cfg1")
+    net_res, x, pts, _ = G.ifnet_inputs(z)
+    m = _model(net_res, z)
+    calls = []
+    orig = ifn._level_orders_async
+    ifn._level_orders_async = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    try:
+        with torch.no_grad():
+            a = m(x.cuda(), pts.cuda())
+        assert not calls
+        b = m(x.cuda(), pts.cuda())
+        assert calls and b.requires_grad
+    finally:
+        ifn._level_orders_async = orig
+    assert torch.equal(a, b.detach())

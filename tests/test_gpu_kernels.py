@@ -37,22 +37,27 @@ def _rand_levels(B, dims, chans, seed):
     return vols
 
 
+@pytest.mark.parametrize("wide", [False, True], ids=["offsets32", "offsets64"])
 @pytest.mark.parametrize("B,dims,N,spread", [(2, (16, 16, 16), 777, 1.0), (1, (35, 26, 28), 500, 1.3), (3, (32, 32, 32), 1, 1.0)])
-def test_gather_fwd_indices_and_features(B, dims, N, spread):
+def test_gather_fwd_indices_and_features(B, dims, N, spread, wide):
+    """`wide` forces the 64-bit-offset forward body (gather.hip gather_fwd_body<16..128>) that production only takes
+    when a volume or the feature matrix has >= 2^31 elements (B >= 17 at the config-3 shape)."""
     ops = _ops()
+    from svr_amd import _lib
+    flags = _lib.GATHER_WIDE_OFFSETS if wide else 0
     chans = [1, 16, 32, 64, 128, 128]
     vols = _rand_levels(B, dims, chans, 5)
     g = torch.Generator().manual_seed(6)
     pts = (torch.rand(B, N, 3, generator=g) - 0.5) * spread
     layout = ops.FeatureLayout(chans)
     vols_g = [_cl(v) for v in vols]
-    rows = ops.gather_fwd(vols_g, pts.cuda(), layout, float(np.float32(0.0722)), False)
+    rows = ops.gather_fwd(vols_g, pts.cuda(), layout, float(np.float32(0.0722)), False, flags=flags)
     # bit-exact corner indices on every level
     for l, v in enumerate(vols):
         idx = ops.corner_indices(vols_g, pts.cuda(), layout, l, float(np.float32(0.0722)), False).cpu()
         ref, _ = O.corner_indices(pts, v.shape[2:], 128)
         assert torch.equal(idx, ref), f"level {l}"
-    # features vs F.grid_sample (reference layout), tolerance 1e-6 relative (bit-exact expected)
+    # features vs F.grid_sample (reference layout): bit for bit
     ref = O.gather_features(vols, pts, 128)                           # (B, sumC*7, N)
     perm = layout.reference_permutation()
     got = rows.cpu().view(B, N, -1)
@@ -60,27 +65,29 @@ def test_gather_fwd_indices_and_features(B, dims, N, spread):
     got_ref_order = torch.empty(B, N, int(valid.sum()))
     got_ref_order[:, :, perm[valid]] = got[:, :, valid]
     got_ref_order = got_ref_order.permute(0, 2, 1)
-    assert G.rel_err(got_ref_order.numpy(), ref.numpy()) <= 1e-6
+    assert torch.equal(got_ref_order, ref)
     assert torch.all(got[:, :, ~valid] == 0)
-    print("gather bit-exact:", torch.equal(got_ref_order, ref))
 
 
-def test_gather_fwd_align_corners_variant():
+@pytest.mark.parametrize("wide", [False, True], ids=["offsets32", "offsets64"])
+def test_gather_fwd_align_corners_variant(wide):
     ops = _ops()
+    from svr_amd import _lib
     chans = [1, 64, 128, 128]
     B, dims, N = 2, (16, 12, 20), 300
     vols = _rand_levels(B, dims, chans, 9)
     g = torch.Generator().manual_seed(10)
     pts = (torch.rand(B, N, 3, generator=g) - 0.5) * 1.1
     layout = ops.FeatureLayout(chans)
-    rows = ops.gather_fwd([_cl(v) for v in vols], pts.cuda(), layout, float(np.float32(0.035)), True)
+    rows = ops.gather_fwd([_cl(v) for v in vols], pts.cuda(), layout, float(np.float32(0.035)), True,
+                          flags=_lib.GATHER_WIDE_OFFSETS if wide else 0)
     ref = O.gather_features(vols, pts, 32)
     perm = layout.reference_permutation()
     valid = perm >= 0
     got = rows.cpu().view(B, N, -1)
     out = torch.empty(B, N, int(valid.sum()))
     out[:, :, perm[valid]] = got[:, :, valid]
-    assert G.rel_err(out.permute(0, 2, 1).numpy(), ref.numpy()) <= 1e-6
+    assert torch.equal(out.permute(0, 2, 1), ref)
 
 
 def test_gather_bwd_volume_and_point_grads():
@@ -105,6 +112,96 @@ def test_gather_bwd_volume_and_point_grads():
     for l, v in enumerate(vols):
         assert G.rel_err(_ncdhw(gvols[l]).numpy(), v.grad.numpy()) < 1e-5, f"level {l}"
     assert G.rel_err(gp.cpu().numpy(), pts.grad.numpy()) < 1e-4
+
+
+def _gfeat_from_reference_layout(w, layout, B, N):
+    """(B, sumC*7, N) cotangent in the reference's row order -> (B*N, FS) rows in the internal column layout."""
+    perm = layout.reference_permutation()
+    valid = perm >= 0
+    gfeat = torch.zeros(B, N, layout.row_stride)
+    gfeat[:, :, valid] = w.permute(0, 2, 1)[:, :, perm[valid]]
+    return gfeat.view(B * N, -1)
+
+
+@pytest.mark.parametrize("net_res,chans,dims", [(128, [1, 16, 32, 64, 128, 128], (12, 10, 14)), (32, [1, 64, 128, 128], (9, 8, 8))])
+def test_gather_bwd_deterministic_mode_is_bit_exact_and_reproducible(net_res, chans, dims):
+    """SVR_GATHER_DETERMINISTIC: atomic-free scatter in the summation order of ATen's CPU grid_sampler_3d_backward
+    (j, then n, then the 8 corners) -- the gradient volumes equal the reference's CPU autograd BIT FOR BIT and two
+    runs give identical bytes (the production scatter uses float atomics: order dependent in the last bits)."""
+    ops = _ops()
+    from svr_amd import _lib
+    B, N = 2, 300
+    vols = [v.requires_grad_(True) for v in _rand_levels(B, dims, chans, 31)]
+    g = torch.Generator().manual_seed(32)
+    pts = (torch.rand(B, N, 3, generator=g) - 0.5) * 1.15
+    ref = O.gather_features(vols, pts, net_res)
+    w = torch.randn(ref.shape, generator=g)
+    (ref * w).sum().backward()
+    layout = ops.FeatureLayout(chans)
+    gfeat = _gfeat_from_reference_layout(w, layout, B, N).cuda()
+    vols_g = [_cl(v.detach()) for v in vols]
+    a = O.ARCH[net_res]
+    runs = []
+    for _ in range(2):
+        gvols = [torch.zeros_like(v) for v in vols_g]
+        ops.gather_bwd(vols_g, gvols, pts.cuda(), gfeat, layout, float(np.float32(a["disp"])), a["align_corners"],
+                       flags=_lib.GATHER_DETERMINISTIC)
+        runs.append(gvols)
+    for l, v in enumerate(vols):
+        assert torch.equal(runs[0][l], runs[1][l]), f"level {l}: not reproducible"
+        assert torch.equal(_ncdhw(runs[0][l]), v.grad), f"level {l}: not the CPU summation order"
+
+
+@pytest.mark.parametrize("dims,align,N", [((16, 16, 16), False, 6000), ((9, 7, 11), False, 3000), ((8, 8, 8), True, 2500),
+                                         ((5, 6, 4), True, 700)])
+def test_voxel_order_is_a_permutation_and_scatter_under_it(dims, align, N):
+    """svr_points_voxel_order + the per-level `level_orders` of the production scatter (row-major voxel order, two open
+    register runs, face hand-over): the order is a per-sample permutation sorted by base voxel, and with DENSE points
+    (N >= voxels, so runs and hand-overs dominate) the scatter under it equals the natural-order scatter and CPU
+    autograd to 1e-5."""
+    ops = _ops()
+    B = 2
+    chans = [1, 16, 32, 64, 128, 128]
+    net_res = 32 if align else 128
+    g = torch.Generator().manual_seed(41 + N)
+    pts = (torch.rand(B, N, 3, generator=g) - 0.5) * 1.1
+    lv_dims = [dims, dims] + [tuple(max(1, s >> k) for s in dims) for k in range(1, 5)]
+    orders = [None]
+    for l in range(1, 6):
+        o = ops.voxel_order(pts.cuda(), lv_dims[l], align)
+        oc = o.cpu().long()
+        assert sorted(oc.tolist()) == list(range(B * N)), f"level {l}: not a permutation"
+        assert torch.equal(oc // N, torch.arange(B).repeat_interleave(N)), f"level {l}: samples not contiguous"
+        # sorted by the row-major base voxel of the undisplaced sample (j = 0) inside every sample
+        idx, _ = O.corner_indices(pts, lv_dims[l], net_res)          # (B, 7, N, 3) z0,y0,x0
+        base = idx[:, 0].reshape(B * N, 3)[oc].long()
+        Dd, H, W = lv_dims[l]
+        inside = ((base >= -1).all(1)) & (base[:, 0] < Dd) & (base[:, 1] < H) & (base[:, 2] < W)
+        key = ((base[:, 0] + 1) * (H + 1) + base[:, 1] + 1) * (W + 1) + base[:, 2] + 1
+        for b in range(B):
+            kb = key[b * N:(b + 1) * N][inside[b * N:(b + 1) * N]]
+            assert bool((kb[1:] >= kb[:-1]).all()), f"level {l} sample {b}: keys not sorted"
+        orders.append(o)
+    vols = []
+    for l, c in enumerate(chans):
+        vols.append(torch.randn(B, c, *lv_dims[l], generator=g).requires_grad_(True))
+    layout = ops.FeatureLayout(chans)
+    disp = float(np.float32(O.ARCH[net_res]["disp"]))
+    g_ = O.sample_grid(pts, net_res)
+    feats = [F.grid_sample(v, g_, mode="bilinear", padding_mode="zeros", align_corners=align) for v in vols]
+    f = torch.cat(feats, 1)
+    ref = f.reshape(B, f.shape[1] * 7, N)
+    w = torch.randn(ref.shape, generator=g)
+    (ref * w).sum().backward()
+    gfeat = _gfeat_from_reference_layout(w, layout, B, N).cuda()
+    vols_g = [_cl(v.detach()) for v in vols]
+    g_nat = [torch.zeros_like(v) for v in vols_g]
+    g_ord = [torch.zeros_like(v) for v in vols_g]
+    ops.gather_bwd(vols_g, g_nat, pts.cuda(), gfeat, layout, disp, align)
+    ops.gather_bwd(vols_g, g_ord, pts.cuda(), gfeat, layout, disp, align, level_orders=orders)
+    for l, v in enumerate(vols):
+        assert G.rel_err(_ncdhw(g_ord[l]).numpy(), v.grad.numpy()) < 1e-5, f"level {l} (ordered) vs autograd"
+        assert G.rel_err(g_ord[l].cpu().numpy(), g_nat[l].cpu().numpy()) < 1e-5, f"level {l} ordered vs natural"
 
 
 @pytest.mark.parametrize("M,N,K", [(1000, 256, 2592), (130, 512, 64), (4099, 256, 256)])
@@ -254,6 +351,16 @@ def test_bn_pool_fwd_bwd(B, dims, C, pool):
     ye_ref = F.batch_norm(x.detach(), rm, rv, gamma.detach(), beta.detach(), False, 0.1, 1e-5)
     ye = ops.bn_forward(_cl(x.detach()), gamma.detach().cuda(), beta.detach().cuda(), rm_g, rv_g, False, want_pool=False)[0]
     assert G.rel_err(_ncdhw(ye).numpy(), ye_ref.numpy()) < 2e-6
+    # ... and its backward has no batch-mean terms (autograd of F.batch_norm(training=False))
+    xe = x.detach().clone().requires_grad_(True)
+    ge_, be_ = gamma.detach().clone().requires_grad_(True), beta.detach().clone().requires_grad_(True)
+    obj_e = (F.batch_norm(xe, rm, rv, ge_, be_, False, 0.1, 1e-5) * dy).sum()
+    gxe, gge, gbe = torch.autograd.grad(obj_e, (xe, ge_, be_))
+    _, _, _, ss_e, mean_e = ops.bn_forward(_cl(x.detach()), gamma.detach().cuda(), beta.detach().cuda(), rm_g, rv_g, False,
+                                           want_pool=False)
+    dxe, dge, dbe = ops.bn_backward(_cl(x.detach()), _cl(dy), None, None, mean_e, ss_e, relu_mask=True, training=False)
+    assert G.rel_err(_ncdhw(dxe).numpy(), (gxe * (x > 0)).detach().numpy()) < 1e-5
+    assert G.rel_err(dge.cpu().numpy(), gge.numpy()) < 1e-5 and G.rel_err(dbe.cpu().numpy(), gbe.numpy()) < 1e-5
 
 
 def test_morton_order_is_a_permutation_and_gather_is_order_independent():

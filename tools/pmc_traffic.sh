@@ -1,30 +1,64 @@
 #!/bin/bash
-# HBM traffic of the fused gather kernels: two separate rocprofv3 --pmc passes (FETCH_SIZE; WRITE_SIZE) of a short
-# bench run, as MI355X_MICROARCH.md prescribes.  usage (GPU box): bash tools/pmc_traffic.sh  -> gpurun_out/traffic.json
+# HBM traffic of the fused gather kernels: two SEPARATE rocprofv3 --pmc passes (FETCH_SIZE; WRITE_SIZE) of a short
+# bench run, as MI355X_MICROARCH.md (sections HBM, rocprofv3 PMC slots) prescribes: one TCC counter per pass,
+# --kernel-trace only, the program directly after `--`.  Fails fast on a non-zero rocprofv3 exit; every profiler run
+# sits behind its own wall-clock timeout.
+#   usage (GPU box): bash tools/pmc_traffic.sh [tag] [extra bench.py args]
+#   -> gpurun_out/gather_traffic.json  (copy to profiles/gather_traffic.json; bench.py reads that)
+#   -> gpurun_out/pmc_traffic_<COUNTER>/   (counter CSVs; keep the gather rows under profiles/)
+set -u
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
+TAG=${1:-r02}; shift || true
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $C --output-format csv -d $R/gpurun_out/pmc_traffic_$C -o p -- python3 $R/bench.py --no-cpu-baseline --steps 2 --warmup 1 > $R/gpurun_out/pmc_traffic_$C.log 2>&1
+  rm -rf "$R/gpurun_out/pmc_traffic_$C"
+  timeout -k 10 420 rocprofv3 --kernel-trace --pmc $C --output-format csv -d "$R/gpurun_out/pmc_traffic_$C" -o p -- \
+      python3 "$R/bench.py" --no-cpu-baseline --no-fwd-only --steps 2 --warmup 1 "$@" > "$R/gpurun_out/pmc_traffic_$C.log" 2>&1
+  rc=$?
+  if [ $rc -ne 0 ]; then
+    echo "pmc_traffic: rocprofv3 --pmc $C failed (rc=$rc)"; tail -15 "$R/gpurun_out/pmc_traffic_$C.log"; exit 1
+  fi
 done
-python3 - <<PY
-import csv, glob, json, collections
+python3 - "$R" "$TAG" "$@" <<'PY'
+import collections, csv, glob, json, sys
+R, tag, extra = sys.argv[1], sys.argv[2], sys.argv[3:]
+def arg(name, default):
+    return type(default)(extra[extra.index(name) + 1]) if name in extra else default
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
-for f in glob.glob("$R/gpurun_out/pmc_traffic_*/**/*counter_collection.csv", recursive=True):
-    for r in csv.DictReader(open(f)):
+rows = collections.defaultdict(list)
+for f in glob.glob(f"{R}/gpurun_out/pmc_traffic_*/**/*counter_collection.csv", recursive=True):
+    rd = csv.DictReader(open(f))
+    for r in rd:
         n = r["Kernel_Name"]
-        for key in ("gather_fwd_fused_kernel", "gather_bwd_fused_kernel"):
+        for key in ("gather_fwd_fused_kernel", "gather_bwd_fused_kernel", "gather_bwd_brick_kernel"):
             if key in n:
                 agg[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
-out = {}
+                rows[r["Counter_Name"]].append(r)
+for cname, rr in rows.items():                      # the gather rows of each pass, for profiles/
+    with open(f"{R}/gpurun_out/{tag}_pmc_{cname.lower()}_gather_rows.csv", "w", newline="") as fh:
+        w = csv.DictWriter(fh, fieldnames=list(rr[0].keys()))
+        w.writeheader()
+        w.writerows(rr)
+out = {"round": tag, "batch": arg("--batch", 8), "grid": arg("--grid", 128), "points": arg("--points", 50000),
+       "dist": arg("--dist", "uniform")}
 for k, d in agg.items():
     out[k] = {c + "_KB": sum(v) / len(v) for c, v in d.items()}
     out[k]["dispatches_averaged"] = len(next(iter(d.values())))
 f = out.get("gather_fwd_fused_kernel", {})
-if f:
+if "FETCH_SIZE_KB" in f and "WRITE_SIZE_KB" in f:
     fetch = f["FETCH_SIZE_KB"] * 1024
-    out["fetch_bytes_corrected_x2"] = 2 * fetch
+    out["fetch_bytes_raw"] = fetch
+    out["fetch_bytes_corrected_x2"] = 2 * fetch     # gfx950: FETCH_SIZE counts 128-B requests at 64 B (guide, section HBM)
     out["write_bytes"] = f["WRITE_SIZE_KB"] * 1024
     out["hbm_bytes_per_launch"] = 2 * fetch + f["WRITE_SIZE_KB"] * 1024
-json.dump(out, open("$R/gpurun_out/traffic.json", "w"), indent=1)
+bw = 0.0
+for k in ("gather_bwd_fused_kernel", "gather_bwd_brick_kernel"):
+    if "WRITE_SIZE_KB" in out.get(k, {}):
+        bw += out[k]["WRITE_SIZE_KB"] * 1024
+if "gather_bwd_fused_kernel" in out:
+    out["gather_bwd_write_bytes"] = out["gather_bwd_fused_kernel"].get("WRITE_SIZE_KB", 0.0) * 1024   # = atomics issued
+out["source"] = (f"separate rocprofv3 --pmc passes (FETCH_SIZE; WRITE_SIZE) of `bench.py --steps 2 --warmup 1 {' '.join(extra)}` "
+                 f"(tools/pmc_traffic.sh), averaged over the dispatches of each kernel; rows kept in profiles/{tag}_pmc_*_gather_rows.csv")
+json.dump(out, open(f"{R}/gpurun_out/gather_traffic.json", "w"), indent=1)
 print(json.dumps(out))
 PY
