@@ -207,9 +207,13 @@ def main():
         dp.step(batch)
     # live HIP-event timing of the roofline kernels on the stream they run on (installed after the warm-up)
     kt = _KernelTimer(torch)
+    def layer(x, w, *r, **k):          # fc_0 (K = 2592 feature columns) apart from the two 256 x 256 layers
+        return "fc_0" if max(w.shape[-1], x.shape[-1]) > 1024 else "fc_1+fc_2"
+
     restore = [(ops, "gather_fwd", kt.wrap(ops, "gather_fwd")), (ops, "gather_bwd", kt.wrap(ops, "gather_bwd")),
-               (ops, "linear_fwd", kt.wrap(ops, "linear_fwd")), (ops, "linear_bwd_data", kt.wrap(ops, "linear_bwd_data")),
-               (ops, "linear_bwd_weight", kt.wrap(ops, "linear_bwd_weight"))]
+               (ops, "linear_fwd", kt.wrap(ops, "linear_fwd", lambda *r, **k: "linear_fwd:" + layer(*r, **k))),
+               (ops, "linear_bwd_data", kt.wrap(ops, "linear_bwd_data", lambda *r, **k: "linear_bwd_data:" + layer(*r, **k))),
+               (ops, "linear_bwd_weight", kt.wrap(ops, "linear_bwd_weight", lambda *r, **k: "linear_bwd_weight:" + layer(*r, **k)))]
     sync()
     t0 = time.perf_counter()
     for _ in range(a.steps):
@@ -306,18 +310,19 @@ def main():
                             "note": "achieved = float-atomic bytes issued per launch (PMC WRITE_SIZE) / live time, against "
                                     "the ~1.3 TB/s global-float-atomic rate; null when the scatter issues no atomics or "
                                     "no counter file matches"})
-        flop_fwd = npts * MLP_FLOP_PER_POINT
-        for key, mult, what in (("linear_fwd", 1, "fc_0..fc_2 forward (f16x3)"),
-                                ("linear_bwd_data", 1, "fc_0..fc_2 dX (bf16x3)"),
-                                ("linear_bwd_weight", 1, "fc_0..fc_2 dW (bf16x3)")):
-            ms = kt.ms_per_step(key, a.steps)
-            if ms > 0:
-                tf = flop_fwd * mult * SPLIT_PRODUCTS / (ms * 1e-3) / 1e12
-                kernels.append({"kernel": f"point-MLP GEMMs: {what}", "bound": "mfma", "unit": "TFLOP/s",
-                                "peak": MFMA_F16_PEAK_TFLOPS, "achieved": tf, "frac": tf / MFMA_F16_PEAK_TFLOPS,
-                                "ms_per_step": ms, "f32_equivalent_TFLOPs": tf / SPLIT_PRODUCTS,
-                                "note": "achieved counts the 3 split products actually issued on the f16/bf16 matrix "
-                                        "cores (f32-equivalent rate = a third); HIP-event bracket of the three calls"})
+        flops = {"fc_0": npts * 2 * 2583 * 256, "fc_1+fc_2": npts * 2 * 2 * 256 * 256}    # f32-equivalent, per pass
+        for op, what in (("linear_fwd", "forward (f16x3)"), ("linear_bwd_data", "dX (bf16x3)"),
+                         ("linear_bwd_weight", "dW + bias gradient (bf16x3)")):
+            for lay, fl in flops.items():
+                ms = kt.ms_per_step(f"{op}:{lay}", a.steps)
+                if ms > 0:
+                    tf = fl * SPLIT_PRODUCTS / (ms * 1e-3) / 1e12
+                    kernels.append({"kernel": f"point-MLP GEMM {lay} {what}", "bound": "mfma", "unit": "TFLOP/s",
+                                    "peak": MFMA_F16_PEAK_TFLOPS, "achieved": tf, "frac": tf / MFMA_F16_PEAK_TFLOPS,
+                                    "ms_per_step": ms, "f32_equivalent_TFLOPs": tf / SPLIT_PRODUCTS})
+        res["roofline_kernels_note"] = ("MFMA entries: achieved counts the 3 split products actually issued on the f16 / bf16 "
+                                        "matrix cores (the f32-equivalent rate is a third of it); ms = HIP-event brackets "
+                                        "around the C-ABI calls on their stream, summed per step")
         res["roofline_kernels"] = kernels
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(a.grid, a.points)

