@@ -42,6 +42,16 @@ const char *svr_last_error(void);
  * the six F.grid_sample calls :162,168,175,181,187,193, torch.cat :197 and the reshape
  * model/ifnet.py:43-45; 32-variant :93-118).
  * ------------------------------------------------------------------------------------- */
+/* Backward plan of one level for the atomic-free "pull" scatter (svr_gather_pull_plan): the 7*B*N (point,
+ * displacement) items sorted by the row-major key of their base cell, one 16-byte record per item and the first
+ * item of every occupied cell.  All three arrays are device memory owned by the caller.                    */
+typedef struct svr_pull_plan {
+  const uint32_t *keys;  /* (7*B*N) sorted cell keys; items that touch no voxel carry the largest key      */
+  const void *recs;      /* (7*B*N) x {float fx, fy, fz; int32 gfeat_offset} in sorted order               */
+  const int32_t *heads;  /* (B*(D+1)*(H+1)*(W+1) + 1) CSR offsets: heads[c] = number of items with a key < c     */
+  int64_t n_items;       /* 7*B*N                                                                          */
+} svr_pull_plan;
+
 typedef struct svr_level {
   const float *vol; /* (B, D, H, W, C) channels-last                                  */
   float *gvol;      /* backward only: gradient volume, same shape, accumulated into   */
@@ -49,6 +59,9 @@ typedef struct svr_level {
   int32_t col;      /* first column of this level inside a feature row                */
   const int32_t *order; /* backward only, optional: (B*N) visiting order for THIS level from
                            svr_points_voxel_order (overrides svr_gather_desc.order)   */
+  const svr_pull_plan *plan; /* backward only, optional (host pointer, read at call time): scatter this level
+                           atomic-free in pull form.  gvol is then OVERWRITTEN (it need not be zeroed) and
+                           `order` is ignored.  C in {16, 32, 64}.                     */
 } svr_level;
 
 typedef struct svr_gather_desc {
@@ -90,6 +103,19 @@ int svr_points_voxel_order(const float *points, int32_t *order, int32_t B, int32
 int64_t svr_points_morton_order_workspace(int32_t B, int32_t N);
 int svr_points_morton_order(const float *points, int32_t *order, float *sorted_points /* (B,N,3) or NULL */,
                             int32_t B, int32_t N, void *workspace, void *stream);
+
+/* Plan for the pull-form backward scatter of ONE level (volume D x H x W, C channels at feature column `col`).
+ * The scatter of a sparse level is bound by the float-atomic rate (~1.3 TB/s); in pull form every voxel sums the
+ * items of its <= 8 neighbouring base cells in a fixed order and is written once with plain stores: no atomics, no
+ * zero-initialised gradient volume, bit-reproducible.  Not a reference op (ATen's CPU backward scatters serially).
+ * keys / recs / heads: see svr_pull_plan (heads needs B*(D+1)*(H+1)*(W+1)+1 int32).  B*N*row_stride and the cell
+ * count must be below 2^31.  workspace: svr_gather_pull_plan_workspace(B, N) +
+ * svr_gather_pull_plan_workspace_cells(B, D, H, W) bytes.                                                    */
+int64_t svr_gather_pull_plan_workspace(int32_t B, int32_t N);
+int64_t svr_gather_pull_plan_workspace_cells(int32_t B, int32_t D, int32_t H, int32_t W);
+int svr_gather_pull_plan(const float *points, int32_t B, int32_t N, int32_t D, int32_t H, int32_t W, int32_t C,
+                         int32_t col, int32_t row_stride, int32_t align_corners, float displacement,
+                         uint32_t *keys, void *recs, int32_t *heads, void *workspace, void *stream);
 
 /* features[b*N+n][level.col + j*C + c] = trilinear sample j of channel c (zeros padding);
  * columns past the last level (up to row_stride) are written as zeros.                      */

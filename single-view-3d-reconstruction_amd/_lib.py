@@ -16,8 +16,13 @@ P = C.c_void_p
 I32, I64, F32 = C.c_int32, C.c_int64, C.c_float
 
 
+class PullPlan(C.Structure):
+    _fields_ = [("keys", P), ("recs", P), ("heads", P), ("n_items", I64)]
+
+
 class Level(C.Structure):
-    _fields_ = [("vol", P), ("gvol", P), ("C", I32), ("D", I32), ("H", I32), ("W", I32), ("col", I32), ("order", P)]
+    _fields_ = [("vol", P), ("gvol", P), ("C", I32), ("D", I32), ("H", I32), ("W", I32), ("col", I32), ("order", P),
+                ("plan", C.POINTER(PullPlan))]
 
 
 class GatherDesc(C.Structure):
@@ -37,6 +42,9 @@ SIGNATURES = {
     "svr_points_morton_order_workspace": (I64, [I32, I32]),
     "svr_points_morton_order": (C.c_int, [P, P, P, I32, I32, P, P]),
     "svr_points_voxel_order": (C.c_int, [P, P, I32, I32, I32, I32, I32, I32, P, P]),
+    "svr_gather_pull_plan_workspace": (I64, [I32, I32]),
+    "svr_gather_pull_plan_workspace_cells": (I64, [I32, I32, I32, I32]),
+    "svr_gather_pull_plan": (C.c_int, [P, I32, I32, I32, I32, I32, I32, I32, I32, I32, F32, P, P, P, P, P]),
     "svr_gather_trilinear_fwd": (C.c_int, [C.POINTER(GatherDesc), P, P, P]),
     "svr_gather_trilinear_bwd": (C.c_int, [C.POINTER(GatherDesc), P, P, P, P]),
     "svr_gather_corner_indices": (C.c_int, [C.POINTER(GatherDesc), I32, P, P, P]),

@@ -24,6 +24,12 @@ __host__ __device__ inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 
 constexpr int kXcds = 8;
 inline unsigned xcd_grid(int64_t total) { return (unsigned)(kXcds * cdiv(total, kXcds)); }
 __device__ __forceinline__ int64_t xcd_logical(int64_t bid, int64_t grid) { return (bid % kXcds) * (grid / kXcds) + bid / kXcds; }
+// sort.hip: stable 32-bit key / value radix sort (rocPRIM)
+size_t sort_pairs_u32_temp_bytes(int64_t n, int bits);
+hipError_t sort_pairs_u32(void *tmp, size_t tmp_bytes, const uint32_t *kin, uint32_t *kout, const int32_t *vin, int32_t *vout,
+                          int64_t n, int bits, hipStream_t s);
+size_t scan_max_i32_temp_bytes(int64_t n);
+hipError_t scan_max_i32(void *tmp, size_t tmp_bytes, const int32_t *in, int32_t *out, int64_t n, hipStream_t s);
 }  // namespace svr
 
 #define SVR_CHECK(cond, code, ...)      \

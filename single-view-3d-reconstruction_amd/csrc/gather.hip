@@ -589,6 +589,160 @@ __global__ __launch_bounds__(128) void gather_bwd_serial_kernel(LevelArgs L, con
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Backward scatter, PULL form (levels with C <= 64, i.e. the sparse ones: 0.02 .. 1.5 samples per base cell and
+// displacement, where run-combining cannot help and the atomic kernel above sits at the ~1.3 TB/s float-atomic rate).
+//
+// Plan (svr_gather_pull_plan, once per step and level, on a side stream): the 7*B*N items (point, displacement j) are
+// keyed by the row-major index of their base cell c = floor(source index) + 1 in a (D+1) x (H+1) x (W+1) lattice
+// (c = 0 <=> base -1), radix-sorted (stable), and every sorted item gets a 16-byte record {fx, fy, fz, offset of its
+// C gradient values}; cs[c] = number of items with a key below c (CSR offsets: a running maximum over the cell ends).
+// Kernel: a voxel v receives from the cells c = v + d, d in {0,1}^3, with weight f (d = 0: v is the item's upper
+// corner) or 1 - f (d = 1) per axis.  A thread owns XS consecutive x voxels and one float4 of channels: the cells
+// x0 .. x0+XS of one (dz, dy) pair are consecutive keys, so their items are ONE contiguous range [cs[k], cs[k+XS+1]):
+// four ranges per thread, walked together (one item of each per round, all loads of a round issued first).
+// No atomics, no memset of the gradient volume, fixed summation order (sorted order) -> bit-reproducible.
+// (First version: one voxel per thread, walks one after the other: 1.2 ms at level 1 = four dependent load chains per
+// voxel at 16 waves per CU; the x strips put 4x the work behind every chain and read every item once per row pair.)
+// ---------------------------------------------------------------------------------------------
+struct PullRec {
+  float fx, fy, fz;
+  int32_t goff;
+};
+
+__device__ __forceinline__ bool pull_cell(const float *pt, int j, float disp, int D, int H, int W, int ac, int b,
+                                          uint32_t &key, float &fx, float &fy, float &fz) {
+  const Corner c = sample_corner(pt, j, disp, D, H, W, ac);
+  const int x0 = clamp_int(c.x0f), y0 = clamp_int(c.y0f), z0 = clamp_int(c.z0f);
+  fx = c.ix - c.x0f;
+  fy = c.iy - c.y0f;
+  fz = c.iz - c.z0f;
+  if (!(z0 >= -1 && z0 < D && y0 >= -1 && y0 < H && x0 >= -1 && x0 < W)) return false;  // touches no voxel (or NaN)
+  key = (uint32_t)((((int64_t)b * (D + 1) + z0 + 1) * (H + 1) + y0 + 1) * (W + 1) + x0 + 1);
+  return true;
+}
+
+__global__ __launch_bounds__(256) void pull_key_kernel(const float *__restrict__ points, uint32_t *__restrict__ keys,
+                                                       int32_t *__restrict__ vals, int64_t total, int N, int D, int H,
+                                                       int W, float disp, int ac, uint32_t sentinel) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;  // item = pn * 7 + j
+  if (i >= total) return;
+  const int64_t pn = i / 7;
+  const int j = (int)(i - pn * 7);
+  uint32_t key;
+  float fx, fy, fz;
+  const float p3[3] = {points[pn * 3], points[pn * 3 + 1], points[pn * 3 + 2]};
+  const bool ok = pull_cell(p3, j, disp, D, H, W, ac, (int)(pn / N), key, fx, fy, fz);
+  keys[i] = ok ? key : sentinel;
+  vals[i] = (int32_t)i;
+}
+
+// sorted item -> record; the last item of a cell writes the cell's end (same arithmetic as the key kernel: both are
+// compiled in this file)
+__global__ __launch_bounds__(256) void pull_record_kernel(const float *__restrict__ points,
+                                                          const uint32_t *__restrict__ keys,
+                                                          const int32_t *__restrict__ items, PullRec *__restrict__ recs,
+                                                          int32_t *__restrict__ ends, int64_t total, int N, int D, int H,
+                                                          int W, int C, int col, int row_stride, float disp, int ac,
+                                                          uint32_t sentinel) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const uint32_t k = keys[idx];
+  if (k == sentinel) return;
+  const int32_t id = items[idx];
+  const int32_t pn = id / 7;
+  const int j = id - pn * 7;
+  const float p3[3] = {points[(int64_t)pn * 3], points[(int64_t)pn * 3 + 1], points[(int64_t)pn * 3 + 2]};
+  uint32_t key;
+  PullRec r;
+  pull_cell(p3, j, disp, D, H, W, ac, pn / N, key, r.fx, r.fy, r.fz);
+  r.goff = pn * row_stride + col + j * C;
+  recs[idx] = r;
+  if (idx == total - 1 || keys[idx + 1] != k) ends[k + 1] = (int32_t)idx + 1;  // ends[0] stays 0
+}
+
+// workgroup = BZ x BY x BXG strips of XS voxels x C/4 channel quads (256 threads): the voxels that share an item sit
+// in the same workgroup most of the time, so its record and gradient slice are L1 hits after the first touch
+template <int C, int XS, int BZ, int BY, int BXG>
+__global__ __launch_bounds__(256) void gather_bwd_pull_kernel(float *__restrict__ gvol, const uint32_t *__restrict__ keys,
+                                                              const PullRec *__restrict__ recs,
+                                                              const int32_t *__restrict__ cs,
+                                                              const float *__restrict__ gfeat, int n_items, int B, int D,
+                                                              int H, int W) {
+  constexpr int V = C / 4;
+  static_assert(BZ * BY * BXG * V == 256, "brick must fill the workgroup");
+  const int t = threadIdx.x;
+  const int q4 = (t % V) * 4, si = t / V;
+  const int nbx = (W + BXG * XS - 1) / (BXG * XS), nby = (H + BY - 1) / BY, nbz = (D + BZ - 1) / BZ;
+  uint32_t bid = blockIdx.x;
+  const int bx = bid % nbx; bid /= nbx;
+  const int by = bid % nby; bid /= nby;
+  const int bz = bid % nbz;
+  const int b = bid / nbz;
+  const int x0 = (bx * BXG + si % BXG) * XS, y = by * BY + (si / BXG) % BY, z = bz * BZ + si / (BXG * BY);
+  if (x0 >= W || y >= H || z >= D) return;
+  const int ncell = min(XS, W - x0) + 1;  // cells x0 .. x0 + ncell - 1 (cell coordinates end at W)
+  uint32_t kbase[4];
+  int lo[4], hi[4];
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    const int dz = w >> 1, dy = w & 1;
+    kbase[w] = (uint32_t)((((int64_t)b * (D + 1) + z + dz) * (H + 1) + y + dy) * (W + 1) + x0);
+    lo[w] = cs[kbase[w]];
+    hi[w] = cs[kbase[w] + ncell];
+  }
+  float4 acc[XS];
+#pragma unroll
+  for (int i = 0; i < XS; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int last = n_items - 1;
+  // one item of each of the four ranges per round; all key / record loads of a round first (unconditional, from clamped
+  // indices: a load inside a branch is waited for on its own), then the four gradient loads
+  while (lo[0] < hi[0] || lo[1] < hi[1] || lo[2] < hi[2] || lo[3] < hi[3]) {
+    uint32_t k[4];
+    PullRec r[4];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const int i = min(lo[w], last);
+      k[w] = keys[i];
+      r[w] = recs[i];
+    }
+    float4 g[4];
+    bool v[4];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      v[w] = lo[w] < hi[w];
+      g[w] = *reinterpret_cast<const float4 *>(gfeat + (v[w] ? r[w].goff : 0) + q4);
+    }
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const int dz = w >> 1, dy = w & 1;
+      if (v[w]) {
+        const int o = (int)(k[w] - kbase[w]);  // cell x0 + o: voxel x0 + o gets f, voxel x0 + o - 1 gets 1 - f
+        const float wyz = (dy ? 1.f - r[w].fy : r[w].fy) * (dz ? 1.f - r[w].fz : r[w].fz);
+        const float wa = r[w].fx * wyz, wb = (1.f - r[w].fx) * wyz;
+#pragma unroll
+        for (int i = 0; i < XS; ++i) {
+          const float wt = (o == i) ? wa : ((o == i + 1) ? wb : 0.f);
+          acc[i].x += wt * g[w].x; acc[i].y += wt * g[w].y; acc[i].z += wt * g[w].z; acc[i].w += wt * g[w].w;
+        }
+        ++lo[w];
+      }
+    }
+  }
+  float *out = gvol + ((((int64_t)b * D + z) * H + y) * W + x0) * C + q4;
+#pragma unroll
+  for (int i = 0; i < XS; ++i)
+    if (x0 + i < W) *reinterpret_cast<float4 *>(out + (int64_t)i * C) = acc[i];
+}
+
+int64_t pull_cells(int B, int D, int H, int W) { return (int64_t)B * (D + 1) * (H + 1) * (W + 1); }
+int pull_key_bits(int64_t cells) {  // sentinel = cells must fit
+  int nb = 1;
+  while ((1LL << nb) <= cells) ++nb;
+  return nb;
+}
+int64_t al256(int64_t x) { return (x + 255) / 256 * 256; }
+
 int check_desc(const svr_gather_desc *d, bool bwd) {
   SVR_CHECK(d != nullptr, SVR_E_BADARG, "gather: null descriptor");
   SVR_CHECK(d->n_levels >= 1 && d->n_levels <= SVR_MAX_LEVELS, SVR_E_BADARG, "gather: n_levels=%d", d->n_levels);
@@ -690,6 +844,29 @@ extern "C" int svr_gather_trilinear_bwd(const svr_gather_desc *d, const float *p
                                          d->align_corners));
     }
     if (!gv) continue;
+    if (d->level[l].plan && !(d->flags & SVR_GATHER_DETERMINISTIC)) {  // atomic-free pull form: gvol is overwritten
+      const svr_pull_plan *P = d->level[l].plan;
+      SVR_CHECK(L.C == 16 || L.C == 32 || L.C == 64, SVR_E_UNSUPPORTED, "gather_bwd: level %d: pull plan with C=%d", l, L.C);
+      SVR_CHECK(P->keys && P->recs && P->heads && P->n_items == 7 * BN, SVR_E_BADARG, "gather_bwd: level %d: bad pull plan", l);
+      SVR_CHECK(P->n_items < (1LL << 31) && BN * (int64_t)d->row_stride < (1LL << 31), SVR_E_UNSUPPORTED,
+                "gather_bwd: level %d: pull plan needs 32-bit item / gradient offsets", l);
+      const int n = (int)P->n_items;
+      const PullRec *recs = (const PullRec *)P->recs;
+#define SVR_PULL(CC, XS, BZ, BY, BXG)                                                                                     \
+  {                                                                                                                       \
+    const int64_t blocks = (int64_t)d->B * svr::cdiv(L.D, BZ) * svr::cdiv(L.H, BY) * svr::cdiv(L.W, BXG * XS);            \
+    SVR_CHECK(blocks < (1LL << 31), SVR_E_UNSUPPORTED, "gather_bwd: level %d: %ld pull workgroups", l, (long)blocks);     \
+    hipLaunchKernelGGL((gather_bwd_pull_kernel<CC, XS, BZ, BY, BXG>), dim3((unsigned)blocks), dim3(256), 0, s, L.gvol,    \
+                       P->keys, recs, P->heads, gfeatures, n, d->B, L.D, L.H, L.W);                                       \
+  }
+      // strips of 8 / 4 / 4 voxels (measured at config 3: 0.55 / 0.38 / 0.57 ms; strips of 4 / 2 / 2: 0.57 / 0.41 / 0.66,
+      // one voxel per thread: 1.29 / 0.60 / 0.66)
+      if (L.C == 16) SVR_PULL(16, 8, 4, 4, 4)
+      else if (L.C == 32) SVR_PULL(32, 4, 2, 4, 4)
+      else SVR_PULL(64, 4, 2, 2, 4)
+#undef SVR_PULL
+      continue;
+    }
     if (d->flags & SVR_GATHER_DETERMINISTIC) {
       hipLaunchKernelGGL(gather_bwd_serial_kernel, dim3((unsigned)d->B), dim3(128), 0, s, L, points, gfeatures, d->N,
                          d->row_stride, d->displacement, d->align_corners);
@@ -726,4 +903,58 @@ extern "C" int svr_gather_corner_indices(const svr_gather_desc *d, int32_t level
   hipLaunchKernelGGL(corner_index_kernel, dim3((unsigned)svr::cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream,
                      points, out, total, d->N, L.D, L.H, L.W, d->displacement, d->align_corners);
   return svr::launch_status("corner_indices");
+}
+
+extern "C" int64_t svr_gather_pull_plan_workspace(int32_t B, int32_t N) {
+  // items: 3 x uint32 arrays + radix temp; the raw cell ends (cells + 1 ints, at most 2^31 cells) are sized by
+  // svr_gather_pull_plan_workspace_cells below -- callers add both
+  const int64_t T = (int64_t)7 * B * N;
+  if (T <= 0) return 256;
+  return 3 * al256(T * 4) + al256((int64_t)svr::sort_pairs_u32_temp_bytes(T, 32)) + 256;
+}
+
+extern "C" int64_t svr_gather_pull_plan_workspace_cells(int32_t B, int32_t D, int32_t H, int32_t W) {
+  const int64_t cells = pull_cells(B, D, H, W);
+  return al256((cells + 1) * 4) + al256((int64_t)svr::scan_max_i32_temp_bytes(cells + 1)) + 256;
+}
+
+extern "C" int svr_gather_pull_plan(const float *points, int32_t B, int32_t N, int32_t D, int32_t H, int32_t W, int32_t C,
+                                    int32_t col, int32_t row_stride, int32_t align_corners, float displacement,
+                                    uint32_t *keys, void *recs, int32_t *heads, void *workspace, void *stream) {
+  const int64_t T = (int64_t)7 * B * N;
+  SVR_CHECK(B >= 0 && N >= 0 && D > 0 && H > 0 && W > 0, SVR_E_BADSHAPE, "pull_plan: B=%d N=%d dims %dx%dx%d", B, N, D, H, W);
+  SVR_CHECK(heads && workspace, SVR_E_BADARG, "pull_plan: null heads / workspace");
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t cells = pull_cells(B, D, H, W);
+  SVR_CHECK(cells < (1LL << 31) - 1 && T < (1LL << 31) && (int64_t)B * N * row_stride < (1LL << 31), SVR_E_UNSUPPORTED,
+            "pull_plan: %ld cells / %ld items / %ld gradient floats exceed 32-bit offsets", (long)cells, (long)T,
+            (long)((int64_t)B * N * row_stride));
+  char *w = (char *)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+  int32_t *ends = (int32_t *)w;   // raw cell ends, then the running maximum goes to `heads`
+  w += al256((cells + 1) * 4);
+  void *scan_tmp = (void *)w;
+  const size_t scan_bytes = svr::scan_max_i32_temp_bytes(cells + 1);
+  w += al256((int64_t)scan_bytes);
+  hipError_t e = hipMemsetAsync(ends, 0, (size_t)(cells + 1) * sizeof(int32_t), s);
+  SVR_CHECK(e == hipSuccess, (int)e, "pull_plan: memset failed: %s", hipGetErrorString(e));
+  if (T > 0) {
+    SVR_CHECK(points && keys && recs, SVR_E_BADARG, "pull_plan: null pointer");
+    uint32_t *keys_in = (uint32_t *)w;
+    w += al256(T * 4);
+    int32_t *vals_in = (int32_t *)w;
+    w += al256(T * 4);
+    int32_t *items = (int32_t *)w;
+    w += al256(T * 4);
+    const uint32_t sentinel = (uint32_t)cells;
+    const int bits = pull_key_bits(cells);
+    hipLaunchKernelGGL(pull_key_kernel, dim3((unsigned)svr::cdiv(T, 256)), dim3(256), 0, s, points, keys_in, vals_in, T, N, D,
+                       H, W, displacement, align_corners, sentinel);
+    e = svr::sort_pairs_u32((void *)w, svr::sort_pairs_u32_temp_bytes(T, bits), keys_in, keys, vals_in, items, T, bits, s);
+    SVR_CHECK(e == hipSuccess, (int)e, "pull_plan: radix sort failed: %s", hipGetErrorString(e));
+    hipLaunchKernelGGL(pull_record_kernel, dim3((unsigned)svr::cdiv(T, 256)), dim3(256), 0, s, points, keys, items,
+                       (PullRec *)recs, ends, T, N, D, H, W, C, col, row_stride, displacement, align_corners, sentinel);
+  }
+  e = svr::scan_max_i32(scan_tmp, scan_bytes, ends, heads, cells + 1, s);
+  SVR_CHECK(e == hipSuccess, (int)e, "pull_plan: scan failed: %s", hipGetErrorString(e));
+  return svr::launch_status("pull_plan");
 }

@@ -129,6 +129,30 @@ int sort_points(const float *points, int32_t *order, float *sorted_points, int B
 
 }  // namespace
 
+namespace svr {
+// 32-bit key / 32-bit value radix sort (stable) for the pull-form scatter plan (gather.hip)
+size_t sort_pairs_u32_temp_bytes(int64_t n, int bits) {
+  size_t tmp = 0;
+  rocprim::radix_sort_pairs(nullptr, tmp, (uint32_t *)nullptr, (uint32_t *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr,
+                            (size_t)n, 0, bits, (hipStream_t)0);
+  return tmp;
+}
+hipError_t sort_pairs_u32(void *tmp, size_t tmp_bytes, const uint32_t *kin, uint32_t *kout, const int32_t *vin, int32_t *vout,
+                          int64_t n, int bits, hipStream_t s) {
+  return rocprim::radix_sort_pairs(tmp, tmp_bytes, kin, kout, vin, vout, (size_t)n, 0, bits, s);
+}
+// inclusive running maximum (cell -> number of items with a smaller-or-equal key) for the pull plan's CSR offsets
+size_t scan_max_i32_temp_bytes(int64_t n) {
+  size_t tmp = 0;
+  rocprim::inclusive_scan(nullptr, tmp, (const int32_t *)nullptr, (int32_t *)nullptr, (size_t)n, rocprim::maximum<int32_t>(),
+                          (hipStream_t)0);
+  return tmp;
+}
+hipError_t scan_max_i32(void *tmp, size_t tmp_bytes, const int32_t *in, int32_t *out, int64_t n, hipStream_t s) {
+  return rocprim::inclusive_scan(tmp, tmp_bytes, in, out, (size_t)n, rocprim::maximum<int32_t>(), s);
+}
+}  // namespace svr
+
 extern "C" int64_t svr_points_morton_order_workspace(int32_t B, int32_t N) {
   int64_t total = (int64_t)B * N;
   if (total <= 0) return 256;

@@ -53,15 +53,23 @@ def _get_side_stream(device):
     return _side_stream
 
 
-def _level_orders_async(pts, D, H, W, n_levels, align):
-    """Visiting orders for the backward scatter, computed on a side stream; returns (orders per level, ready event).
+# Backward scatter form per level: "pull" = atomic-free pull form for the sparse levels (C <= 64; gather.hip), "atomic" =
+# float atomics with run-combining everywhere (the round-1 path, kept selectable for A/B measurements and tests).
+SCATTER_FORM = os.environ.get("SVR_SCATTER_FORM", "pull")
 
-    Levels with >= ~1 point per voxel get their own order (points sharing a base voxel become consecutive -> long
-    register runs, few atomics); finer levels keep the natural (Morton) order.  Level l has the pyramid's resolution
-    (D, H, W) >> (l - 1) for l >= 1 (level 0 is the input grid, one channel: no order).  (Reusing level 4's order for
-    level 5 saved a sort but cost 0.65 ms in the scatter: every level keeps its own.)"""
-    N = pts.shape[1]
+
+def _level_orders_async(pts, D, H, W, n_levels, align, layout=None, disp=None):
+    """Backward-scatter preparation that depends only on the points, computed on a side stream beside the encoder;
+    returns (orders per level, pull plans per level, ready event).
+
+    Levels with C <= 64 (the sparse ones) get a pull plan (svr_gather_pull_plan: all 7N items of a sample sorted by base
+    cell): they are scattered atomic-free and their gradient volume needs no zero fill.  The wide levels keep the float
+    atomics with run-combining: those with >= ~0.15 points per voxel get their own visiting order (points sharing a base
+    voxel become consecutive -> long register runs, few atomics); level l has the pyramid's resolution (D, H, W) >> (l-1)
+    for l >= 1 (level 0 is the input grid, one channel: neither)."""
+    B, N = pts.shape[0], pts.shape[1]
     orders = [None] * n_levels
+    plans = [None] * n_levels
     main = torch.cuda.current_stream()
     side = _get_side_stream(pts.device)
     side.wait_stream(main)          # pts may have just been produced on the main stream
@@ -70,7 +78,12 @@ def _level_orders_async(pts, D, H, W, n_levels, align):
     with torch.cuda.stream(side):
         for l in range(1, n_levels):
             dhw = (max(D >> (l - 1), 1), max(H >> (l - 1), 1), max(W >> (l - 1), 1))
-            if N >= 0.15 * dhw[0] * dhw[1] * dhw[2] and N > 64:
+            C = layout.channels[l] if layout is not None else 0
+            if SCATTER_FORM == "pull" and layout is not None and ops.pull_plan_supported(B, N, dhw, C, layout.row_stride):
+                plans[l] = ops.pull_plan(pts, dhw, C, layout.col[l], layout.row_stride, disp, align)
+                plans[l].record_stream(main)
+                launched = True
+            elif N >= 0.15 * dhw[0] * dhw[1] * dhw[2] and N > 64:
                 orders[l] = ops.voxel_order(pts, dhw, align)
                 orders[l].record_stream(main)
                 launched = True
@@ -78,7 +91,7 @@ def _level_orders_async(pts, D, H, W, n_levels, align):
         if launched:
             ready = torch.cuda.Event()
             ready.record(side)
-    return orders, ready
+    return orders, plans, ready
 
 
 class _EncoderGatherFn(torch.autograd.Function):
@@ -101,12 +114,13 @@ class _EncoderGatherFn(torch.autograd.Function):
         nst = len(ext._stages)
         # The per-level visiting orders of the backward scatter depend only on the points: their radix sorts (dozens
         # of ~6 us launches) run on a side stream beside the encoder instead of in front of the scatter.
-        ctx.level_orders, ctx.orders_ready = None, None
+        ctx.level_orders, ctx.level_plans, ctx.orders_ready = None, None, None
         # only when a backward can follow: grad mode of the CALLER (it is always off inside Function.forward, and
         # needs_input_grad ignores no_grad) and something that requires grad
         will_backward = bool(grad_mode) and any(ctx.needs_input_grad)
         if will_backward and x.is_cuda:
-            ctx.level_orders, ctx.orders_ready = _level_orders_async(pts, D, H, W, nst + 1, ext._align)
+            ctx.level_orders, ctx.level_plans, ctx.orders_ready = _level_orders_async(
+                pts, D, H, W, nst + 1, ext._align, ext._layout, ext._disp)
         for si, (convs, bn) in enumerate(ext._stages):
             acts = []
             cur = inp
@@ -133,7 +147,9 @@ class _EncoderGatherFn(torch.autograd.Function):
         if will_backward and x.is_cuda:
             main, side = torch.cuda.current_stream(), _get_side_stream(x.device)
             with torch.cuda.stream(side):
-                ctx.gvols = [None] + [torch.zeros_like(v) for v in levels[1:]]
+                # (levels with a pull plan are written by plain stores: no zero fill)
+                ctx.gvols = [None] + [torch.empty_like(v) if ctx.level_plans[l] is not None else torch.zeros_like(v)
+                                      for l, v in enumerate(levels) if l >= 1]
                 for g in ctx.gvols[1:]:
                     g.record_stream(main)
                 ctx.orders_ready = torch.cuda.Event()
@@ -148,20 +164,26 @@ class _EncoderGatherFn(torch.autograd.Function):
         ext, saved, levels, pts = ctx.ext, ctx.saved, ctx.levels, ctx.pts
         need_x, need_pts = ctx.needs_input_grad[2], ctx.needs_input_grad[3]
         gfeat = gfeat.contiguous()
+        level_orders, level_plans = ctx.level_orders, ctx.level_plans
+        if level_orders is None:
+            level_orders, level_plans, ready = _level_orders_async(pts, *levels[0].shape[1:4], len(levels), ext._align,
+                                                                   ext._layout, ext._disp)
+        else:
+            ready = ctx.orders_ready
+        if ops.GATHER_FLAGS & ops._lib.GATHER_DETERMINISTIC:      # the serial test scatter accumulates into zeros
+            level_plans = [None] * len(levels)
+            ctx.gvols = None
         if ctx.gvols is not None:
             gvols = [torch.zeros_like(levels[0]) if need_x else None] + ctx.gvols[1:]
             ctx.gvols = None
         else:
-            gvols = [torch.zeros_like(levels[0]) if need_x else None] + [torch.zeros_like(v) for v in levels[1:]]
-        level_orders = ctx.level_orders
-        if level_orders is None:
-            level_orders, ready = _level_orders_async(pts, *levels[0].shape[1:4], len(levels), ext._align)
-        else:
-            ready = ctx.orders_ready
+            gvols = [torch.zeros_like(levels[0]) if need_x else None] + \
+                    [torch.empty_like(v) if level_plans[l] is not None else torch.zeros_like(v)
+                     for l, v in enumerate(levels) if l >= 1]
         if ready is not None:
             torch.cuda.current_stream().wait_event(ready)
         gpts = ops.gather_bwd(levels, gvols, pts, gfeat, ext._layout, ext._disp, ext._align, want_gpoints=need_pts,
-                              level_orders=level_orders)
+                              level_orders=level_orders, level_plans=level_plans)
         grads = {}
         dpooled = None
         gx = None

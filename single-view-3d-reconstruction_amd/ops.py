@@ -84,7 +84,44 @@ def voxel_order(points, dims, align_corners=False):
     return order
 
 
-def make_gather_desc(vols, gvols, layout, B, N, displacement, align_corners, order=None, level_orders=None, flags=0):
+class PullPlan:
+    """Plan of the atomic-free pull-form backward scatter of one level (svr_gather_pull_plan): keeps the device
+    arrays alive and hands the C struct to the gather descriptor."""
+
+    def __init__(self, keys, recs, heads, n_items):
+        self.keys, self.recs, self.heads = keys, recs, heads
+        self.c = _lib.PullPlan(_p(keys), _p(recs), _p(heads), n_items)
+
+    def record_stream(self, stream):
+        for t in (self.keys, self.recs, self.heads):
+            t.record_stream(stream)
+
+
+def pull_plan_supported(B, N, dims, C, row_stride):
+    cells = B * (dims[0] + 1) * (dims[1] + 1) * (dims[2] + 1)
+    return C in (16, 32, 64) and N > 0 and cells < 2 ** 31 - 1 and 7 * B * N < 2 ** 31 and B * N * row_stride < 2 ** 31
+
+
+def pull_plan(points, dims, C, col, row_stride, displacement, align_corners=False):
+    """Sort the 7*B*N (point, displacement) items of one level by base cell and build the records / cell heads."""
+    _f32(points)
+    B, N, _ = points.shape
+    l = _lib.lib()
+    T = 7 * B * N
+    cells = B * (dims[0] + 1) * (dims[1] + 1) * (dims[2] + 1)
+    dev = points.device
+    keys = torch.empty(max(T, 1), device=dev, dtype=torch.int32)
+    recs = torch.empty(max(T, 1), 4, device=dev, dtype=torch.int32)
+    heads = torch.empty(cells + 1, device=dev, dtype=torch.int32)
+    ws = torch.empty(l.svr_gather_pull_plan_workspace(B, N) + l.svr_gather_pull_plan_workspace_cells(B, *dims), device=dev,
+                     dtype=torch.uint8)
+    check(l.svr_gather_pull_plan(_p(points), B, N, dims[0], dims[1], dims[2], C, col, row_stride, int(align_corners),
+                                 displacement, _p(keys), _p(recs), _p(heads), _p(ws), _stream()), "gather_pull_plan")
+    return PullPlan(keys, recs, heads, T)
+
+
+def make_gather_desc(vols, gvols, layout, B, N, displacement, align_corners, order=None, level_orders=None, flags=0,
+                     level_plans=None):
     d = GatherDesc()
     d.flags = int(flags)
     d.order = _p(order)
@@ -104,6 +141,8 @@ def make_gather_desc(vols, gvols, layout, B, N, displacement, align_corners, ord
         L.C, L.D, L.H, L.W = ref.shape[4], ref.shape[1], ref.shape[2], ref.shape[3]
         L.col = layout.col[l]
         L.order = _p(level_orders[l]) if level_orders is not None else C.c_void_p(0)
+        if level_plans is not None and level_plans[l] is not None:
+            L.plan = C.pointer(level_plans[l].c)
     return d
 
 
@@ -124,10 +163,12 @@ def gather_fwd(vols, points, layout, displacement, align_corners, out=None, orde
 
 
 def gather_bwd(vols, gvols, points, gfeat, layout, displacement, align_corners, want_gpoints=False, order=None,
-               level_orders=None, flags=0):
+               level_orders=None, flags=0, level_plans=None):
+    """level_plans[l] (PullPlan or None): that level is scattered atomic-free in pull form and its gvol OVERWRITTEN
+    (it may be uninitialised); the other levels accumulate into their (zeroed) gvol with float atomics."""
     B, N, _ = points.shape
     d = make_gather_desc(vols, gvols, layout, B, N, displacement, align_corners, order, level_orders,
-                         flags=flags | GATHER_FLAGS)
+                         flags=flags | GATHER_FLAGS, level_plans=level_plans)
     gp = torch.empty_like(points) if want_gpoints else None
     check(_lib.lib().svr_gather_trilinear_bwd(C.byref(d), _p(points), _p(gfeat), _p(gp), _stream()), "gather_bwd")
     return gp

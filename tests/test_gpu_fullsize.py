@@ -46,10 +46,10 @@ def test_config3_gather_bit_exact_on_real_pyramid_and_scatter():
     """Forward gather at 128^3 x 50k x B=8 on the encoder's real pyramid: every level's rows for a strided subset of
     4 167 points per sample equal F.grid_sample bit for bit (CPU, reference op order model/ifnet.py:156-197), the
     corner indices of ALL points are exact, and the 64-bit-offset body gives the same bytes.  Backward scatter at the
-    same size with the production per-level voxel orders: samples 0 and 7 against CPU autograd of grid_sample."""
+    same size in both forms (atomic-free pull plans / float atomics with voxel orders): samples 0 and 7 against CPU
+    autograd of grid_sample, 1e-5; the pull form twice: identical bytes."""
     import svr_amd  # noqa: F401
     from svr_amd import _lib, ops
-    from svr_amd.model.ifnet import _level_orders_async
     m, _ = _model()
     x, pts, _ = _synth(103, B, D, N)
     ext = m.ifnet_feature_extractor
@@ -77,26 +77,48 @@ def test_config3_gather_bit_exact_on_real_pyramid_and_scatter():
     rows_wide = ops.gather_fwd(levels, pg, layout, DISP, False, flags=_lib.GATHER_WIDE_OFFSETS)
     assert torch.equal(rows, rows_wide)
     del rows_wide, got
-    # ---- backward scatter, production configuration (per-level voxel orders from the side stream)
+    # ---- backward scatter at the same size, both forms: production (pull plans for levels 1-3, atomics + voxel orders
+    # for the 128-channel levels) and all-atomic (round-1 path); plan levels start from NaN: every voxel must be written
+    from svr_amd.model import ifnet as ifn
     g = torch.Generator().manual_seed(7)
     gfeat = torch.randn(B * N, layout.row_stride, generator=g).cuda()
-    orders, ready = _level_orders_async(pg, D, D, D, len(levels), False)
-    assert sum(o is not None for o in orders) >= 3
-    if ready is not None:
+    results = {}
+    for form in ("pull", "atomic"):
+        saved_form, ifn.SCATTER_FORM = ifn.SCATTER_FORM, form
+        try:
+            orders, plans, ready = ifn._level_orders_async(pg, D, D, D, len(levels), False, layout, DISP)
+        finally:
+            ifn.SCATTER_FORM = saved_form
+        if form == "pull":
+            assert [p is not None for p in plans] == [False, True, True, True, False, False]
+            assert orders[4] is not None and orders[5] is not None
+        else:
+            assert all(p is None for p in plans) and sum(o is not None for o in orders) >= 3
         torch.cuda.current_stream().wait_event(ready)
-    gvols = [torch.zeros_like(v) for v in levels]
-    ops.gather_bwd(levels, gvols, pg, gfeat, layout, DISP, False, level_orders=orders)
+        gvols = [torch.full_like(v, float("nan")) if plans[l] is not None else torch.zeros_like(v)
+                 for l, v in enumerate(levels)]
+        ops.gather_bwd(levels, gvols, pg, gfeat, layout, DISP, False, level_orders=orders, level_plans=plans)
+        results[form] = gvols
+    # the pull form is bit-reproducible (fixed summation order)
+    orders, plans, ready = ifn._level_orders_async(pg, D, D, D, len(levels), False, layout, DISP)
+    torch.cuda.current_stream().wait_event(ready)
+    again = [torch.empty_like(v) if plans[l] is not None else torch.zeros_like(v) for l, v in enumerate(levels)]
+    ops.gather_bwd(levels, again, pg, gfeat, layout, DISP, False, level_orders=orders, level_plans=plans)
+    for l in (1, 2, 3):
+        assert torch.equal(again[l], results["pull"][l]), f"pull scatter not reproducible, level {l}"
+    del again
+    perm = layout.reference_permutation()
+    valid = perm >= 0
     for b in (0, B - 1):
         vols_c = [_ncdhw(v[b:b + 1]).requires_grad_(True) for v in levels]
         ref = O.gather_features(vols_c, pts[b:b + 1], 128)     # (1, 2583, N), row k = c*7 + j
-        perm = layout.reference_permutation()
-        valid = perm >= 0
         w = torch.empty(1, int(valid.sum()), N)
         w[0, perm[valid]] = gfeat[b * N:(b + 1) * N].cpu()[:, valid].t()
         (ref * w).sum().backward()
-        for l, v in enumerate(vols_c):
-            e = G.rel_err(_ncdhw(gvols[l][b:b + 1]).numpy(), v.grad.numpy())
-            assert e < 1e-5, (b, l, e)
+        for form, gvols in results.items():
+            for l, v in enumerate(vols_c):
+                e = G.rel_err(_ncdhw(gvols[l][b:b + 1]).numpy(), v.grad.numpy())
+                assert e < 1e-5, (form, b, l, e)
 
 
 def test_config3_training_step_matches_oracle():

@@ -33,7 +33,7 @@ def timeit(fn, n=5):
 
 feat = torch.empty(B * N, layout.row_stride, device=dev)
 gfeat = torch.randn(B * N, layout.row_stride, device=dev)
-for name, p in (("random", pts), ("sorted", pts_sorted)):
+for name, p in (() if "--pull-only" in sys.argv else (("random", pts), ("sorted", pts_sorted))):
     print(name, "fwd all levels: %.3f ms" % timeit(lambda: ops.gather_fwd(vols, p, layout, disp, False, out=feat)))
     for l in range(1, 6):
         gv = [None] * 6
@@ -51,3 +51,24 @@ for name, p in (("random", pts), ("sorted", pts_sorted)):
         gv1[l] = torch.zeros_like(vols[l])
         print(f"  bwd level {l} with its voxel order: %.3f ms" % timeit(lambda: ops.gather_bwd(vols, gv1, p, gfeat, layout, disp, False, level_orders=lo)))
     print("  bwd levels 1-5 fused + level orders: %.3f ms" % timeit(lambda: ops.gather_bwd(vols, gv, p, gfeat, layout, disp, False, level_orders=lo)))
+
+# ---- pull form (atomic-free) vs atomics, per level, on the Morton-sorted point set (what the training step sees)
+p = pts_sorted
+print("pull-form scatter (sorted points), SVR_PULL_VARIANT =", os.environ.get("SVR_PULL_VARIANT", "0"))
+plans = [None] * 6
+for l in (1, 2, 3):
+    dims = tuple(vols[l].shape[1:4])
+    t = timeit(lambda: ops.pull_plan(p, dims, chans[l], layout.col[l], layout.row_stride, disp, False))
+    plans[l] = ops.pull_plan(p, dims, chans[l], layout.col[l], layout.row_stride, disp, False)
+    pl = [None] * 6
+    pl[l] = plans[l]
+    gv1 = [None] * 6
+    gv1[l] = torch.empty_like(vols[l])
+    tk = timeit(lambda: ops.gather_bwd(vols, gv1, p, gfeat, layout, disp, False, level_plans=pl))
+    print(f"  level {l} (C={chans[l]}, S={dims[0]}): plan {t:.3f} ms, pull scatter {tk:.3f} ms")
+lo = [None] * 6
+for l in (4, 5):
+    lo[l] = ops.voxel_order(p, tuple(vols[l].shape[1:4]))
+gv = [None] + [torch.empty_like(v) if plans[l] is not None else torch.zeros_like(v) for l, v in enumerate(vols) if l >= 1]
+print("  levels 1-3 pull + 4-5 atomic (orders): %.3f ms" % timeit(
+    lambda: ops.gather_bwd(vols, gv, p, gfeat, layout, disp, False, level_orders=lo, level_plans=plans)))
