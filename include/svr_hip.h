@@ -59,6 +59,9 @@ typedef struct svr_level {
   int32_t col;      /* first column of this level inside a feature row                */
   const int32_t *order; /* backward only, optional: (B*N) visiting order for THIS level from
                            svr_points_voxel_order (overrides svr_gather_desc.order)   */
+  const int32_t *item_order; /* backward only, optional: (7*B*N) item ids from svr_gather_item_order -- the atomic
+                           scatter then walks (point, displacement) items sorted jointly by base cell (7x longer
+                           runs on the coarse levels); overrides `order`             */
   const svr_pull_plan *plan; /* backward only, optional (host pointer, read at call time): scatter this level
                            atomic-free in pull form.  gvol is then OVERWRITTEN (it need not be zeroed) and
                            `order` is ignored.  C in {16, 32, 64}.                     */
@@ -116,6 +119,12 @@ int64_t svr_gather_pull_plan_workspace_cells(int32_t B, int32_t D, int32_t H, in
 int svr_gather_pull_plan(const float *points, int32_t B, int32_t N, int32_t D, int32_t H, int32_t W, int32_t C,
                          int32_t col, int32_t row_stride, int32_t align_corners, float displacement,
                          uint32_t *keys, void *recs, int32_t *heads, void *workspace, void *stream);
+
+/* items[i] = id (b*N+n)*7 + j of the i-th (point, displacement) item in (sample, row-major base cell of ITS displaced
+ * sample in a D x H x W volume) order; items that touch no voxel come last.  For svr_level.item_order.
+ * workspace: svr_gather_pull_plan_workspace(B, N) bytes.                                                     */
+int svr_gather_item_order(const float *points, int32_t B, int32_t N, int32_t D, int32_t H, int32_t W,
+                          int32_t align_corners, float displacement, int32_t *items, void *workspace, void *stream);
 
 /* features[b*N+n][level.col + j*C + c] = trilinear sample j of channel c (zeros padding);
  * columns past the last level (up to row_stride) are written as zeros.                      */

@@ -22,7 +22,7 @@ class PullPlan(C.Structure):
 
 class Level(C.Structure):
     _fields_ = [("vol", P), ("gvol", P), ("C", I32), ("D", I32), ("H", I32), ("W", I32), ("col", I32), ("order", P),
-                ("plan", C.POINTER(PullPlan))]
+                ("item_order", P), ("plan", C.POINTER(PullPlan))]
 
 
 class GatherDesc(C.Structure):
@@ -42,6 +42,7 @@ SIGNATURES = {
     "svr_points_morton_order_workspace": (I64, [I32, I32]),
     "svr_points_morton_order": (C.c_int, [P, P, P, I32, I32, P, P]),
     "svr_points_voxel_order": (C.c_int, [P, P, I32, I32, I32, I32, I32, I32, P, P]),
+    "svr_gather_item_order": (C.c_int, [P, I32, I32, I32, I32, I32, I32, F32, P, P, P]),
     "svr_gather_pull_plan_workspace": (I64, [I32, I32]),
     "svr_gather_pull_plan_workspace_cells": (I64, [I32, I32, I32, I32]),
     "svr_gather_pull_plan": (C.c_int, [P, I32, I32, I32, I32, I32, I32, I32, I32, I32, F32, P, P, P, P, P]),

@@ -21,6 +21,7 @@ struct LevelArgs {
   float *gvol;
   int C, D, H, W, col;
   const int32_t *order;  // backward: visiting order of this level (or null = natural order)
+  const int32_t *items;  // backward: (7*B*N) item ids pn*7+j sorted by base cell (svr_gather_item_order), or null
 };
 
 struct Corner {
@@ -524,6 +525,158 @@ __device__ __forceinline__ void gather_bwd_runs_body(const LevelArgs L, const fl
   flush(cur0, acc0, 0);
 }
 
+// Same run-combining scatter, walking ITEMS (point, displacement j) in the order of svr_gather_item_order: all 7*N items
+// of a sample sorted jointly by base cell, so a coarse level's cell holds 7x longer runs than under a per-displacement
+// point order (level 5: ~680 consecutive items per cell), and a lane group walks REPS * PG consecutive items with its
+// two runs kept open across the repetitions: the atomics issued for the 128-channel levels drop from ~0.8 GB to ~0.15 GB
+// and the kernel is bound by reading the gradient rows (1.43 GB per 128-channel level).
+constexpr int kItemReps = 4;
+
+template <int C>
+__device__ __forceinline__ void gather_bwd_items_body(const LevelArgs L, const float *__restrict__ points,
+                                                      const float *__restrict__ gfeat, int64_t T, int N, int row_stride,
+                                                      float disp, int ac, int64_t witem, int64_t waves) {
+  constexpr int CW = C < 64 ? C : 64;  // channels per lane group
+  constexpr int G = 64 / CW;           // independent runs per wave
+  constexpr int CG = C / CW;           // channel groups per sample
+  constexpr int PG = 2 * CW;           // items per repetition and run group
+  if (witem >= waves) return;
+  const int lane = threadIdx.x & 63;
+  const int ch = lane % CW, grp = lane / CW;
+  const int cg = (int)(witem % CG);
+  const int64_t nchunks = waves / CG;
+  const int64_t cperm = ((witem / CG) * 1000003LL) % nchunks;  // spread concurrently running waves over distant cells
+  const int64_t base_i = (cperm * G + grp) * (int64_t)(PG * kItemReps);
+  const int64_t vol = (int64_t)L.D * L.H * L.W;
+  float *gl = L.gvol + cg * CW + ch;
+
+  float acc0[8], acc1[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) acc0[k] = acc1[k] = 0.f;
+  int cur0 = -1, cur1 = -1, b0 = 0, b1 = 0;  // open runs: base-voxel key and sample
+  auto flush = [&](int cur, int bb, const float (&acc)[8], int skip) {
+    if (cur >= 0) {
+      const int x0 = (cur & 1023) - 1, y0 = ((cur >> 10) & 1023) - 1, z0 = (cur >> 20) - 1;
+      float *gb = gl + (size_t)bb * vol * C;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int z = z0 + (k >> 2), y = y0 + ((k >> 1) & 1), x = x0 + (k & 1);
+        if (!((skip >> k) & 1) && z >= 0 && z < L.D && y >= 0 && y < L.H && x >= 0 && x < L.W)
+          atomicAdd(gb + (((size_t)z * L.H + y) * L.W + x) * C, acc[k]);
+      }
+    }
+  };
+  auto retire = [&]() {  // retires slot 1; hands the shared face over to slot 0 when the two are face neighbours
+    int skip = 0;
+    if (cur1 >= 0 && cur0 >= 0 && b0 == b1) {
+      const int d = cur0 - cur1;
+      if (d == 1) { acc0[0] += acc1[1]; acc0[2] += acc1[3]; acc0[4] += acc1[5]; acc0[6] += acc1[7]; skip = 0xAA; }
+      else if (d == -1) { acc0[1] += acc1[0]; acc0[3] += acc1[2]; acc0[5] += acc1[4]; acc0[7] += acc1[6]; skip = 0x55; }
+      else if (d == 1024) { acc0[0] += acc1[2]; acc0[1] += acc1[3]; acc0[4] += acc1[6]; acc0[5] += acc1[7]; skip = 0xCC; }
+      else if (d == -1024) { acc0[2] += acc1[0]; acc0[3] += acc1[1]; acc0[6] += acc1[4]; acc0[7] += acc1[5]; skip = 0x33; }
+      else if (d == (1 << 20)) { acc0[0] += acc1[4]; acc0[1] += acc1[5]; acc0[2] += acc1[6]; acc0[3] += acc1[7]; skip = 0xF0; }
+      else if (d == -(1 << 20)) { acc0[4] += acc1[0]; acc0[5] += acc1[1]; acc0[6] += acc1[2]; acc0[7] += acc1[3]; skip = 0x0F; }
+    }
+    flush(cur1, b1, acc1, skip);
+  };
+  constexpr int UNR = 4;
+  for (int rep = 0; rep < kItemReps; ++rep) {
+    const int64_t i0 = base_i + (int64_t)rep * PG;
+    const int cnt = (int)min((int64_t)PG, T - i0);  // items of this repetition (<= 0: none)
+    if (cnt <= 0) break;                            // uniform within the group
+    // ---- stage 1: two items per lane
+    int key[2], bb[2], goff[2];
+    float fx[2], fy[2], fz[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      key[s] = -1;
+      bb[s] = 0;
+      goff[s] = 0;
+      fx[s] = fy[s] = fz[s] = 0.f;
+      if (s * CW + ch < cnt) {
+        const int id = L.items[i0 + s * CW + ch];
+        const int pn = id / 7, j = id - pn * 7;
+        const float p3[3] = {points[(int64_t)pn * 3], points[(int64_t)pn * 3 + 1], points[(int64_t)pn * 3 + 2]};
+        Corner c = sample_corner(p3, j, disp, L.D, L.H, L.W, ac);
+        const int x0 = clamp_int(c.x0f), y0 = clamp_int(c.y0f), z0 = clamp_int(c.z0f);
+        goff[s] = pn * row_stride + L.col + j * C;
+        bb[s] = pn / N;
+        if (z0 >= -1 && z0 < L.D && y0 >= -1 && y0 < L.H && x0 >= -1 && x0 < L.W) {
+          key[s] = (x0 + 1) | ((y0 + 1) << 10) | ((z0 + 1) << 20);
+          fx[s] = c.ix - c.x0f;
+          fy[s] = c.iy - c.y0f;
+          fz[s] = c.iz - c.z0f;
+        }
+      }
+    }
+    // ---- stage 2: walk them with the two open runs.  The gradient loads run one block of UNR items AHEAD of the
+    // arithmetic (two register sets): with the loads of a block issued and waited for in the same block every 4 items
+    // paid a full memory latency and the 128-channel levels ran at 0.5 ms each instead of the 0.29 ms of their reads.
+    constexpr int NB = 2 * CW / UNR;
+    auto issue = [&](float (&gq)[UNR], int blk) {
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const int t = blk * UNR + u, s = t >= CW ? 1 : 0;
+        const int go = __shfl(s ? goff[1] : goff[0], grp * CW + t - s * CW);
+        gq[u] = gfeat[(t < cnt ? go : 0) + cg * CW + ch];  // unconditional load, no branch
+      }
+    };
+    auto process = [&](const float (&gq)[UNR], int blk) {
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const int t = blk * UNR + u, s = t >= CW ? 1 : 0, src = grp * CW + t - s * CW;
+        const int kraw = __shfl(s ? key[1] : key[0], src);
+        const int bqu = __shfl(s ? bb[1] : bb[0], src);
+        const float xq = __shfl(s ? fx[1] : fx[0], src), yq = __shfl(s ? fy[1] : fy[0], src),
+                    zq = __shfl(s ? fz[1] : fz[0], src);
+        const int kk = t < cnt ? kraw : -1;
+        if (kk < 0) continue;  // item touches no voxel (or padding slot)
+        if (kk != cur0 || bqu != b0) {
+          if (kk == cur1 && bqu == b1) {  // hit on the older run: make it the most recent
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { const float tt = acc0[k]; acc0[k] = acc1[k]; acc1[k] = tt; }
+            cur1 = cur0;
+            b1 = b0;
+          } else {                        // miss: retire the older run, age the recent one, open a new one
+            retire();
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { acc1[k] = acc0[k]; acc0[k] = 0.f; }
+            cur1 = cur0;
+            b1 = b0;
+          }
+          cur0 = kk;
+          b0 = bqu;
+        }
+        const float wx1 = xq, wx0 = 1.f - wx1, wy1 = yq, wy0 = 1.f - wy1, wz1 = zq, wz0 = 1.f - wz1;
+        const float g = gq[u];
+        const float a00 = wy0 * wz0 * g, a10 = wy1 * wz0 * g, a01 = wy0 * wz1 * g, a11 = wy1 * wz1 * g;
+        acc0[0] += wx0 * a00; acc0[1] += wx1 * a00;
+        acc0[2] += wx0 * a10; acc0[3] += wx1 * a10;
+        acc0[4] += wx0 * a01; acc0[5] += wx1 * a01;
+        acc0[6] += wx0 * a11; acc0[7] += wx1 * a11;
+      }
+    };
+    float gA[UNR], gB[UNR];
+    issue(gA, 0);
+    for (int blk = 0; blk < NB; blk += 2) {  // all conditions are uniform within the lane group
+      if ((blk + 1) * UNR < cnt) issue(gB, blk + 1);
+      process(gA, blk);
+      if ((blk + 1) * UNR >= cnt) break;
+      if ((blk + 2) * UNR < cnt) issue(gA, blk + 2);
+      process(gB, blk + 1);
+      if ((blk + 2) * UNR >= cnt) break;
+    }
+  }
+  retire();
+  flush(cur0, b0, acc0, 0);
+}
+
+__host__ __device__ inline int64_t bwd_items_waves(int C, int64_t T) {
+  const int cw = C < 64 ? C : 64;
+  const int64_t per = (int64_t)(64 / cw) * 2 * cw * kItemReps;  // items per wave
+  return svr::cdiv(T, per) * (C / cw);
+}
+
 __host__ __device__ inline int64_t bwd_runs_waves(int C, int B, int N) {
   int cw = C < 64 ? C : 64;
   int64_t per = (int64_t)(64 / cw) * 2 * cw;  // points per wave
@@ -539,6 +692,16 @@ __global__ __launch_bounds__(256) void gather_bwd_fused_kernel(FusedArgs A, cons
   while (l + 1 < A.n && blockIdx.x >= A.block_start[l + 1]) ++l;
   const LevelArgs L = A.L[l];  // by value: read from the kernel arguments once, then lives in SGPRs
   const int64_t item = ((int64_t)(blockIdx.x - A.block_start[l]) * 256 + threadIdx.x) >> 6;
+  if (L.items) {  // joint item order of this level
+    const int64_t T = (int64_t)7 * B * N, iw = bwd_items_waves(L.C, T);
+    switch (L.C) {
+      case 16: gather_bwd_items_body<16>(L, points, gfeat, T, N, row_stride, disp, ac, item, iw); break;
+      case 32: gather_bwd_items_body<32>(L, points, gfeat, T, N, row_stride, disp, ac, item, iw); break;
+      case 64: gather_bwd_items_body<64>(L, points, gfeat, T, N, row_stride, disp, ac, item, iw); break;
+      case 128: gather_bwd_items_body<128>(L, points, gfeat, T, N, row_stride, disp, ac, item, iw); break;
+    }
+    return;
+  }
   const int64_t waves = bwd_runs_waves(L.C, B, N);
   const int32_t *order = L.order ? L.order : default_order;
   switch (L.C) {
@@ -763,7 +926,7 @@ int check_desc(const svr_gather_desc *d, bool bwd) {
   return SVR_OK;
 }
 
-LevelArgs level_args(const svr_level &L) { return LevelArgs{L.vol, L.gvol, L.C, L.D, L.H, L.W, L.col, L.order}; }
+LevelArgs level_args(const svr_level &L) { return LevelArgs{L.vol, L.gvol, L.C, L.D, L.H, L.W, L.col, L.order, L.item_order}; }
 
 }  // namespace
 
@@ -881,7 +1044,13 @@ extern "C" int svr_gather_trilinear_bwd(const svr_gather_desc *d, const float *p
     FA.L[FA.n] = L;
     FA.block_start[FA.n] = fblocks;
     SVR_CHECK(L.D < 1022 && L.H < 1022 && L.W < 1022, SVR_E_UNSUPPORTED, "gather_bwd: level %d: dims above 1021", l);
-    fblocks += (unsigned)svr::cdiv(bwd_runs_waves(L.C, d->B, d->N) * 64, 256);
+    if (L.items) {
+      SVR_CHECK(7 * BN < (1LL << 31) && BN * (int64_t)d->row_stride < (1LL << 31), SVR_E_UNSUPPORTED,
+                "gather_bwd: level %d: item order needs 32-bit item / gradient offsets", l);
+      fblocks += (unsigned)svr::cdiv(bwd_items_waves(L.C, 7 * BN) * 64, 256);
+    } else {
+      fblocks += (unsigned)svr::cdiv(bwd_runs_waves(L.C, d->B, d->N) * 64, 256);
+    }
     ++FA.n;
   }
   if (FA.n > 0) {
@@ -957,4 +1126,31 @@ extern "C" int svr_gather_pull_plan(const float *points, int32_t B, int32_t N, i
   e = svr::scan_max_i32(scan_tmp, scan_bytes, ends, heads, cells + 1, s);
   SVR_CHECK(e == hipSuccess, (int)e, "pull_plan: scan failed: %s", hipGetErrorString(e));
   return svr::launch_status("pull_plan");
+}
+
+extern "C" int svr_gather_item_order(const float *points, int32_t B, int32_t N, int32_t D, int32_t H, int32_t W,
+                                     int32_t align_corners, float displacement, int32_t *items, void *workspace,
+                                     void *stream) {
+  const int64_t T = (int64_t)7 * B * N;
+  SVR_CHECK(B >= 0 && N >= 0 && D > 0 && H > 0 && W > 0, SVR_E_BADSHAPE, "item_order: B=%d N=%d dims %dx%dx%d", B, N, D, H, W);
+  if (T == 0) return SVR_OK;
+  SVR_CHECK(points && items && workspace, SVR_E_BADARG, "item_order: null pointer");
+  const int64_t cells = pull_cells(B, D, H, W);
+  SVR_CHECK(cells < (1LL << 31) - 1 && T < (1LL << 31), SVR_E_UNSUPPORTED, "item_order: %ld cells / %ld items exceed 32 bits",
+            (long)cells, (long)T);
+  hipStream_t s = (hipStream_t)stream;
+  char *w = (char *)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+  uint32_t *keys_in = (uint32_t *)w;
+  w += al256(T * 4);
+  int32_t *vals_in = (int32_t *)w;
+  w += al256(T * 4);
+  uint32_t *keys_out = (uint32_t *)w;
+  w += al256(T * 4);
+  const int bits = pull_key_bits(cells);
+  hipLaunchKernelGGL(pull_key_kernel, dim3((unsigned)svr::cdiv(T, 256)), dim3(256), 0, s, points, keys_in, vals_in, T, N, D, H,
+                     W, displacement, align_corners, (uint32_t)cells);
+  hipError_t e = svr::sort_pairs_u32((void *)w, svr::sort_pairs_u32_temp_bytes(T, bits), keys_in, keys_out, vals_in, items, T,
+                                     bits, s);
+  SVR_CHECK(e == hipSuccess, (int)e, "item_order: radix sort failed: %s", hipGetErrorString(e));
+  return svr::launch_status("item_order");
 }

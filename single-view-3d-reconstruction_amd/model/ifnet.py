@@ -83,6 +83,12 @@ def _level_orders_async(pts, D, H, W, n_levels, align, layout=None, disp=None):
                 plans[l] = ops.pull_plan(pts, dhw, C, layout.col[l], layout.row_stride, disp, align)
                 plans[l].record_stream(main)
                 launched = True
+            elif SCATTER_FORM == "pull" and 7 * B * N < 2 ** 31 and layout is not None and \
+                    B * N * layout.row_stride < 2 ** 31 and N > 0:
+                # wide levels: float atomics with run-combining over the JOINT item order (all 7N items of a sample by cell)
+                orders[l] = ops.item_order(pts, dhw, disp, align)
+                orders[l].record_stream(main)
+                launched = True
             elif N >= 0.15 * dhw[0] * dhw[1] * dhw[2] and N > 64:
                 orders[l] = ops.voxel_order(pts, dhw, align)
                 orders[l].record_stream(main)

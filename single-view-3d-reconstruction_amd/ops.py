@@ -120,6 +120,18 @@ def pull_plan(points, dims, C, col, row_stride, displacement, align_corners=Fals
     return PullPlan(keys, recs, heads, T)
 
 
+def item_order(points, dims, displacement, align_corners=False):
+    """(7*B*N,) int32 item ids pn*7+j sorted by (sample, base cell of the displaced sample) in a volume of `dims`."""
+    _f32(points)
+    B, N, _ = points.shape
+    l = _lib.lib()
+    items = torch.empty(max(7 * B * N, 1), device=points.device, dtype=torch.int32)
+    ws = torch.empty(l.svr_gather_pull_plan_workspace(B, N), device=points.device, dtype=torch.uint8)
+    check(l.svr_gather_item_order(_p(points), B, N, dims[0], dims[1], dims[2], int(align_corners), displacement, _p(items),
+                                  _p(ws), _stream()), "gather_item_order")
+    return items
+
+
 def make_gather_desc(vols, gvols, layout, B, N, displacement, align_corners, order=None, level_orders=None, flags=0,
                      level_plans=None):
     d = GatherDesc()
@@ -140,7 +152,12 @@ def make_gather_desc(vols, gvols, layout, B, N, displacement, align_corners, ord
         L.vol, L.gvol = _p(v), _p(g)
         L.C, L.D, L.H, L.W = ref.shape[4], ref.shape[1], ref.shape[2], ref.shape[3]
         L.col = layout.col[l]
-        L.order = _p(level_orders[l]) if level_orders is not None else C.c_void_p(0)
+        o = level_orders[l] if level_orders is not None else None
+        # a (7*B*N) order is an ITEM order (svr_gather_item_order), a (B*N) one a point order (svr_points_voxel_order)
+        if o is not None and B * N > 0 and o.numel() == 7 * B * N:
+            L.item_order, L.order = _p(o), C.c_void_p(0)
+        else:
+            L.item_order, L.order = C.c_void_p(0), _p(o)
         if level_plans is not None and level_plans[l] is not None:
             L.plan = C.pointer(level_plans[l].c)
     return d

@@ -91,7 +91,7 @@ def test_config3_gather_bit_exact_on_real_pyramid_and_scatter():
             ifn.SCATTER_FORM = saved_form
         if form == "pull":
             assert [p is not None for p in plans] == [False, True, True, True, False, False]
-            assert orders[4] is not None and orders[5] is not None
+            assert orders[4].numel() == 7 * B * N and orders[5].numel() == 7 * B * N      # joint item orders
         else:
             assert all(p is None for p in plans) and sum(o is not None for o in orders) >= 3
         torch.cuda.current_stream().wait_event(ready)

@@ -202,6 +202,26 @@ def test_voxel_order_is_a_permutation_and_scatter_under_it(dims, align, N):
     for l, v in enumerate(vols):
         assert G.rel_err(_ncdhw(g_ord[l]).numpy(), v.grad.numpy()) < 1e-5, f"level {l} (ordered) vs autograd"
         assert G.rel_err(g_ord[l].cpu().numpy(), g_nat[l].cpu().numpy()) < 1e-5, f"level {l} ordered vs natural"
+    # the joint ITEM order (svr_gather_item_order: all 7N items of a sample sorted by the base cell of their displaced
+    # sample; the atomic scatter walks items with its runs kept open over kItemReps repetitions)
+    iorders = [None]
+    for l in range(1, 6):
+        it = ops.item_order(pts.cuda(), lv_dims[l], disp, align)
+        ic = it.cpu().long()
+        assert sorted(ic.tolist()) == list(range(7 * B * N)), f"level {l}: item order is not a permutation"
+        idx, _ = O.corner_indices(pts, lv_dims[l], net_res)          # (B, 7, N, 3)
+        pn, j = ic // 7, ic % 7
+        base = idx[pn // N, j, pn % N].long()
+        Dd, H, W = lv_dims[l]
+        inside = ((base >= -1).all(1)) & (base[:, 0] < Dd) & (base[:, 1] < H) & (base[:, 2] < W)
+        key = (((pn // N) * (Dd + 1) + base[:, 0] + 1) * (H + 1) + base[:, 1] + 1) * (W + 1) + base[:, 2] + 1
+        n_in = int(inside.sum())
+        assert bool(inside[:n_in].all()) and bool((key[1:n_in] >= key[:n_in - 1]).all()), f"level {l}: items not sorted"
+        iorders.append(it)
+    g_it = [torch.zeros_like(v) for v in vols_g]
+    ops.gather_bwd(vols_g, g_it, pts.cuda(), gfeat, layout, disp, align, level_orders=iorders)
+    for l, v in enumerate(vols):
+        assert G.rel_err(_ncdhw(g_it[l]).numpy(), v.grad.numpy()) < 1e-5, f"level {l} (item order) vs autograd"
 
 
 @pytest.mark.parametrize("dims,align,N,B", [((16, 16, 16), False, 6000, 2), ((9, 7, 11), False, 3000, 3), ((8, 8, 8), True, 2500, 1),

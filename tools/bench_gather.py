@@ -68,7 +68,15 @@ for l in (1, 2, 3):
     print(f"  level {l} (C={chans[l]}, S={dims[0]}): plan {t:.3f} ms, pull scatter {tk:.3f} ms")
 lo = [None] * 6
 for l in (4, 5):
-    lo[l] = ops.voxel_order(p, tuple(vols[l].shape[1:4]))
+    dims = tuple(vols[l].shape[1:4])
+    t = timeit(lambda: ops.item_order(p, dims, disp, False))
+    lo[l] = ops.item_order(p, dims, disp, False)
+    l1 = [None] * 6
+    l1[l] = lo[l]
+    gv1 = [None] * 6
+    gv1[l] = torch.zeros_like(vols[l])
+    tk = timeit(lambda: ops.gather_bwd(vols, gv1, p, gfeat, layout, disp, False, level_orders=l1))
+    print(f"  level {l} (C={chans[l]}, S={dims[0]}): item order {t:.3f} ms, atomic scatter over items {tk:.3f} ms")
 gv = [None] + [torch.empty_like(v) if plans[l] is not None else torch.zeros_like(v) for l, v in enumerate(vols) if l >= 1]
-print("  levels 1-3 pull + 4-5 atomic (orders): %.3f ms" % timeit(
+print("  levels 1-3 pull + 4-5 atomic (item orders): %.3f ms" % timeit(
     lambda: ops.gather_bwd(vols, gv, p, gfeat, layout, disp, False, level_orders=lo, level_plans=plans)))
