@@ -84,6 +84,7 @@ struct FusedArgs {
   int n;
   int pad_start;  // forward: columns [pad_start, row_stride) of every row are zero-filled by the last level
   int shared;     // forward: levels with C >= 16 use gather_fwd_shared_body (sizes fit 32-bit element offsets)
+  int xcd;        // forward: XCD-aware block order inside every level (block ranges are multiples of 8)
 };
 
 template <int C, bool JMAJOR = false>
@@ -259,8 +260,14 @@ __global__ __launch_bounds__(256) void gather_fwd_fused_kernel(FusedArgs A, cons
   int l = 0;
   while (l + 1 < A.n && blockIdx.x >= A.block_start[l + 1]) ++l;
   const LevelArgs L = A.L[l];  // by value: read from the kernel arguments once, then lives in SGPRs
+  // XCD-aware order inside a level: workgroups are dealt round-robin over the 8 XCDs (each with its own L2), so
+  // consecutive workgroups -- consecutive Morton-sorted points, i.e. the same corner voxels -- would pull the same lines
+  // into all 8 L2s.  Every level's block range starts at a multiple of 8 and is padded to one (host), and block i of the
+  // level works on logical block (i % 8) * (n / 8) + i / 8: one XCD walks one contiguous eighth of the level's items.
+  const unsigned nlev = A.block_start[l + 1] - A.block_start[l], li = blockIdx.x - A.block_start[l];
+  const unsigned lblock = A.xcd ? (li % svr::kXcds) * (nlev / svr::kXcds) + li / svr::kXcds : li;
   if (A.shared && L.C >= 16) {  // one wave = 64 items
-    const int64_t wave_id = (int64_t)(blockIdx.x - A.block_start[l]) * 4 + (threadIdx.x >> 6);
+    const int64_t wave_id = (int64_t)lblock * 4 + (threadIdx.x >> 6);
     const int pad = (l == A.n - 1) ? A.pad_start : -1;
     switch (L.C) {
       case 16: gather_fwd_shared_body<16, false>(L, points, feat, order, wave_id, BN, N, row_stride, disp, ac, pad); break;
@@ -270,7 +277,7 @@ __global__ __launch_bounds__(256) void gather_fwd_fused_kernel(FusedArgs A, cons
     }
     return;
   }
-  const int64_t gid = (int64_t)(blockIdx.x - A.block_start[l]) * 256 + threadIdx.x;
+  const int64_t gid = (int64_t)lblock * 256 + threadIdx.x;
   const int V = L.C >= 4 ? L.C / 4 : 1;
   const int64_t total = BN * 7 * V;
   if (l == A.n - 1 && gid < total && gid % (7 * V) == 0) {  // padding columns: written once per row
@@ -964,10 +971,14 @@ extern "C" int svr_gather_trilinear_fwd(const svr_gather_desc *d, const float *p
       int V = L.C >= 4 ? L.C / 4 : 1;
       A.L[A.n] = L;
       A.block_start[A.n] = blocks;
-      blocks += (unsigned)((shared && L.C >= 16) ? svr::cdiv(BN * 7, 256) : svr::cdiv(BN * 7 * V, 256));
+      blocks += svr::xcd_grid((shared && L.C >= 16) ? svr::cdiv(BN * 7, 256) : svr::cdiv(BN * 7 * V, 256));  // multiple of 8
       ++A.n;
     }
   A.block_start[A.n] = blocks;
+  // Off by default: measured at config 3 it helps UNSORTED points (3.04 -> 2.57 ms) but costs Morton-sorted ones, the
+  // production order (2.00 -> 2.20 ms: with round-robin placement the lines a neighbour XCD just fetched are Infinity
+  // Cache hits, and eight XCDs streaming eight different samples open more DRAM pages).  SVR_GATHER_XCD=1 enables it.
+  A.xcd = getenv("SVR_GATHER_XCD") ? 1 : 0;
   A.pad_start = 0;
   for (int l = 0; l < d->n_levels; ++l) {
     int end = d->level[l].col + 7 * d->level[l].C;

@@ -33,6 +33,10 @@ def timeit(fn, n=5):
 
 feat = torch.empty(B * N, layout.row_stride, device=dev)
 gfeat = torch.randn(B * N, layout.row_stride, device=dev)
+if "--fwd-only" in sys.argv:
+    for name, p in (("random", pts), ("sorted", pts_sorted)):
+        print(name, "fwd all levels: %.3f ms" % timeit(lambda: ops.gather_fwd(vols, p, layout, disp, False, out=feat), n=10))
+    sys.exit(0)
 for name, p in (() if "--pull-only" in sys.argv else (("random", pts), ("sorted", pts_sorted))):
     print(name, "fwd all levels: %.3f ms" % timeit(lambda: ops.gather_fwd(vols, p, layout, disp, False, out=feat)))
     for l in range(1, 6):
