@@ -32,6 +32,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 GATHER_BYTES_PER_POINT_F32 = 93000          # 7*8*369 reads + 7*369 writes + 12 B coords
+GATHER_BYTES_PER_POINT_BF16 = 46506         # the same elements at 2 B + 12 B coords
 GATHER_BWD_BYTES_PER_POINT_F32 = 92776      # 2583 gradient reads + 12 B + 7*8*368 RMW (counted once)
 HBM_PEAK_GBPS = 8000.0                       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured achievable)
 HBM_ACHIEVABLE_GBPS = 6290.0
@@ -163,6 +164,7 @@ def main():
     ap.add_argument("--points", type=int, default=50000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fwd-only", action="store_true")
+    ap.add_argument("--no-query", action="store_true", help="skip the query-path (f32 / bf16 storage) measurement")
     ap.add_argument("--dist", choices=["uniform", "surface"], default="uniform",
                     help="query-point distribution; uniform (default) is the reported worst case")
     a = ap.parse_args()
@@ -240,6 +242,33 @@ def main():
             sync()
             fwd_ms = (time.perf_counter() - t1) / a.steps * 1e3
 
+    # query path alone (cached pyramid -> gather + point MLP forward, no grad; the dense-grid-inference kernels):
+    # default f32 storage against the bf16-storage throughput mode (north_star "bf16 occupancy logits")
+    query = None
+    if not a.no_query and rank == 0:
+        query = {}
+        net = trainer.ifnet
+        pts = batch["points"]
+        with torch.no_grad():
+            for name, storage, gname in (("f32", "f32", "gather_fwd"), ("bf16", "bf16", "gather_fwd_bf16")):
+                levels = net.encode(batch["input"], storage)
+                z = net.query(levels, pts)
+                kq = _KernelTimer(torch)
+                orig = kq.wrap(ops, gname)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(a.steps):
+                    z = net.query(levels, pts)
+                torch.cuda.synchronize()
+                ms = (time.perf_counter() - t1) / a.steps * 1e3
+                setattr(ops, gname, orig)
+                query[name] = {"ms": ms, "gather_ms": kq.ms_per_launch(gname), "logits": z.float()}
+                del levels
+        zf, zb = query["f32"].pop("logits"), query["bf16"].pop("logits")
+        query["bf16"]["logits_rel_dev_vs_f32_storage"] = float((zb - zf).abs().max() / zf.abs().max())
+    if launched:
+        dist.barrier()
+
     if rank == 0:
         npts = a.batch * a.points
         pts_per_step = world * npts
@@ -298,6 +327,18 @@ def main():
         if fwd_ms is not None:
             res["fwd_only"] = {"value": npts / (fwd_ms * 1e-3), "unit": "query-points/s", "ms_per_step": fwd_ms,
                                "note": "rank 0, forward + loss under no_grad, training-mode BatchNorm"}
+        if query is not None:
+            for name, bpp in (("f32", GATHER_BYTES_PER_POINT_F32), ("bf16", GATHER_BYTES_PER_POINT_BF16)):
+                q = query[name]
+                q["value"] = npts / (q["ms"] * 1e-3)
+                q["unit"] = "query-points/s"
+                q["gather_algorithmic_GBps"] = npts * bpp / (q["gather_ms"] * 1e-3) / 1e9
+                q["gather_algorithmic_frac_of_l2_peak_34500"] = q["gather_algorithmic_GBps"] / L2_PEAK_GBPS
+            res["query_path"] = {"workload": f"cached {a.grid}^3 pyramid (batch {a.batch}), {npts} query points per pass: 6-level "
+                                             "trilinear gather + point MLP forward, no grad (dense-grid inference kernels)",
+                                 "dtype_f32": query["f32"], "dtype_bf16": query["bf16"],
+                                 "note": "bf16 = separately named bf16-STORAGE mode (bf16 volumes / feature rows / activations, "
+                                         "f32 accumulation; never the default, not held to the fp32 1e-4 gate)"}
         kernels = []
         bwd_ms = kt.ms_per_launch("gather_bwd")
         if bwd_ms > 0:

@@ -140,6 +140,27 @@ int svr_gather_corner_indices(const svr_gather_desc *d, int32_t level, const flo
                               int32_t *out, void *stream);
 
 /* ---------------------------------------------------------------------------------------
+ * bf16-STORAGE throughput mode of the query path (north_star "bf16 occupancy logits", BASELINE configs[1];
+ * reference hooks: the dtype-generic grid_sample / Conv1d calls model/ifnet.py:161-193,55-59 under
+ * util/arguments.py:30 --precision 16).  Volumes, feature rows and MLP activations are bf16 in memory; corner
+ * weights, sums, MFMA accumulators, bias and ReLU are f32; every stored value is rounded once (nearest even).
+ * The sample geometry is the f32 code of the default path: corner indices stay bit-exact.  A separate mode --
+ * never the default, never held to the fp32 1e-4 gate (bf16_path.hip).
+ * ------------------------------------------------------------------------------------- */
+int svr_cast_f32_to_bf16(const float *in, uint16_t *out, int64_t n, void *stream);
+/* As svr_gather_trilinear_fwd, with svr_level.vol pointing to bf16 volumes (B,D,H,W,C) and bf16 feature rows
+ * (row_stride in ELEMENTS, multiple of 8).  One of the levels must have C == 1 (its kernel writes the padding
+ * columns) unless the levels fill the row.                                                               */
+int svr_gather_trilinear_fwd_bf16(const svr_gather_desc *d, const float *points, uint16_t *features, void *stream);
+/* Y[M,N] (bf16) = epi( X[M,K] (bf16, ldx) W[N,K]^T (bf16, ldw) ), f32 accumulation on v_mfma_f32_32x32x16_bf16;
+ * epilogue NONE / BIAS / BIAS_RELU with an f32 bias; 32 | K, rows 16-byte aligned.                         */
+int svr_linear_fwd_bf16(const uint16_t *X, int64_t ldx, const uint16_t *W, int64_t ldw, const float *bias, uint16_t *Y,
+                        int64_t ldy, int64_t M, int64_t N, int64_t K, int epilogue, void *stream);
+/* logits[m] (f32) = H[m,:] (bf16) . w (f32) + b                                                           */
+int svr_fc_out_fwd_bf16(const uint16_t *H, int64_t ldh, const float *w, const float *b, float *logits, int64_t M,
+                        int64_t K, void *stream);
+
+/* ---------------------------------------------------------------------------------------
  * Dense f32 GEMMs on MFMA (replaces nn.Conv1d(.,.,1) fc_0/fc_1/fc_2 model/ifnet.py:19-21,55-57
  * and their autograd).  Row-major everywhere.
  * ------------------------------------------------------------------------------------- */

@@ -94,6 +94,32 @@ def ifnet_case(IFNet, net_res, tag, seed, B, dims, N, spread=1.0):
           f"absmax={logits.abs().max().item():.4f} size={os.path.getsize(path)/1024:.0f} KiB")
 
 
+def ifnet_bf16_case(IFNet, tag, seed, B, dims, N, spread=1.0):
+    """The reference run end to end in bfloat16 on the CPU (module.bfloat16(), bf16 inputs: every conv, BatchNorm,
+    grid_sample and Conv1d in bf16 -- the precision util/arguments.py:30 --precision 16 asks Lightning for), next to
+    the same module in float32: the two reference answers the bf16-storage throughput mode is reported against."""
+    torch.manual_seed(0)
+    x, pts, _ = make_inputs(seed, B, dims, N, spread)
+    st = O.name_seeded_state(128, GAIN)
+    out = {"meta": np.array([128, seed, B, dims[0], dims[1], dims[2], N], dtype=np.int64), "spread": np.float32(spread),
+           "gain": np.float32(GAIN), "x_bits": np.packbits(x.numpy().astype(np.uint8)), "points": pts.numpy()}
+    for mode in ("train", "eval"):
+        for dt, name in ((torch.float32, "f32"), (torch.bfloat16, "bf16")):
+            ref = IFNet()
+            ref.load_state_dict(st, strict=False)
+            ref = ref.to(dt)
+            ref.train(mode == "train")
+            with torch.no_grad():
+                z = ref(x.to(dt), pts.to(dt))
+            out[f"logits_{name}_{mode}"] = z.float().numpy()
+    for mode in ("train", "eval"):
+        a, b = out[f"logits_bf16_{mode}"], out[f"logits_f32_{mode}"]
+        print(f"  {mode}: reference bf16 vs reference f32: max|d| / max|f32| = {np.abs(a - b).max() / np.abs(b).max():.3e}")
+    path = os.path.join(OUT, f"ifnet_{tag}.npz")
+    np.savez_compressed(path, **out)
+    print(f"{path}: size={os.path.getsize(path)/1024:.0f} KiB")
+
+
 def project_case(project, tag, seed, B, dims, kernel, sigma, scale):
     g = torch.Generator(device="cpu").manual_seed(seed)
     depth = torch.rand(B, 240, 320, generator=g) * 5 + 0.5
@@ -185,6 +211,7 @@ def scene_case(Unet, project, IFNet, tag, seed, B, scale, N):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--net_res", type=int, default=128)
+    ap.add_argument("--only-bf16", action="store_true", help="only (re)generate tests/golden/ifnet_bf16*.npz")
     a = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
     os.chdir(REF)                       # project() reads data/raw/overfit/00000/intrinsic.txt relative to cwd
@@ -198,6 +225,10 @@ def main():
     from model.ifnet import IFNet
     from model.projection import project
     torch.set_num_threads(8)
+    if a.only_bf16:
+        ifnet_bf16_case(IFNet, "bf16_cfg1", 101, 1, (32, 32, 32), 2048)            # BASELINE configs[0] inputs
+        ifnet_bf16_case(IFNet, "bf16_b2", 141, 2, (32, 24, 40), 1500, spread=1.2)
+        return
     if a.net_res == 128:
         ifnet_case(IFNet, 128, "cfg1", 101, 1, (32, 32, 32), 2048)                 # BASELINE configs[0]
         ifnet_case(IFNet, 128, "odd", 111, 2, (35, 26, 28), 600, spread=1.25)      # ragged dims, OOB points

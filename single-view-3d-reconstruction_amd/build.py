@@ -25,6 +25,7 @@ SOURCES = {
     "conv3d_bwdw_bf16.hip": [],
     "bn_pool.hip": [],
     "projection.hip": ["-ffp-contract=off"],
+    "bf16_path.hip": ["-ffp-contract=off"],
 }
 COMMON = ["-O3", "-fPIC", "--offload-arch=gfx950", "-munsafe-fp-atomics", "-std=c++17", "-I" + INCLUDE, "-I" + CSRC]
 

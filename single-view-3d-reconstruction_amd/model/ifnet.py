@@ -381,13 +381,32 @@ class IFNet(nn.Module):
         return wz[:, torch.where(perm >= 0, perm, torch.full_like(perm, w.shape[1]))].contiguous()
 
     @torch.no_grad()
-    def encode(self, x):
-        """Cache the feature pyramid of a grid for repeated queries (dense-grid inference)."""
-        return self.ifnet_feature_extractor.encode_levels(x)
+    def encode(self, x, storage="f32"):
+        """Cache the feature pyramid of a grid for repeated queries (dense-grid inference).  storage="bf16": the
+        throughput mode -- the pyramid (computed in f32) is stored in bf16 and query() runs the bf16-storage gather +
+        point MLP (f32 accumulation; bf16_path.hip).  Never the default: bf16 logits are not held to the fp32 gate."""
+        levels = self.ifnet_feature_extractor.encode_levels(x)
+        if storage == "bf16":
+            return [ops.cast_bf16(v) for v in levels]
+        if storage != "f32":
+            raise ValueError(f"storage={storage!r}")
+        return levels
+
+    @torch.no_grad()
+    def _query_bf16(self, levels, points):
+        B, N = points.shape[0], points.shape[1]
+        ext = self.ifnet_feature_extractor
+        rows = ops.gather_fwd_bf16(levels, points.float().contiguous(), ext._layout, ext._disp, ext._align)
+        h = ops.linear_fwd_bf16(rows, ops.cast_bf16(self._fc0_internal()), self.fc_0.bias, relu=True)
+        h = ops.linear_fwd_bf16(h, ops.cast_bf16(self.fc_1.weight.squeeze(2).contiguous()), self.fc_1.bias, relu=True)
+        h = ops.linear_fwd_bf16(h, ops.cast_bf16(self.fc_2.weight.squeeze(2).contiguous()), self.fc_2.bias, relu=True)
+        return ops.fc_out_fwd_bf16(h, self.fc_out.weight.reshape(-1).contiguous(), self.fc_out.bias).view(B, N)
 
     @torch.no_grad()
     def query(self, levels, points):
-        """Logits (B,N) for `points` against a pyramid from encode()."""
+        """Logits (B,N) for `points` against a pyramid from encode() (f32, or bf16 storage)."""
+        if levels[0].dtype == torch.bfloat16:
+            return self._query_bf16(levels, points)
         B, N = points.shape[0], points.shape[1]
         rows = self.ifnet_feature_extractor.feature_rows_from_levels(levels, points)
         h = ops.linear_fwd(rows, self._fc0_internal(), self.fc_0.bias, relu=True)
@@ -430,7 +449,7 @@ def make_3d_grid(bb_min, bb_max, shape, res_increase=1):
     return torch.stack([pxs, pys, pzs], dim=1)
 
 
-def evaluate_network_on_grid(network, x, resolution, res_increase=1, points_batch_size=2048 * 16):
+def evaluate_network_on_grid(network, x, resolution, res_increase=1, points_batch_size=2048 * 16, storage="f32"):
     """Occupancy probabilities on the dense lattice (model/ifnet.py:215-229).
 
     Same result as the reference loop, but the encoder pyramid is computed once (network.encode) instead of
@@ -440,7 +459,7 @@ def evaluate_network_on_grid(network, x, resolution, res_increase=1, points_batc
     pointsf = make_3d_grid((-0.5,) * 3, (0.5,) * 3, resolution, res_increase).to(x.device)
     values = []
     with torch.no_grad():
-        levels = network.encode(x) if hasattr(network, "encode") else None
+        levels = (network.encode(x, storage) if storage != "f32" else network.encode(x)) if hasattr(network, "encode") else None
         for pi in torch.split(pointsf, points_batch_size):
             pi = pi.unsqueeze(0)
             z = network.query(levels, pi) if levels is not None else network(x, pi)

@@ -200,6 +200,65 @@ def corner_indices(vols, points, layout, level, displacement, align_corners):
 
 
 # ------------------------------------------------------------------------------------------
+# bf16-storage throughput mode of the query path (bf16_path.hip): separate entry points, never the default
+# ------------------------------------------------------------------------------------------
+def cast_bf16(t):
+    """f32 -> bf16 (round to nearest even), same shape."""
+    _f32(t)
+    out = torch.empty(t.shape, device=t.device, dtype=torch.bfloat16)
+    check(_lib.lib().svr_cast_f32_to_bf16(_p(t), _p(out), t.numel(), _stream()), "cast_bf16")
+    return out
+
+
+def _bf16(*ts):
+    for t in ts:
+        if t is not None and t.dtype != torch.bfloat16:
+            raise RuntimeError(f"expected bfloat16, got {t.dtype}")
+
+
+def gather_fwd_bf16(vols, points, layout, displacement, align_corners, order=None):
+    """bf16 volumes (B,D,H,W,C) -> bf16 feature rows (B*N, row_stride); geometry and accumulation in f32."""
+    B, N, _ = points.shape
+    _f32(points)
+    _bf16(*vols)
+    d = GatherDesc()
+    d.order = _p(order)
+    d.n_levels, d.B, d.N, d.row_stride = len(vols), B, N, layout.row_stride
+    d.align_corners, d.displacement = int(align_corners), displacement
+    for l, v in enumerate(vols):
+        if v.dim() != 5 or v.shape[0] != B or v.shape[4] != layout.channels[l]:
+            raise RuntimeError(f"level {l}: expected (B,D,H,W,{layout.channels[l]}) channels-last, got {tuple(v.shape)}")
+        L = d.level[l]
+        L.vol, L.C, L.D, L.H, L.W, L.col = _p(v), v.shape[4], v.shape[1], v.shape[2], v.shape[3], layout.col[l]
+    out = torch.empty(B * N, layout.row_stride, device=points.device, dtype=torch.bfloat16)
+    check(_lib.lib().svr_gather_trilinear_fwd_bf16(C.byref(d), _p(points), _p(out), _stream()), "gather_fwd_bf16")
+    return out
+
+
+def linear_fwd_bf16(x, w, bias, relu=True):
+    """y (bf16) = [relu](x (bf16) @ w (bf16).T + bias (f32)), f32 accumulation."""
+    _bf16(x, w)
+    _f32(bias)
+    M, K = x.shape
+    N = w.shape[0]
+    assert w.shape[1] == K and x.stride(1) == 1 and w.stride(1) == 1
+    out = torch.empty(M, N, device=x.device, dtype=torch.bfloat16)
+    epi = EPI_NONE if bias is None else (EPI_BIAS_RELU if relu else EPI_BIAS)
+    check(_lib.lib().svr_linear_fwd_bf16(C.c_void_p(x.data_ptr()), x.stride(0), C.c_void_p(w.data_ptr()), w.stride(0), _p(bias),
+                                         _p(out), out.stride(0), M, N, K, epi, _stream()), "linear_fwd_bf16")
+    return out
+
+
+def fc_out_fwd_bf16(h, w, b):
+    _bf16(h)
+    _f32(w, b)
+    M, K = h.shape
+    out = torch.empty(M, device=h.device, dtype=torch.float32)
+    check(_lib.lib().svr_fc_out_fwd_bf16(_p(h), h.stride(0), _p(w), _p(b), _p(out), M, K, _stream()), "fc_out_fwd_bf16")
+    return out
+
+
+# ------------------------------------------------------------------------------------------
 # point MLP
 # ------------------------------------------------------------------------------------------
 # Arithmetic of the forward GEMMs of the point MLP: "f16x3" (3-product f16 split with power-of-two scaling, as
