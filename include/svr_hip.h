@@ -156,9 +156,9 @@ int svr_gather_trilinear_fwd_bf16(const svr_gather_desc *d, const float *points,
  * epilogue NONE / BIAS / BIAS_RELU with an f32 bias; 32 | K, rows 16-byte aligned.                         */
 int svr_linear_fwd_bf16(const uint16_t *X, int64_t ldx, const uint16_t *W, int64_t ldw, const float *bias, uint16_t *Y,
                         int64_t ldy, int64_t M, int64_t N, int64_t K, int epilogue, void *stream);
-/* logits[m] (f32) = H[m,:] (bf16) . w (f32) + b                                                           */
-int svr_fc_out_fwd_bf16(const uint16_t *H, int64_t ldh, const float *w, const float *b, float *logits, int64_t M,
-                        int64_t K, void *stream);
+/* logits[r(m)] (f32) = H[m,:] (bf16) . w (f32) + b,  r(m) = row_map[m] or m (see svr_fc_out_fwd)           */
+int svr_fc_out_fwd_bf16(const uint16_t *H, int64_t ldh, const float *w, const float *b, float *logits,
+                        const int32_t *row_map, int64_t M, int64_t K, void *stream);
 
 /* ---------------------------------------------------------------------------------------
  * Dense f32 GEMMs on MFMA (replaces nn.Conv1d(.,.,1) fc_0/fc_1/fc_2 model/ifnet.py:19-21,55-57

@@ -52,7 +52,7 @@ SIGNATURES = {
     "svr_cast_f32_to_bf16": (C.c_int, [P, P, I64, P]),
     "svr_gather_trilinear_fwd_bf16": (C.c_int, [C.POINTER(GatherDesc), P, P, P]),
     "svr_linear_fwd_bf16": (C.c_int, [P, I64, P, I64, P, P, I64, I64, I64, I64, C.c_int, P]),
-    "svr_fc_out_fwd_bf16": (C.c_int, [P, I64, P, P, P, I64, I64, P]),
+    "svr_fc_out_fwd_bf16": (C.c_int, [P, I64, P, P, P, P, I64, I64, P]),
     "svr_linear_fwd": (C.c_int, [P, I64, P, I64, P, P, I64, I64, I64, I64, C.c_int, P, I64, P]),
     "svr_linear_bwd_data": (C.c_int, [P, I64, P, I64, P, I64, I64, I64, I64, C.c_int, P, I64, P]),
     "svr_linear_bwd_weight_workspace": (I64, [I64, I64, I64]),

@@ -182,25 +182,28 @@ __global__ __launch_bounds__(256, 3) void linear_nt_bf16_kernel(const uint16_t *
     xp[i] = X + xr * ldx + (t & 3) * 8;
     wp[i] = Wt + wrw * ldw + (t & 3) * 8;
   }
-  struct Regs { uint4 x[2], w[2]; };
-  Regs ra, rb;
+  // two register sets (A: even steps, B: odd steps) as plain variables: a struct passed by reference into the step
+  // lambdas ended up in scratch memory (144 B per lane, 24 scratch instructions per step)
+  uint4 xa0, xa1, wa0, wa1, xb0, xb1, wb0, wb1;
   const int64_t klast = K - BK;
-  auto load = [&](Regs &r, int64_t k0) {
-    k0 = k0 < klast ? k0 : klast;  // past the end: re-read the last step (never used)
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      r.x[i] = *reinterpret_cast<const uint4 *>(xp[i] + k0);
-      r.w[i] = *reinterpret_cast<const uint4 *>(wp[i] + k0);
-    }
-  };
-  auto store = [&](const Regs &r, uint32_t *st) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int off = ((t >> 2) + 64 * i) * BLW + (t & 3) * 4;
-      *reinterpret_cast<uint4 *>(st + off) = r.x[i];
-      *reinterpret_cast<uint4 *>(st + BPLANE + off) = r.w[i];
-    }
-  };
+#define SVR_LOAD(x0, x1, w0, w1, kk0)                                      \
+  {                                                                        \
+    int64_t kq = (kk0);                                                    \
+    kq = kq < klast ? kq : klast; /* past the end: re-read the last step */ \
+    x0 = *reinterpret_cast<const uint4 *>(xp[0] + kq);                     \
+    x1 = *reinterpret_cast<const uint4 *>(xp[1] + kq);                     \
+    w0 = *reinterpret_cast<const uint4 *>(wp[0] + kq);                     \
+    w1 = *reinterpret_cast<const uint4 *>(wp[1] + kq);                     \
+  }
+  const int soff = (t >> 2) * BLW + (t & 3) * 4;
+#define SVR_STORE(x0, x1, w0, w1, st)                                      \
+  {                                                                        \
+    uint32_t *sp = (st);                                                   \
+    *reinterpret_cast<uint4 *>(sp + soff) = x0;                            \
+    *reinterpret_cast<uint4 *>(sp + soff + 64 * BLW) = x1;                 \
+    *reinterpret_cast<uint4 *>(sp + BPLANE + soff) = w0;                   \
+    *reinterpret_cast<uint4 *>(sp + BPLANE + soff + 64 * BLW) = w1;        \
+  }
   f32x16 acc[2][2];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -208,10 +211,8 @@ __global__ __launch_bounds__(256, 3) void linear_nt_bf16_kernel(const uint16_t *
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  auto step = [&](int64_t k0, int cur, Regs &nxt, Regs &fre) {
-    load(fre, k0 + 2 * BK);
-    const uint32_t *pa = lds + cur * 2 * BPLANE, *pb = pa + BPLANE;
+  auto mma = [&](const uint32_t *pa) {  // fragments of one LDS stage -> 8 MFMAs
+    const uint32_t *pb = pa + BPLANE;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       bf16x8 a[2], b[2];
@@ -225,17 +226,28 @@ __global__ __launch_bounds__(256, 3) void linear_nt_bf16_kernel(const uint16_t *
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
     }
-    store(nxt, lds + (cur ^ 1) * 2 * BPLANE);
-    __syncthreads();
   };
-  load(ra, 0);
-  load(rb, BK);
-  store(ra, lds);
+  uint32_t *st0 = lds, *st1 = lds + 2 * BPLANE;
+  SVR_LOAD(xa0, xa1, wa0, wa1, 0)
+  SVR_LOAD(xb0, xb1, wb0, wb1, BK)
+  SVR_STORE(xa0, xa1, wa0, wa1, st0)
   __syncthreads();
+  // step k0 on stage 0: set A (stored one step ago) is refilled with step k0+2, set B (step k0+1, in flight) goes to
+  // stage 1 after the MFMAs; then the same with the roles swapped
   for (int64_t k0 = 0; k0 < K; k0 += 2 * BK) {
-    step(k0, 0, rb, ra);
-    if (k0 + BK < K) step(k0 + BK, 1, ra, rb);
+    SVR_LOAD(xa0, xa1, wa0, wa1, k0 + 2 * BK)
+    mma(st0);
+    SVR_STORE(xb0, xb1, wb0, wb1, st1)
+    __syncthreads();
+    if (k0 + BK < K) {
+      SVR_LOAD(xb0, xb1, wb0, wb1, k0 + 3 * BK)
+      mma(st1);
+      SVR_STORE(xa0, xa1, wa0, wa1, st0)
+      __syncthreads();
+    }
   }
+#undef SVR_LOAD
+#undef SVR_STORE
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -255,8 +267,8 @@ __global__ __launch_bounds__(256, 3) void linear_nt_bf16_kernel(const uint16_t *
 }
 
 __global__ __launch_bounds__(256) void fc_out_fwd_bf16_kernel(const uint16_t *__restrict__ Hm, int64_t ldh, const float *__restrict__ w,
-                                                              const float *__restrict__ b, float *__restrict__ logits, int64_t M,
-                                                              int64_t K) {
+                                                              const float *__restrict__ b, float *__restrict__ logits,
+                                                              const int32_t *__restrict__ row_map, int64_t M, int64_t K) {
   const int64_t row = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 4;
   const int sub = threadIdx.x & 15;
   float s = 0.f;
@@ -271,7 +283,7 @@ __global__ __launch_bounds__(256) void fc_out_fwd_bf16_kernel(const uint16_t *__
   }
 #pragma unroll
   for (int o = 8; o >= 1; o >>= 1) s += __shfl_xor(s, o);
-  if (row < M && sub == 0) logits[row] = s + b[0];
+  if (row < M && sub == 0) logits[row_map ? (int64_t)row_map[row] : row] = s + b[0];
 }
 
 }  // namespace
@@ -343,12 +355,12 @@ extern "C" int svr_linear_fwd_bf16(const uint16_t *X, int64_t ldx, const uint16_
   return launch_status("linear_fwd_bf16");
 }
 
-extern "C" int svr_fc_out_fwd_bf16(const uint16_t *H, int64_t ldh, const float *w, const float *b, float *logits, int64_t M,
-                                   int64_t K, void *stream) {
+extern "C" int svr_fc_out_fwd_bf16(const uint16_t *H, int64_t ldh, const float *w, const float *b, float *logits,
+                                   const int32_t *row_map, int64_t M, int64_t K, void *stream) {
   if (M <= 0) return SVR_OK;
   SVR_CHECK(H && w && b && logits, SVR_E_BADARG, "fc_out_fwd_bf16: null pointer");
   SVR_CHECK(K > 0 && K % 8 == 0 && ldh % 8 == 0 && (((uintptr_t)H) & 15) == 0, SVR_E_BADSHAPE, "fc_out_fwd_bf16: K=%ld ldh=%ld", (long)K, (long)ldh);
   hipLaunchKernelGGL(fc_out_fwd_bf16_kernel, dim3((unsigned)cdiv(M * 16, 256)), dim3(256), 0, (hipStream_t)stream, H, ldh, w, b,
-                     logits, M, K);
+                     logits, row_map, M, K);
   return launch_status("fc_out_fwd_bf16");
 }

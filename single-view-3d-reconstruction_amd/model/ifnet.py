@@ -393,26 +393,32 @@ class IFNet(nn.Module):
         return levels
 
     @torch.no_grad()
-    def _query_bf16(self, levels, points):
+    def _query_bf16(self, levels, points, row_map):
         B, N = points.shape[0], points.shape[1]
         ext = self.ifnet_feature_extractor
-        rows = ops.gather_fwd_bf16(levels, points.float().contiguous(), ext._layout, ext._disp, ext._align)
+        rows = ops.gather_fwd_bf16(levels, points, ext._layout, ext._disp, ext._align)
         h = ops.linear_fwd_bf16(rows, ops.cast_bf16(self._fc0_internal()), self.fc_0.bias, relu=True)
         h = ops.linear_fwd_bf16(h, ops.cast_bf16(self.fc_1.weight.squeeze(2).contiguous()), self.fc_1.bias, relu=True)
         h = ops.linear_fwd_bf16(h, ops.cast_bf16(self.fc_2.weight.squeeze(2).contiguous()), self.fc_2.bias, relu=True)
-        return ops.fc_out_fwd_bf16(h, self.fc_out.weight.reshape(-1).contiguous(), self.fc_out.bias).view(B, N)
+        return ops.fc_out_fwd_bf16(h, self.fc_out.weight.reshape(-1).contiguous(), self.fc_out.bias, row_map).view(B, N)
 
     @torch.no_grad()
-    def query(self, levels, points):
-        """Logits (B,N) for `points` against a pyramid from encode() (f32, or bf16 storage)."""
-        if levels[0].dtype == torch.bfloat16:
-            return self._query_bf16(levels, points)
+    def query(self, levels, points, spatial_sort=False):
+        """Logits (B,N) for `points` against a pyramid from encode() (f32, or bf16 storage).  spatial_sort: visit the
+        points of every sample in Morton order (pays off for scattered points: the gather's corner reads become cache
+        hits; a dense lattice is ordered already); results do not depend on it."""
         B, N = points.shape[0], points.shape[1]
+        points = points.float().contiguous()
+        row_map = None
+        if spatial_sort and N > 1:
+            row_map, points = ops.morton_order(points, want_sorted=True)
+        if levels[0].dtype == torch.bfloat16:
+            return self._query_bf16(levels, points, row_map)
         rows = self.ifnet_feature_extractor.feature_rows_from_levels(levels, points)
         h = ops.linear_fwd(rows, self._fc0_internal(), self.fc_0.bias, relu=True)
         h = ops.linear_fwd(h, self.fc_1.weight.squeeze(2), self.fc_1.bias, relu=True)
         h = ops.linear_fwd(h, self.fc_2.weight.squeeze(2), self.fc_2.bias, relu=True)
-        return ops.fc_out_fwd(h, self.fc_out.weight.reshape(-1).contiguous(), self.fc_out.bias).view(B, N)
+        return ops.fc_out_fwd(h, self.fc_out.weight.reshape(-1).contiguous(), self.fc_out.bias, row_map).view(B, N)
 
     def forward(self, x, points, spatial_sort=True):
         """logits (B,N).  With spatial_sort the points of every sample are visited in Morton order: the whole

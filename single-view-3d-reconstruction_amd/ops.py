@@ -249,12 +249,13 @@ def linear_fwd_bf16(x, w, bias, relu=True):
     return out
 
 
-def fc_out_fwd_bf16(h, w, b):
+def fc_out_fwd_bf16(h, w, b, row_map=None):
     _bf16(h)
     _f32(w, b)
     M, K = h.shape
     out = torch.empty(M, device=h.device, dtype=torch.float32)
-    check(_lib.lib().svr_fc_out_fwd_bf16(_p(h), h.stride(0), _p(w), _p(b), _p(out), M, K, _stream()), "fc_out_fwd_bf16")
+    check(_lib.lib().svr_fc_out_fwd_bf16(_p(h), h.stride(0), _p(w), _p(b), _p(out), _p(row_map), M, K, _stream()),
+          "fc_out_fwd_bf16")
     return out
 
 

@@ -155,3 +155,16 @@ def test_bf16_dense_grid_inference():
     a = evaluate_network_on_grid(m, x[:1].cuda(), (16, 16, 16), 1, points_batch_size=1000)
     b = evaluate_network_on_grid(m, x[:1].cuda(), (16, 16, 16), 1, points_batch_size=1000, storage="bf16")
     assert b.shape == a.shape and np.abs(a - b).max() < 2e-2 * max(np.abs(a).max(), 1e-6) + 5e-3
+
+
+def test_query_spatial_sort_is_result_neutral():
+    import svr_amd  # noqa: F401
+    from svr_amd.model import IFNet
+    z = G.load("ifnet_cfg1")
+    net_res, x, pts, _ = G.ifnet_inputs(z)
+    m = IFNet(net_res=net_res)
+    m.load_state_dict(G.state(net_res, z=z), strict=False)
+    m = m.cuda().eval()
+    for storage in ("f32", "bf16"):
+        lv = m.encode(x.cuda(), storage)
+        assert torch.equal(m.query(lv, pts.cuda()), m.query(lv, pts.cuda(), spatial_sort=True)), storage
