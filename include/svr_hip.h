@@ -354,6 +354,29 @@ int svr_blur_axis_bwd(const float *in, const float *taps, const float *gout, flo
                       double *gtaps, int32_t B, int32_t D0, int32_t D1, int32_t D2, int32_t axis,
                       int32_t K, void *stream);
 
+/* ---------------------------------------------------------------------------------------
+ * Occupancy labelling against a triangle mesh (replaces check_mesh_contains,
+ * data_processing/libmesh/inside_mesh.py:5-155, and the Cython TriangleHash, libmesh/triangle_hash.pyx:8-85,
+ * called per training step by data_processing/mesh_occupancies.py:24-53 when subsample_points > 0).
+ * Host side (plain C++, no device work): the 2-D triangle hash as a CSR table.
+ *   svr_mesh_hash_entries: number of (cell, triangle) entries; writes scale[3], translate[3] of the mesh rescale to
+ *                          [0.5, res-0.5]^3 (inside_mesh.py:17-22) to scale_translate[6].  Negative = SVR_E_*.
+ *   svr_mesh_hash_build:   tri (n_faces*9 rescaled float64 coordinates), cell_start (res*res+1), tri_ids (entries;
+ *                          triangles in index order inside a cell, like the reference's push_back order).
+ * verts (n_verts,3) float64 and faces (n_faces,3) int32 are HOST arrays; all outputs are HOST arrays the caller
+ * then copies to the device.
+ * Device side: svr_mesh_contains -- points (n,3) float32 (points_f64 = 0) or float64 (1) on the device;
+ * contains[i] = inside by both z-ray directions, holes[i] = the two directions disagree (uint8 0/1).  float64
+ * arithmetic in the reference's operation order: the booleans equal the reference's bit for bit.
+ * ------------------------------------------------------------------------------------- */
+int64_t svr_mesh_hash_entries(const double *verts, int64_t n_verts, const int32_t *faces, int64_t n_faces, int32_t res,
+                              double *scale_translate);
+int svr_mesh_hash_build(const double *verts, int64_t n_verts, const int32_t *faces, int64_t n_faces, int32_t res,
+                        double *tri, int32_t *cell_start, int32_t *tri_ids, int64_t entries);
+int svr_mesh_contains(const void *points, int32_t points_f64, int64_t n, const double *tri, const int32_t *cell_start,
+                      const int32_t *tri_ids, int32_t res, const double *scale_translate, uint8_t *contains,
+                      uint8_t *holes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

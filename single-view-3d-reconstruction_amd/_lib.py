@@ -90,6 +90,9 @@ SIGNATURES = {
     "svr_bn_apply_pool": (C.c_int, [P, P, P, P, P, I32, I32, I32, I32, I32, P]),
     "svr_bn_bwd_reduce": (C.c_int, [P, P, P, P, P, P, P, I32, I32, I32, I32, I32, P, P]),
     "svr_bn_bwd_apply": (C.c_int, [P, P, P, P, P, P, P, P, P, P, P, I32, I32, I32, I32, I32, C.c_int, P]),
+    "svr_mesh_hash_entries": (I64, [P, I64, P, I64, I32, P]),
+    "svr_mesh_hash_build": (C.c_int, [P, I64, P, I64, I32, P, P, P, I64]),
+    "svr_mesh_contains": (C.c_int, [P, I32, I64, P, P, P, I32, P, P, P, P]),
     "svr_unproject_fwd": (C.c_int, [P, P, I32, I32, I32, C.POINTER(F32), C.c_int, P]),
     "svr_unproject_bwd": (C.c_int, [P, P, P, I32, I32, I32, C.POINTER(F32), C.c_int, P]),
     "svr_voxelize_splat_fwd": (C.c_int, [P, P, P, P, I32, I32, I32, I32, I32, P]),

@@ -26,6 +26,7 @@ SOURCES = {
     "bn_pool.hip": [],
     "projection.hip": ["-ffp-contract=off"],
     "bf16_path.hip": ["-ffp-contract=off"],
+    "mesh_occupancy.hip": ["-ffp-contract=off"],
 }
 COMMON = ["-O3", "-fPIC", "--offload-arch=gfx950", "-munsafe-fp-atomics", "-std=c++17", "-I" + INCLUDE, "-I" + CSRC]
 

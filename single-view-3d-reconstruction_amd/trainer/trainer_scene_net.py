@@ -8,8 +8,9 @@
     Adam groups: unet lr, project 10*lr, ifnet lr                                        (:45-55)
 
 The UNet is stock PyTorch-ROCm ops; unprojection, splat, blur, encoder, gather,
-MLP and the BCE run in the HIP kernels.  `subsample_points > 0` needs the reference's CPU mesh
-labelling (determine_occupancy, trimesh: out of scope) and raises here.
+MLP and the BCE run in the HIP kernels.  `subsample_points != 0` (:91-99,108-114): the projected point cloud is
+queried too and labelled against the sample's mesh ON THE DEVICE (..data_processing.mesh_occupancies.determine_occupancy,
+SURVEY §8 f3) -- the reference copies it to the host and runs trimesh + Cython + numpy per step.
 """
 from types import SimpleNamespace
 
@@ -21,6 +22,7 @@ from .. import ops
 from ..model.ifnet import IFNet
 from ..model.projection import project
 from ..model.unet import UNetMini, Unet
+from ..data_processing.mesh_occupancies import determine_occupancy
 
 
 class _BCELogitsMeanFn(torch.autograd.Function):
@@ -40,7 +42,8 @@ class _BCELogitsMeanFn(torch.autograd.Function):
 
 def default_hparams(**kw):
     h = dict(lr=1e-4, kernel_size=[3, 3, 3], sigma=[1.5, 1.5, 1.5], scale_factor=1, resize_input=True, skip_unet=False,
-             subsample_points=0, no_depth_sup=False, min_z=0.1953997164964676, max_z=7.0, net_res=128)
+             subsample_points=0, no_depth_sup=False, min_z=0.1953997164964676, max_z=7.0, net_res=128,
+             reference_occupancy_quirk=True)
     h.update(kw)
     return SimpleNamespace(**h)
 
@@ -85,16 +88,41 @@ class SceneNetTrainer(nn.Module):
         # unproject + normalise fused in one kernel
         point_cloud = self.project.depthmap_to_gridspace(depth.contiguous(), h.scale_factor, normalize=True)
         voxel_occupancy = self.project(point_cloud)
-        if h.subsample_points != 0:
-            raise NotImplementedError("subsample_points > 0 needs the reference's CPU mesh labelling (out of scope)")
-        points = batch["points"]
+        # trainer_scene_net.py:91-99.  The reference's first condition reads `n < (240*320) & n > 0`: `&` binds tighter
+        # than the comparisons, so it is the chain  n < (76800 & n) > 0 , which no n satisfies (76800 & n <= n) -- the
+        # random-subset branch is dead code there and the whole point cloud is used whenever n != 0.  Mirrored as is.
+        n = h.subsample_points
+        masked = (240 * 320) & n if n > 0 else 0
+        if n < masked and masked > 0:
+            indices = torch.randperm(point_cloud.shape[1], device=point_cloud.device)[:n]
+            point_cloud = point_cloud[:, indices, :].contiguous()
+            points = torch.cat((point_cloud, batch["points"]), dim=1)
+        elif n == 0:
+            points = batch["points"]
+        else:
+            points = torch.cat((point_cloud, batch["points"]), dim=1)
         logits_depth = self.ifnet(voxel_occupancy, points)
         return logits_depth, depth, point_cloud
+
+    def _occupancies(self, batch, point_cloud):
+        """trainer_scene_net.py:108-114: ground truth of the extra query points = on-the-fly labelling against the mesh."""
+        if self.hparams.subsample_points == 0:
+            return batch["occupancies"]
+        # (the reference calls it with the default dims (139, 104, 112) whatever scale_factor is, :112)
+        _, occ_pc = determine_occupancy(batch["mesh"], point_cloud.detach(),
+                                        reference_quirk=getattr(self.hparams, "reference_occupancy_quirk", True),
+                                        points_normalized=True)
+        return torch.cat((occ_pc.to(batch["occupancies"].dtype), batch["occupancies"]), dim=1)
 
     def losses_and_logging(self, batch, depthmap, logits, occupancies, mode="train"):
         ce_loss = _BCELogitsMeanFn.apply(logits, occupancies)
         mse_loss = F.mse_loss(depthmap, batch["depthmap_target"], reduction="mean")
+        mesh_ce_loss = ce_loss
+        if self.hparams.subsample_points > 0:          # :151-154 (logged only)
+            k = self.hparams.subsample_points
+            mesh_ce_loss = _BCELogitsMeanFn.apply(logits[:, k:].contiguous(), occupancies[:, k:].contiguous())
         self.last_log = {f"{mode}_ce_loss": ce_loss.detach(), f"{mode}_mse_depth_loss": mse_loss.detach(),
+                         f"{mode}_mesh_ce_loss": mesh_ce_loss.detach(),
                          "sigma_x": self.project.sigma[2].detach(), "sigma_y": self.project.sigma[1].detach(),
                          "sigma_z": self.project.sigma[0].detach()}
         if self.hparams.no_depth_sup:
@@ -102,6 +130,7 @@ class SceneNetTrainer(nn.Module):
         return ce_loss + mse_loss
 
     def training_step(self, batch, batch_idx):
-        logits, depthmap, _ = self.forward(batch)
-        loss = self.losses_and_logging(batch, depthmap, logits, batch["occupancies"], "train")
+        logits, depthmap, point_cloud = self.forward(batch)
+        occupancies = self._occupancies(batch, point_cloud)
+        loss = self.losses_and_logging(batch, depthmap, logits, occupancies, "train")
         return {"loss": loss}
