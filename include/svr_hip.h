@@ -31,6 +31,8 @@ extern "C" {
 #define SVR_E_BADSHAPE (-2)
 #define SVR_E_ALIGN (-3)
 #define SVR_E_UNSUPPORTED (-4)
+#define SVR_E_IO (-5)
+#define SVR_E_NOTFOUND (-6)
 
 #define SVR_MAX_LEVELS 6
 
@@ -376,6 +378,31 @@ int svr_mesh_hash_build(const double *verts, int64_t n_verts, const int32_t *fac
 int svr_mesh_contains(const void *points, int32_t points_f64, int64_t n, const double *tri, const int32_t *cell_start,
                       const int32_t *tri_ids, int32_t res, const double *scale_translate, uint8_t *contains,
                       uint8_t *holes, void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Sample wire formats (replaces the Python loaders of dataset/implicit_dataset.py:24-56,
+ * data_processing/volume_reader.py:36-45 and the np.load calls on process_sample.py:19-30's outputs).
+ * Host side (plain C++ + zlib; `out` / `payload` are HOST buffers, ideally pinned):
+ *   .df  = 3 x uint64 dims (X, Y, Z) + X*Y*Z float32, x fastest;
+ *   .npz = zip of .npy members (stored by np.savez, deflated by np.savez_compressed; zip64 local headers).
+ * Device side: x-fastest -> C-order transpose of a .df payload, casts to float32, and the random row subset of
+ * implicit_dataset.py:40-43 as a gather with cast (idx: device int64; rows outside [0, n_rows) set *bad_flag).
+ * ------------------------------------------------------------------------------------- */
+#define SVR_DT_F32 0
+#define SVR_DT_F64 1
+#define SVR_DT_BOOL 2
+#define SVR_DT_U8 3
+#define SVR_DT_I32 4
+#define SVR_DT_I64 5
+int svr_df_dims(const char *path, int64_t *dims /*[3]*/);
+int svr_df_read(const char *path, float *payload, int64_t n);
+int svr_npz_member_info(const char *path, const char *member, int32_t *dtype, int32_t *ndim, int64_t *shape /*[8]*/,
+                        int32_t *fortran_order);
+int svr_npz_member_read(const char *path, const char *member, void *out, int64_t nbytes);
+int svr_df_to_grid(const float *payload, float *out /*(X,Y,Z) C order*/, int32_t X, int32_t Y, int32_t Z, void *stream);
+int svr_cast_to_f32(const void *in, int32_t dtype, float *out, int64_t n, void *stream);
+int svr_subsample_rows(const void *rows, int32_t dtype, int64_t n_rows, int32_t cols, const int64_t *idx, int64_t n_idx,
+                       float *out, int32_t *bad_flag, void *stream);
 
 #ifdef __cplusplus
 }

@@ -93,6 +93,13 @@ SIGNATURES = {
     "svr_mesh_hash_entries": (I64, [P, I64, P, I64, I32, P]),
     "svr_mesh_hash_build": (C.c_int, [P, I64, P, I64, I32, P, P, P, I64]),
     "svr_mesh_contains": (C.c_int, [P, I32, I64, P, P, P, I32, P, P, P, P]),
+    "svr_df_dims": (C.c_int, [C.c_char_p, P]),
+    "svr_df_read": (C.c_int, [C.c_char_p, P, I64]),
+    "svr_npz_member_info": (C.c_int, [C.c_char_p, C.c_char_p, P, P, P, P]),
+    "svr_npz_member_read": (C.c_int, [C.c_char_p, C.c_char_p, P, I64]),
+    "svr_df_to_grid": (C.c_int, [P, P, I32, I32, I32, P]),
+    "svr_cast_to_f32": (C.c_int, [P, I32, P, I64, P]),
+    "svr_subsample_rows": (C.c_int, [P, I32, I64, I32, P, I64, P, P, P]),
     "svr_unproject_fwd": (C.c_int, [P, P, I32, I32, I32, C.POINTER(F32), C.c_int, P]),
     "svr_unproject_bwd": (C.c_int, [P, P, P, I32, I32, I32, C.POINTER(F32), C.c_int, P]),
     "svr_voxelize_splat_fwd": (C.c_int, [P, P, P, P, I32, I32, I32, I32, I32, P]),

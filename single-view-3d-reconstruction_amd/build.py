@@ -27,6 +27,7 @@ SOURCES = {
     "projection.hip": ["-ffp-contract=off"],
     "bf16_path.hip": ["-ffp-contract=off"],
     "mesh_occupancy.hip": ["-ffp-contract=off"],
+    "sample_io.hip": [],
 }
 COMMON = ["-O3", "-fPIC", "--offload-arch=gfx950", "-munsafe-fp-atomics", "-std=c++17", "-I" + INCLUDE, "-I" + CSRC]
 
@@ -68,7 +69,7 @@ def build(force=False, verbose=False):
         if p.returncode != 0:
             raise RuntimeError(f"hipcc failed on {src}:\n{out.decode(errors='replace')}")
     if force or procs or _stale(LIB, objs):
-        cmd = [_hipcc(), "-shared", "-fPIC", "--offload-arch=gfx950", "-o", LIB] + objs
+        cmd = [_hipcc(), "-shared", "-fPIC", "--offload-arch=gfx950", "-o", LIB] + objs + ["-lz"]
         r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
         if r.returncode != 0:
             raise RuntimeError("link failed:\n" + r.stdout.decode(errors="replace"))

@@ -1,0 +1,87 @@
+"""CPU: the native sample readers (C++ + zlib behind the C ABI's host functions; no GPU) against numpy's own loaders,
+the struct-based oracle restatement of the reference's read_df, and the reference's real depth_grid.npz; and the
+ImplicitDataset mirror against the oracle's restatement of the reference's __getitem__ under the same numpy seed."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import dataset_oracle as DO
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _io():
+    import svr_amd  # noqa: F401
+    from svr_amd.data_processing import sample_io
+    return sample_io
+
+
+def test_reference_depth_grid_npz():
+    io = _io()
+    p = os.path.join(GOLD, "ref_depth_grid.npz")          # data/processed/overfit/00000/depth_grid.npz of the reference
+    ref = np.load(p)["grid"]
+    assert io.npz_member_info(p, "grid") == (np.float64, (139, 104, 112), False)
+    got = io.npz_load(p, "grid")
+    assert got.dtype == np.float64 and np.array_equal(got, ref) and ref.sum() == 5466.0
+    with pytest.raises(RuntimeError, match="no member"):
+        io.npz_load(p, "nope")
+
+
+@pytest.mark.parametrize("dims", [(139, 104, 112), (7, 5, 3), (1, 1, 1), (33, 64, 2)])
+def test_df_reader_and_read_df(tmp_path, dims):
+    io = _io()
+    from svr_amd.data_processing.volume_reader import down_sample, read_df
+    rng = np.random.default_rng(sum(dims))
+    vol = rng.standard_normal(dims).astype(np.float32)
+    f = tmp_path / "v.df"
+    DO.write_df(f, vol)
+    assert io.df_dims(f) == dims
+    got = read_df(str(f))
+    if np.prod(dims) <= 100000:
+        assert np.array_equal(got, DO.read_df(str(f)))         # the struct.unpack restatement (small sizes only: slow)
+    assert got.dtype == np.float32 and got.shape == dims and np.array_equal(got, vol)
+    half = read_df(str(f), 2)
+    assert half.shape == tuple(-(-d // 2) for d in dims)
+    assert np.allclose(half[0, 0, 0], np.pad(vol, [(0, (-d) % 2) for d in dims])[:2, :2, :2].mean(), atol=1e-6)
+    with open(f, "r+b") as fh:                                   # truncated payload: loud, like the reference's raise
+        fh.truncate(24 + 4 * (int(np.prod(dims)) - 1) if np.prod(dims) > 1 else 20)
+    with pytest.raises(RuntimeError):
+        read_df(str(f))
+
+
+def test_npz_members_stored_and_deflated(tmp_path):
+    io = _io()
+    rng = np.random.default_rng(1)
+    arrays = {"points": rng.uniform(-0.5, 0.5, size=(10000, 3)), "occupancies": rng.random(10000) < 0.3,
+              "grid_coords": rng.standard_normal((10000, 3)), "f32": rng.standard_normal((5, 7)).astype(np.float32),
+              "i64": np.arange(12, dtype=np.int64).reshape(3, 4), "fort": np.asfortranarray(rng.standard_normal((4, 6)))}
+    np.savez(tmp_path / "stored.npz", **arrays)
+    np.savez_compressed(tmp_path / "deflated.npz", **arrays)
+    for name in ("stored.npz", "deflated.npz"):
+        for k, v in arrays.items():
+            dtype, shape, fortran = io.npz_member_info(tmp_path / name, k)
+            assert dtype == v.dtype.type and shape == v.shape and fortran == (k == "fort")
+            assert np.array_equal(io.npz_load(tmp_path / name, k), v), (name, k)
+
+
+def test_implicit_dataset_matches_reference_getitem(tmp_path):
+    import svr_amd  # noqa: F401
+    from svr_amd.dataset import ImplicitDataset
+    root = tmp_path / "data"
+    (tmp_path / "splits" / "overfit").mkdir(parents=True)
+    (tmp_path / "splits" / "overfit" / "train.txt").write_text("00000\n00001\n\n")
+    DO.make_sample(root / "processed" / "overfit" / "00000", grid_from=os.path.join(GOLD, "ref_depth_grid.npz"), seed=1)
+    DO.make_sample(root / "processed" / "overfit" / "00001", dims=(20, 12, 16), n_pts=700, seed=2)
+    ds = ImplicitDataset("train", root, 300, "overfit", splits_root=tmp_path / "splits")
+    assert len(ds) == 100 and ds.data[0] == "00000" and ds.data[1] == "00001"          # x50 for the overfit split (:18)
+    for idx in (0, 1):
+        np.random.seed(123 + idx)
+        got = ds[idx]
+        np.random.seed(123 + idx)
+        ref = DO.getitem(root / "processed" / "overfit" / ds.data[idx], ds.data[idx], 300)
+        assert set(got) == set(ref) and got["name"] == ref["name"]
+        for k in ("grid", "points", "input", "occupancies", "target"):
+            assert got[k].dtype == ref[k].dtype and got[k].shape == ref[k].shape and torch.equal(got[k], ref[k]), k
+    assert tuple(ds[0]["input"].shape) == (1, 139, 104, 112) and tuple(ds[0]["points"].shape) == (600, 3)
