@@ -43,7 +43,7 @@ class _BCELogitsMeanFn(torch.autograd.Function):
 def default_hparams(**kw):
     h = dict(lr=1e-4, kernel_size=[3, 3, 3], sigma=[1.5, 1.5, 1.5], scale_factor=1, resize_input=True, skip_unet=False,
              subsample_points=0, no_depth_sup=False, min_z=0.1953997164964676, max_z=7.0, net_res=128,
-             reference_occupancy_quirk=True)
+             reference_occupancy_quirk=True, miopen_benchmark=True)
     h.update(kw)
     return SimpleNamespace(**h)
 
@@ -59,6 +59,10 @@ class SceneNetTrainer(nn.Module):
             dims = (torch.tensor([139, 104, 112]) / h.scale_factor).round().long()
         self.dims = torch.as_tensor(dims).long()
         self.project = project(self.dims, self.kernel_size, torch.tensor(h.sigma, dtype=torch.float32))
+        if not h.skip_unet and getattr(h, "miopen_benchmark", True):
+            # The UNet's stock MIOpen convolutions fall back to `naive_conv_*` solvers on gfx950 unless MIOpen is allowed
+            # to time its solvers once per shape: config-5 step 79 -> 27 ms (tools/bench_scene.py).  Process-wide switch.
+            torch.backends.cudnn.benchmark = True
         if h.skip_unet:
             self.unet = None
         elif h.resize_input:
