@@ -357,6 +357,26 @@ int svr_blur_axis_bwd(const float *in, const float *taps, const float *gout, flo
                       int32_t K, void *stream);
 
 /* ---------------------------------------------------------------------------------------
+ * 2-D convolution blocks of the UNet depth regressor (replaces nn.Conv2d(k4,s2,p1) / nn.Conv2d(k3,s1,p1),
+ * nn.LeakyReLU(0.2) / nn.ReLU, nn.Upsample(scale_factor=2, mode="bilinear") and torch.cat of model/unet.py:38-60,
+ * 66-118 and their autograd).  Channels-last (B,H,W,C) float32.  A block's input is  act( cat(src0, src1) ), optionally
+ * upsampled x2 (align_corners False); svr_conv2d_im2col writes its patch matrix
+ *   col[(b,oy,ox)][(ky*k+kx)*C + c],  C = C0 + C1,  (B*Ho*Wo) x (k*k*C),  Ho = (Hv + 2 - k)/stride + 1
+ * and the convolution itself is svr_linear_fwd* on it (weights repacked to [Cout][(ky*k+kx)*C + c]); backward:
+ * svr_linear_bwd_weight* on (dY, col), svr_linear_bwd_data* -> dcol, then svr_conv2d_col2im sums dcol back in gather
+ * form (workspace dvirt: B*Hv*Wv*C floats), applies the upsample adjoint and the activation mask and writes the
+ * gradients of the two sources (either may be NULL).  act: 0 none, 1 LeakyReLU(0.2), 2 ReLU.
+ * ------------------------------------------------------------------------------------- */
+typedef struct svr_conv2d_desc {
+  const float *src0, *src1; /* (B,H,W,C0), (B,H,W,C1) or NULL */
+  int32_t B, H, W, C0, C1;
+  int32_t k, stride;        /* (4,2) or (3,1); padding 1 */
+  int32_t act, upsample;
+} svr_conv2d_desc;
+int svr_conv2d_im2col(const svr_conv2d_desc *d, float *col, void *stream);
+int svr_conv2d_col2im(const svr_conv2d_desc *d, const float *dcol, float *dvirt, float *dsrc0, float *dsrc1, void *stream);
+
+/* ---------------------------------------------------------------------------------------
  * Occupancy labelling against a triangle mesh (replaces check_mesh_contains,
  * data_processing/libmesh/inside_mesh.py:5-155, and the Cython TriangleHash, libmesh/triangle_hash.pyx:8-85,
  * called per training step by data_processing/mesh_occupancies.py:24-53 when subsample_points > 0).

@@ -16,6 +16,11 @@ P = C.c_void_p
 I32, I64, F32 = C.c_int32, C.c_int64, C.c_float
 
 
+class Conv2dDesc(C.Structure):
+    _fields_ = [("src0", P), ("src1", P), ("B", I32), ("H", I32), ("W", I32), ("C0", I32), ("C1", I32), ("k", I32),
+                ("stride", I32), ("act", I32), ("upsample", I32)]
+
+
 class PullPlan(C.Structure):
     _fields_ = [("keys", P), ("recs", P), ("heads", P), ("n_items", I64)]
 
@@ -90,6 +95,8 @@ SIGNATURES = {
     "svr_bn_apply_pool": (C.c_int, [P, P, P, P, P, I32, I32, I32, I32, I32, P]),
     "svr_bn_bwd_reduce": (C.c_int, [P, P, P, P, P, P, P, I32, I32, I32, I32, I32, P, P]),
     "svr_bn_bwd_apply": (C.c_int, [P, P, P, P, P, P, P, P, P, P, P, I32, I32, I32, I32, I32, C.c_int, P]),
+    "svr_conv2d_im2col": (C.c_int, [C.POINTER(Conv2dDesc), P, P]),
+    "svr_conv2d_col2im": (C.c_int, [C.POINTER(Conv2dDesc), P, P, P, P, P]),
     "svr_mesh_hash_entries": (I64, [P, I64, P, I64, I32, P]),
     "svr_mesh_hash_build": (C.c_int, [P, I64, P, I64, I32, P, P, P, I64]),
     "svr_mesh_contains": (C.c_int, [P, I32, I64, P, P, P, I32, P, P, P, P]),

@@ -28,6 +28,7 @@ SOURCES = {
     "bf16_path.hip": ["-ffp-contract=off"],
     "mesh_occupancy.hip": ["-ffp-contract=off"],
     "sample_io.hip": [],
+    "conv2d.hip": [],
 }
 COMMON = ["-O3", "-fPIC", "--offload-arch=gfx950", "-munsafe-fp-atomics", "-std=c++17", "-I" + INCLUDE, "-I" + CSRC]
 

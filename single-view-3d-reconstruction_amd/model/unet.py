@@ -1,13 +1,86 @@
-"""UNet depth regressors (mirror of the reference's model/unet.py:15-118 `Unet`, :121-186 `UNetMini`).
+"""UNet depth regressors on MI355X: mirror of the reference's model/unet.py:15-118 (`Unet`) and :121-186 (`UNetMini`),
+the stage in front of the hot path in BASELINE config 5.
 
-This is the stage BEFORE the hot path in BASELINE config 5.  It is not a
-hand-kernel target of the north star: the layers are stock PyTorch-ROCm ops (MIOpen Conv2d,
-BatchNorm2d, bilinear upsample).  Parameter names and shapes match the reference so `unet.*`
-checkpoint entries load (trainer/trainer_scene_net.py:204-212).
-"""
+Same constructor arguments, forward signature ((B,Cin,H,W) -> (B,Cout,H,W)) and parameter / buffer names, so `unet.*`
+checkpoint entries load (trainer/trainer_scene_net.py:204-212).  The nn.Conv2d / nn.BatchNorm2d submodules only HOLD the
+parameters.  backend="hip" (default on GPU tensors): every layer runs in the library's kernels -- an explicit im2col with
+the LeakyReLU / ReLU, the bilinear x2 upsample and the decoder's torch.cat fused into the gather (conv2d.hip), the
+split-precision MFMA GEMMs of the point MLP for the products (f16x3 forward, bf16x3 backward), and the BatchNorm kernels
+of the 3-D encoder on (B,1,H,W,C) views; activations are channels-last inside.  backend="stock": the layers as stock
+PyTorch-ROCm ops (MIOpen), kept for A/B measurements (15-50 ms per config-5 step against ~3 ms)."""
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
+
+from .. import ops
+
+
+class _ConvBlockFn(torch.autograd.Function):
+    """y (B,Ho,Wo,Cout) = conv_k( [upsample x2]( act( cat(src0, src1) ) ) ) + bias, channels-last."""
+
+    @staticmethod
+    def forward(ctx, src0, src1, weight, bias, k, stride, act, up):
+        src0 = src0.contiguous()
+        src1 = src1.contiguous() if src1 is not None else None
+        Cout = weight.shape[0]
+        col, (Ho, Wo) = ops.conv2d_im2col(src0, src1, k, stride, act, up)
+        wp = weight.detach().permute(0, 2, 3, 1).reshape(Cout, -1)              # [Cout][(ky*k+kx)*C + c]
+        npad = Cout if Cout % 32 == 0 else (Cout + 31) // 32 * 32                # the GEMMs want 32 | N (dconv8: Cout = 1)
+        if npad != Cout:
+            wp = torch.cat([wp, wp.new_zeros(npad - Cout, wp.shape[1])])
+            b = torch.cat([bias.detach(), bias.new_zeros(npad - Cout)])
+        else:
+            b = bias.detach()
+        wp = wp.contiguous()
+        y = ops.linear_fwd(col, wp, b, relu=False)
+        ctx.save_for_backward(src0, src1, wp)
+        ctx.cfg = (k, stride, act, up, Cout, npad, tuple(weight.shape))
+        B = src0.shape[0]
+        return y[:, :Cout].reshape(B, Ho, Wo, Cout) if npad != Cout else y.view(B, Ho, Wo, Cout)
+
+    @staticmethod
+    def backward(ctx, dy):
+        src0, src1, wp = ctx.saved_tensors
+        k, stride, act, up, Cout, npad, wshape = ctx.cfg
+        dy2 = dy.reshape(-1, Cout)
+        if npad != Cout:
+            dyp = dy2.new_zeros(dy2.shape[0], npad)
+            dyp[:, :Cout] = dy2
+            dy2 = dyp
+        dy2 = dy2.contiguous()
+        col, _ = ops.conv2d_im2col(src0, src1, k, stride, act, up)              # recomputed: cheaper than keeping 1.2 GB
+        dwp, db = ops.linear_bwd_weight(dy2, col)
+        del col
+        dw = dwp[:Cout].view(Cout, k, k, -1).permute(0, 3, 1, 2).contiguous().view(wshape)
+        need0, need1 = ctx.needs_input_grad[0], ctx.needs_input_grad[1] and src1 is not None
+        d0 = d1 = None
+        if need0 or need1:
+            dcol = ops.linear_bwd_data(dy2, wp)
+            d0, d1 = ops.conv2d_col2im(src0, src1, k, stride, act, up, dcol, need0, need1)
+        return d0, d1, dw, db[:Cout].contiguous(), None, None, None, None
+
+
+class _BN2dFn(torch.autograd.Function):
+    """BatchNorm2d on a channels-last (B,H,W,C) tensor through the 3-D encoder's BatchNorm kernels (D = 1)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, bn):
+        B, H, W, C_ = x.shape
+        x5 = x.contiguous().view(B, 1, H, W, C_)
+        y, _, _, ss, mean = ops.bn_forward(x5, gamma.detach(), beta.detach(), bn.running_mean, bn.running_var, bn.training,
+                                           eps=bn.eps, momentum=bn.momentum, want_pool=False)
+        if bn.training:
+            bn.num_batches_tracked += 1
+        ctx.save_for_backward(x5, ss, mean)
+        ctx.training = bn.training
+        return y.view(B, H, W, C_)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x5, ss, mean = ctx.saved_tensors
+        dx, dgamma, dbeta = ops.bn_backward(x5, dy.contiguous().view(x5.shape), None, None, mean, ss, relu_mask=False,
+                                            training=ctx.training)
+        return dx.view(dy.shape), dgamma, dbeta, None
 
 
 class _UNetBase(nn.Module):
@@ -16,7 +89,7 @@ class _UNetBase(nn.Module):
     ENC_BN = ()
     DEC = ()
 
-    def __init__(self, num_filters=32, channels_in=3, channels_out=3):
+    def __init__(self, num_filters=32, channels_in=3, channels_out=3, backend="hip"):
         super().__init__()
         nf = num_filters
         c_prev = channels_in
@@ -30,8 +103,35 @@ class _UNetBase(nn.Module):
             setattr(self, name, nn.BatchNorm2d(nf * mult))
         self.leaky_relu = nn.LeakyReLU(0.2)
         self.relu = nn.ReLU()
+        self.backend = backend
 
     def forward(self, input):
+        if self.backend == "stock":
+            return self._forward_stock(input)
+        if not input.is_cuda:
+            raise RuntimeError("UNet HIP path needs GPU tensors (no CPU fallback; backend='stock' runs stock torch ops)")
+        x = input.float().permute(0, 2, 3, 1).contiguous()                       # NCHW -> channels-last
+        skips = []
+        for i in range(1, len(self.ENC) + 1):
+            conv = getattr(self, f"conv{i}")
+            x = _ConvBlockFn.apply(x, None, conv.weight, conv.bias, 4, 2, ops.ACT_LEAKY if i > 1 else ops.ACT_NONE, False)
+            bn = self.ENC_BN[i - 1]
+            if bn is not None:
+                m = getattr(self, bn)
+                x = _BN2dFn.apply(x, m.weight, m.bias, m)
+            skips.append(x)
+        d0, d1 = skips.pop(), None                                                # innermost code: no skip of itself
+        for name, _, _, bn in self.DEC:
+            conv = getattr(self, name)
+            d = _ConvBlockFn.apply(d0, d1, conv.weight, conv.bias, 3, 1, ops.ACT_RELU, True)   # cat(d0, d1) never materialised
+            if bn is not None:
+                m = getattr(self, bn)
+                d0, d1 = _BN2dFn.apply(d, m.weight, m.bias, m), skips.pop()
+            else:
+                d0, d1 = d, None
+        return d0.permute(0, 3, 1, 2)                                             # (B,H,W,Cout) -> (B,Cout,H,W) view
+
+    def _forward_stock(self, input):
         skips = []
         x = input
         for i in range(1, len(self.ENC) + 1):

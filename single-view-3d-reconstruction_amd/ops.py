@@ -332,7 +332,7 @@ def linear_bwd_weight(dy, x, want_bias=True, mode=None):
     l = _lib.lib()
     dw = torch.empty(N, K, device=dy.device, dtype=torch.float32)
     db = torch.empty(N, device=dy.device, dtype=torch.float32) if want_bias else None
-    if (mode or BACKWARD_GEMM) == "bf16x3":
+    if (mode or BACKWARD_GEMM) == "bf16x3" and N % 4 == 0:
         ws = torch.empty(l.svr_linear_bwd_weight_bf16x3_workspace(M, N, K), device=dy.device, dtype=torch.uint8)
         check(l.svr_linear_bwd_weight_bf16x3(C.c_void_p(dy.data_ptr()), dy.stride(0), C.c_void_p(x.data_ptr()), x.stride(0),
                                              _p(dw), dw.stride(0), _p(db), M, N, K, _p(ws), _stream()),
@@ -621,3 +621,40 @@ def blur_axis_bwd(x, taps, gout, axis, want_gin=True, want_gtaps=True):
     check(_lib.lib().svr_blur_axis_bwd(_p(x), _p(taps), _p(gout), _p(gin), _p(gt), B, D0, D1, D2, axis, taps.numel(),
                                        _stream()), "blur_bwd")
     return gin, gt
+
+
+# ------------------------------------------------------------------------------------------
+# UNet 2-D convolution blocks (conv2d.hip): act -> [x2 upsample] -> conv on cat(src0, src1), channels-last
+# ------------------------------------------------------------------------------------------
+ACT_NONE, ACT_LEAKY, ACT_RELU = 0, 1, 2
+
+
+def _conv2d_desc(src0, src1, k, stride, act, up):
+    _f32(src0, src1)
+    B, H, W, C0 = src0.shape
+    d = _lib.Conv2dDesc(_p(src0), _p(src1), B, H, W, C0, src1.shape[3] if src1 is not None else 0, k, stride, act, int(up))
+    Hv, Wv = (2 * H, 2 * W) if up else (H, W)
+    Ho, Wo = (Hv + 2 - k) // stride + 1, (Wv + 2 - k) // stride + 1
+    return d, (Hv, Wv, Ho, Wo)
+
+
+def conv2d_im2col(src0, src1, k, stride, act, up):
+    """-> col (B*Ho*Wo, k*k*C) float32 and (Ho, Wo)."""
+    d, (Hv, Wv, Ho, Wo) = _conv2d_desc(src0, src1, k, stride, act, up)
+    C_ = d.C0 + d.C1
+    col = torch.empty(d.B * Ho * Wo, k * k * C_, device=src0.device, dtype=torch.float32)
+    check(_lib.lib().svr_conv2d_im2col(C.byref(d), _p(col), _stream()), "conv2d_im2col")
+    return col, (Ho, Wo)
+
+
+def conv2d_col2im(src0, src1, k, stride, act, up, dcol, need0=True, need1=True):
+    """dcol (B*Ho*Wo, k*k*C) -> gradients wrt src0 / src1 (None where not needed)."""
+    d, (Hv, Wv, Ho, Wo) = _conv2d_desc(src0, src1, k, stride, act, up)
+    C_ = d.C0 + d.C1
+    dvirt = torch.empty(d.B, Hv, Wv, C_, device=src0.device, dtype=torch.float32)
+    d0 = torch.empty_like(src0) if need0 else None
+    d1 = torch.empty_like(src1) if (src1 is not None and need1) else None
+    if d0 is None and d1 is None:
+        return None, None
+    check(_lib.lib().svr_conv2d_col2im(C.byref(d), _p(dcol), _p(dvirt), _p(d0), _p(d1), _stream()), "conv2d_col2im")
+    return d0, d1
