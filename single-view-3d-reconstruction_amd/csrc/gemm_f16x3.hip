@@ -228,9 +228,14 @@ extern "C" int svr_linear_fwd_f16x3(const float *X, int64_t ldx, const float *W,
   hipLaunchKernelGGL(split_w_kernel, dim3((unsigned)cdiv(N * (K / 2), 256)), dim3(256), 0, s, W, ldw, amax, p0, p1, N, K);
   const float *eb = epilogue == SVR_EPI_NONE ? nullptr : bias;
   const int relu = epilogue == SVR_EPI_BIAS_RELU ? 1 : 0;
-  dim3 grid(xcd_grid(cdiv(N, 128) * cdiv(M, TM)));
   // SCHED = 2 (one MFMA, a slice of the split, one LDS store, ...): 2.39 ms at 400 000 x 2592 x 256 against 2.49 for
   // the compiler's own order and 2.50 for iglp_opt(0)
+  if (N <= 64) {  // narrow outputs (the UNet's 32- and 64-channel layers): 128 x 64 tiles, two waves, half the wasted columns
+    dim3 grid(xcd_grid(cdiv(N, 64) * cdiv(M, TM)));
+    hipLaunchKernelGGL((linear_nt_h3_kernel<64, 0, 2>), grid, dim3(128), 0, s, X, ldx, p0, p1, amax, eb, Y, ldy, M, N, K, relu);
+    return launch_status("linear_fwd_f16x3");
+  }
+  dim3 grid(xcd_grid(cdiv(N, 128) * cdiv(M, TM)));
   hipLaunchKernelGGL((linear_nt_h3_kernel<128, 0, 2>), grid, dim3(256), 0, s, X, ldx, p0, p1, amax, eb, Y, ldy, M, N, K, relu);
   return launch_status("linear_fwd_f16x3");
 }

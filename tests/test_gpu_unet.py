@@ -87,3 +87,44 @@ def test_unet_matches_oracle(variant, B, H, W):
     with torch.no_grad():
         stock = m(rgb.cuda())
     assert G.rel_err(stock.cpu().numpy(), ref.detach().numpy()) < 1e-4
+
+
+def test_whole_step_hip_graph_replays_the_eager_step():
+    """svr_amd.graphs.GraphedStep: the captured step (forward, backward, side-stream sorts, Adam) replayed on new inputs
+    gives the eager step's loss and parameters (float atomics in the 128-channel scatter: 1e-5 / one Adam flip)."""
+    import copy
+    import svr_amd  # noqa: F401
+    from oracle import ifnet_oracle as O
+    from svr_amd.graphs import GraphedStep
+    from svr_amd.trainer import ImplicitRefinementTrainer
+
+    def make():
+        tr = ImplicitRefinementTrainer()
+        tr.ifnet.load_state_dict(O.name_seeded_state(128), strict=False)
+        tr = tr.cuda().train()
+        return tr, torch.optim.Adam(tr.ifnet.parameters(), lr=1e-4, capturable=True)
+
+    def batch(seed):
+        g = torch.Generator().manual_seed(seed)
+        return {"input": (torch.rand(2, 1, 32, 32, 32, generator=g) < 0.05).float().cuda(),
+                "points": (torch.rand(2, 3000, 3, generator=g) - 0.5).cuda(),
+                "occupancies": (torch.rand(2, 3000, generator=g) < 0.5).float().cuda()}
+
+    tr_e, opt_e = make()
+    tr_g, opt_g = make()
+    gs = GraphedStep(tr_g, opt_g, batch(0), warmup=1)           # one eager warm-up step (creates the optimizer state), then capture
+    tr_g.load_state_dict(copy.deepcopy(tr_e.state_dict()))     # undo the warm-up step: both trainers start from the same state
+    for st in opt_g.state.values():
+        for k, v in st.items():
+            if torch.is_tensor(v):
+                v.zero_()
+    for seed in (1, 2, 3):
+        b = batch(seed)
+        opt_e.zero_grad(set_to_none=True)
+        le = tr_e.training_step(b, 0)["loss"]
+        le.backward()
+        opt_e.step()
+        lg = gs.run(b)
+        assert abs(le.item() - lg.item()) < 1e-4 * abs(le.item()), (seed, le.item(), lg.item())
+    for (n, pe), (_, pg) in zip(tr_e.named_parameters(), tr_g.named_parameters()):
+        assert float((pe - pg).abs().max()) <= 6.1e-4, n             # three Adam steps of lr 1e-4: at most one sign flip each

@@ -20,6 +20,8 @@ ap.add_argument("--steps", type=int, default=5)
 ap.add_argument("--warmup", type=int, default=2)
 ap.add_argument("--batch", type=int, default=4)
 ap.add_argument("--points", type=int, default=50000)
+ap.add_argument("--graph", action="store_true", help="capture the whole step into a HIP graph (svr_amd.graphs.GraphedStep)")
+ap.add_argument("--unet-backend", default="hip", choices=["hip", "stock"])
 ap.add_argument("--miopen-benchmark", action="store_true", help="torch.backends.cudnn.benchmark: let MIOpen time its solvers")
 a = ap.parse_args()
 torch.backends.cudnn.benchmark = bool(a.miopen_benchmark)
@@ -33,7 +35,13 @@ tr = SceneNetTrainer(default_hparams(), dims=dims)
 tr.unet.load_state_dict(S.name_seeded_like(tr.unet.state_dict(), 1.0, "unet."), strict=False)
 tr.ifnet.load_state_dict(O.name_seeded_state(128), strict=False)
 tr = tr.cuda().train()
-opt = tr.configure_optimizers()[0][0]
+tr.unet.backend = a.unet_backend
+if a.graph:
+    h = tr.hparams
+    opt = torch.optim.Adam([{"params": tr.unet.parameters(), "lr": h.lr}, {"params": tr.project.parameters(), "lr": 10 * h.lr},
+                            {"params": tr.ifnet.parameters()}], lr=h.lr, capturable=True)
+else:
+    opt = tr.configure_optimizers()[0][0]
 batch = {"rgb": rgb.cuda(), "depthmap_target": target.cuda(), "points": pts.cuda(), "occupancies": occ.cuda()}
 
 
@@ -45,6 +53,12 @@ def step():
     return loss
 
 
+if a.graph:
+    from svr_amd.graphs import GraphedStep
+    gs = GraphedStep(tr, opt, batch, warmup=a.warmup)
+
+    def step():                      # noqa: F811
+        return gs.run(batch)
 for _ in range(a.warmup):
     step()
 torch.cuda.synchronize()
@@ -55,4 +69,5 @@ torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / a.steps
 print(json.dumps({"workload": f"BASELINE configs[4] per-GPU shard: UNet -> unproject -> project(128^3) -> IF-Net, batch {a.batch}, "
                               f"{a.points} points, fwd+bwd+Adam", "ms_per_step": dt * 1e3,
-                  "query_points_per_s": a.batch * a.points / dt, "loss": float(loss)}))
+                  "query_points_per_s": a.batch * a.points / dt, "loss": float(loss), "unet_backend": a.unet_backend,
+                  "hip_graph": bool(a.graph)}))
