@@ -284,7 +284,7 @@ def main():
             if i >= 1:
                 d = max(d // 2, 1)
         compulsory = a.batch * (vol_elems * 4 + a.points * 12 + a.points * 2583 * 4)
-        traffic, bwd_atomic_bytes, tsrc = None, None, None
+        traffic, bwd_atomic_bytes, bwd_hbm_bytes, tsrc = None, None, None, None
         tfile = os.path.join(ROOT, "profiles", "gather_traffic.json")
         if os.path.exists(tfile):
             try:
@@ -293,6 +293,7 @@ def main():
                         and t.get("dist", "uniform") == a.dist:
                     traffic = t.get("hbm_bytes_per_launch")
                     bwd_atomic_bytes = t.get("gather_bwd_write_bytes")
+                    bwd_hbm_bytes = t.get("gather_bwd_hbm_bytes")
                     tsrc = t.get("source")
             except Exception:
                 traffic = None
@@ -342,15 +343,19 @@ def main():
         kernels = []
         bwd_ms = kt.ms_per_launch("gather_bwd")
         if bwd_ms > 0:
-            rate = bwd_atomic_bytes / (bwd_ms * 1e-3) / 1e9 if bwd_atomic_bytes else None
-            kernels.append({"kernel": "gather_bwd (svr_gather_trilinear_bwd: the backward scatter)", "bound": "atomics",
-                            "unit": "GB/s", "peak": ATOMIC_PEAK_GBPS, "achieved": rate,
-                            "frac": (rate / ATOMIC_PEAK_GBPS) if rate else None, "ms_per_launch": bwd_ms,
-                            "traffic": bwd_atomic_bytes,
+            # compulsory traffic of the scatter: the gradient rows once + the gradient volumes (levels 1..5) once
+            bwd_comp = a.batch * (a.points * 2583 * 4 + (vol_elems - a.grid ** 3) * 4)
+            rate = bwd_hbm_bytes / (bwd_ms * 1e-3) / 1e9 if bwd_hbm_bytes else None
+            kernels.append({"kernel": "gather_bwd (svr_gather_trilinear_bwd: pull-form scatter of levels 1-3 + atomic scatter of "
+                                      "the 128-channel levels, 4 launches)", "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBPS,
+                            "achieved": rate, "frac": (rate / HBM_PEAK_GBPS) if rate else None, "ms_per_launch": bwd_ms,
+                            "traffic": bwd_hbm_bytes, "float_atomic_bytes": bwd_atomic_bytes,
                             "algorithmic_bytes_per_launch": npts * GATHER_BWD_BYTES_PER_POINT_F32,
-                            "note": "achieved = float-atomic bytes issued per launch (PMC WRITE_SIZE) / live time, against "
-                                    "the ~1.3 TB/s global-float-atomic rate; null when the scatter issues no atomics or "
-                                    "no counter file matches"})
+                            "compulsory_bytes_per_launch": bwd_comp,
+                            "compulsory_frac_of_hbm_peak": bwd_comp / (bwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                            "note": "achieved = HBM bytes of all scatter kernels (PMC FETCH_SIZE x2 + WRITE_SIZE) / live time; the "
+                                    "round-1 kernel sat at the ~1.3 TB/s float-atomic rate (7.0 GB of atomics), the atomics left are "
+                                    "float_atomic_bytes"})
         flops = {"fc_0": npts * 2 * 2583 * 256, "fc_1+fc_2": npts * 2 * 2 * 256 * 256}    # f32-equivalent, per pass
         for op, what in (("linear_fwd", "forward (f16x3)"), ("linear_bwd_data", "dX (bf16x3)"),
                          ("linear_bwd_weight", "dW + bias gradient (bf16x3)")):

@@ -120,7 +120,10 @@ int64_t svr_gather_pull_plan_workspace(int32_t B, int32_t N);
 int64_t svr_gather_pull_plan_workspace_cells(int32_t B, int32_t D, int32_t H, int32_t W);
 int svr_gather_pull_plan(const float *points, int32_t B, int32_t N, int32_t D, int32_t H, int32_t W, int32_t C,
                          int32_t col, int32_t row_stride, int32_t align_corners, float displacement,
-                         uint32_t *keys, void *recs, int32_t *heads, void *workspace, void *stream);
+                         uint32_t *keys, void *recs, int32_t *heads, int32_t *items /* optional (7*B*N): the sorted item
+                         ids = svr_level.item_order of the same level */, int32_t *stats /* optional, 2 device ints:
+                         [0] = longest serial walk of the pull kernel (items in one (row, x strip) range) */,
+                         void *workspace, void *stream);
 
 /* items[i] = id (b*N+n)*7 + j of the i-th (point, displacement) item in (sample, row-major base cell of ITS displaced
  * sample in a D x H x W volume) order; items that touch no voxel come last.  For svr_level.item_order.

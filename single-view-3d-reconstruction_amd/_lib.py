@@ -50,7 +50,7 @@ SIGNATURES = {
     "svr_gather_item_order": (C.c_int, [P, I32, I32, I32, I32, I32, I32, F32, P, P, P]),
     "svr_gather_pull_plan_workspace": (I64, [I32, I32]),
     "svr_gather_pull_plan_workspace_cells": (I64, [I32, I32, I32, I32]),
-    "svr_gather_pull_plan": (C.c_int, [P, I32, I32, I32, I32, I32, I32, I32, I32, I32, F32, P, P, P, P, P]),
+    "svr_gather_pull_plan": (C.c_int, [P, I32, I32, I32, I32, I32, I32, I32, I32, I32, F32, P, P, P, P, P, P, P]),
     "svr_gather_trilinear_fwd": (C.c_int, [C.POINTER(GatherDesc), P, P, P]),
     "svr_gather_trilinear_bwd": (C.c_int, [C.POINTER(GatherDesc), P, P, P, P]),
     "svr_gather_corner_indices": (C.c_int, [C.POINTER(GatherDesc), I32, P, P, P]),

@@ -853,6 +853,36 @@ __global__ __launch_bounds__(256) void gather_bwd_pull_kernel(float *__restrict_
     if (x0 + i < W) *reinterpret_cast<float4 *>(out + (int64_t)i * C) = acc[i];
 }
 
+// x-strip length of the pull kernel per channel count (measured at config 3: 0.55 / 0.38 / 0.57 ms; strips of 4 / 2 / 2:
+// 0.57 / 0.41 / 0.66, one voxel per thread: 1.29 / 0.60 / 0.66)
+__host__ __device__ inline int pull_xs(int C) { return C == 16 ? 8 : 4; }
+
+// The pull kernel's cost is set by its LONGEST serial walk: stats[0] = max number of items in one (row, x strip) range,
+// stats[1] = number of occupied cells.  Points clustered on surfaces give walks of hundreds of items (level 3 at config 3:
+// 3.5 ms against 0.49 ms for the atomic scatter over the item order); the caller reads the statistic of the PREVIOUS
+// step (no synchronisation) and picks the form per level.
+__global__ __launch_bounds__(256) void pull_stats_kernel(const int32_t *__restrict__ cs, int32_t *__restrict__ stats, int B, int D,
+                                                         int H, int W, int XS) {
+  const int nsx = (W + XS - 1) / XS;
+  const int64_t total = (int64_t)B * (D + 1) * (H + 1) * nsx, i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  int len = 0;
+  if (i < total) {
+    const int sx = (int)(i % nsx);
+    const int64_t row = i / nsx;  // (b, cz, cy)
+    const int x0 = sx * XS, ncell = min(XS, W - x0) + 1;
+    const int64_t k = row * (W + 1) + x0;
+    len = cs[k + ncell] - cs[k];
+  }
+  __shared__ int red[256];
+  red[threadIdx.x] = len;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] = max(red[threadIdx.x], red[threadIdx.x + o]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0 && red[0] > 0) atomicMax(stats, red[0]);
+}
+
 int64_t pull_cells(int B, int D, int H, int W) { return (int64_t)B * (D + 1) * (H + 1) * (W + 1); }
 int pull_key_bits(int64_t cells) {  // sentinel = cells must fit
   int nb = 1;
@@ -1048,7 +1078,8 @@ extern "C" int64_t svr_gather_pull_plan_workspace_cells(int32_t B, int32_t D, in
 
 extern "C" int svr_gather_pull_plan(const float *points, int32_t B, int32_t N, int32_t D, int32_t H, int32_t W, int32_t C,
                                     int32_t col, int32_t row_stride, int32_t align_corners, float displacement,
-                                    uint32_t *keys, void *recs, int32_t *heads, void *workspace, void *stream) {
+                                    uint32_t *keys, void *recs, int32_t *heads, int32_t *items_out, int32_t *stats,
+                                    void *workspace, void *stream) {
   const int64_t T = (int64_t)7 * B * N;
   SVR_CHECK(B >= 0 && N >= 0 && D > 0 && H > 0 && W > 0, SVR_E_BADSHAPE, "pull_plan: B=%d N=%d dims %dx%dx%d", B, N, D, H, W);
   SVR_CHECK(heads && workspace, SVR_E_BADARG, "pull_plan: null heads / workspace");
@@ -1071,7 +1102,7 @@ extern "C" int svr_gather_pull_plan(const float *points, int32_t B, int32_t N, i
     w += al256(T * 4);
     int32_t *vals_in = (int32_t *)w;
     w += al256(T * 4);
-    int32_t *items = (int32_t *)w;
+    int32_t *items = items_out ? items_out : (int32_t *)w;   // the sorted item ids double as svr_level.item_order
     w += al256(T * 4);
     const uint32_t sentinel = (uint32_t)cells;
     const int bits = pull_key_bits(cells);
@@ -1084,6 +1115,14 @@ extern "C" int svr_gather_pull_plan(const float *points, int32_t B, int32_t N, i
   }
   e = svr::scan_max_i32(scan_tmp, scan_bytes, ends, heads, cells + 1, s);
   SVR_CHECK(e == hipSuccess, (int)e, "pull_plan: scan failed: %s", hipGetErrorString(e));
+  if (stats) {
+    e = hipMemsetAsync(stats, 0, 2 * sizeof(int32_t), s);
+    SVR_CHECK(e == hipSuccess, (int)e, "pull_plan: memset failed: %s", hipGetErrorString(e));
+    const int XS = pull_xs(C);
+    const int64_t strips = (int64_t)B * (D + 1) * (H + 1) * svr::cdiv(W, XS);
+    hipLaunchKernelGGL(pull_stats_kernel, dim3((unsigned)svr::cdiv(strips, 256)), dim3(256), 0, s, (const int32_t *)heads, stats, B,
+                       D, H, W, XS);
+  }
   return svr::launch_status("pull_plan");
 }
 

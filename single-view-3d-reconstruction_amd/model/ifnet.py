@@ -53,20 +53,50 @@ def _get_side_stream(device):
     return _side_stream
 
 
-# Backward scatter form per level: "pull" = atomic-free pull form for the sparse levels (C <= 64; gather.hip), "atomic" =
-# float atomics with run-combining everywhere (the round-1 path, kept selectable for A/B measurements and tests).
-SCATTER_FORM = os.environ.get("SVR_SCATTER_FORM", "pull")
+# Backward scatter form per level (gather.hip):
+#   "auto"   (default) levels with C <= 64: atomic-free PULL form when the points are spread out (uniform-like: it is bound
+#            by its longest serial walk), float atomics over the joint ITEM order when they are clustered (surface samples:
+#            walks of thousands of items).  The statistic is the plan's `longest walk` of the PREVIOUS step, read without
+#            synchronisation (pinned copy + event); the first step of a shape uses the item order.  C = 128: item order.
+#   "pull"   force the pull form for C <= 64;  "items": item orders everywhere;  "atomic": the round-1 configuration
+#            (per-displacement point orders for levels with >= ~0.15 points per voxel).
+# Measured at config 3 (ms, levels 1/2/3): uniform points pull 0.56/0.38/0.57, items 1.07/0.99/0.45; points clustered on
+# planes pull 1.72/1.81/3.53, items 0.65/0.56/0.49 -- longest walk 13/24/94 against 1409/1669/3282.
+SCATTER_FORM = os.environ.get("SVR_SCATTER_FORM", "auto")
+PULL_MAX_WALK = 64
+_pull_hint = {}       # (level, dims, C, B, N) -> {"use": last decision, "slots": [(pinned int32[2], event), ...]}
+
+
+def _pull_decision(key, plan, side):
+    """Use the pull form?  Decided from the most recent plan statistic that has ARRIVED on the host (the host runs about a
+    step ahead of the GPU, so that is usually the one of two steps ago); this step's statistic is queued behind the plan
+    on the side stream into a free pinned slot.  No synchronisation, no blocking read."""
+    h = _pull_hint.setdefault(key, {"use": False, "slots": [], "seq": 0, "seen": -1})
+    if torch.cuda.is_current_stream_capturing():
+        return h["use"]            # inside a HIP-graph capture: no event queries / pinned allocations; the decision of the
+        #                            eager warm-up steps is baked into the graph
+    free = None
+    for slot in h["slots"]:
+        if slot["event"].query():
+            if slot["seq"] > h["seen"]:
+                h["seen"] = slot["seq"]
+                h["use"] = 0 < int(slot["host"][0]) <= PULL_MAX_WALK
+            free = slot
+    if free is None and len(h["slots"]) < 4:
+        free = {"host": torch.empty(2, dtype=torch.int32, pin_memory=True), "event": torch.cuda.Event(), "seq": -1}
+        h["slots"].append(free)
+    if free is not None:
+        free["host"].copy_(plan.stats, non_blocking=True)
+        free["seq"] = h["seq"]
+        free["event"].record(side)
+        h["seq"] += 1
+    return h["use"]
 
 
 def _level_orders_async(pts, D, H, W, n_levels, align, layout=None, disp=None):
     """Backward-scatter preparation that depends only on the points, computed on a side stream beside the encoder;
-    returns (orders per level, pull plans per level, ready event).
-
-    Levels with C <= 64 (the sparse ones) get a pull plan (svr_gather_pull_plan: all 7N items of a sample sorted by base
-    cell): they are scattered atomic-free and their gradient volume needs no zero fill.  The wide levels keep the float
-    atomics with run-combining: those with >= ~0.15 points per voxel get their own visiting order (points sharing a base
-    voxel become consecutive -> long register runs, few atomics); level l has the pyramid's resolution (D, H, W) >> (l-1)
-    for l >= 1 (level 0 is the input grid, one channel: neither)."""
+    returns (orders per level, pull plans per level, ready event).  Level l has the pyramid's resolution
+    (D, H, W) >> (l - 1) for l >= 1 (level 0 is the input grid, one channel: neither).  See SCATTER_FORM."""
     B, N = pts.shape[0], pts.shape[1]
     orders = [None] * n_levels
     plans = [None] * n_levels
@@ -75,17 +105,21 @@ def _level_orders_async(pts, D, H, W, n_levels, align, layout=None, disp=None):
     side.wait_stream(main)          # pts may have just been produced on the main stream
     pts.record_stream(side)         # ... and must not return to the main stream's pool while the side stream reads it
     launched = False
+    form = SCATTER_FORM
+    fits32 = layout is not None and N > 0 and 7 * B * N < 2 ** 31 and B * N * layout.row_stride < 2 ** 31
     with torch.cuda.stream(side):
         for l in range(1, n_levels):
             dhw = (max(D >> (l - 1), 1), max(H >> (l - 1), 1), max(W >> (l - 1), 1))
             C = layout.channels[l] if layout is not None else 0
-            if SCATTER_FORM == "pull" and layout is not None and ops.pull_plan_supported(B, N, dhw, C, layout.row_stride):
-                plans[l] = ops.pull_plan(pts, dhw, C, layout.col[l], layout.row_stride, disp, align)
-                plans[l].record_stream(main)
+            if form in ("auto", "pull") and fits32 and ops.pull_plan_supported(B, N, dhw, C, layout.row_stride):
+                plan = ops.pull_plan(pts, dhw, C, layout.col[l], layout.row_stride, disp, align)
+                plan.record_stream(main)
+                if form == "pull" or _pull_decision((l, dhw, C, B, N), plan, side):
+                    plans[l] = plan
+                else:
+                    orders[l] = plan.items            # the plan's sorted item ids are this level's item order
                 launched = True
-            elif SCATTER_FORM == "pull" and 7 * B * N < 2 ** 31 and layout is not None and \
-                    B * N * layout.row_stride < 2 ** 31 and N > 0:
-                # wide levels: float atomics with run-combining over the JOINT item order (all 7N items of a sample by cell)
+            elif form in ("auto", "pull", "items") and fits32:
                 orders[l] = ops.item_order(pts, dhw, disp, align)
                 orders[l].record_stream(main)
                 launched = True

@@ -88,13 +88,14 @@ class PullPlan:
     """Plan of the atomic-free pull-form backward scatter of one level (svr_gather_pull_plan): keeps the device
     arrays alive and hands the C struct to the gather descriptor."""
 
-    def __init__(self, keys, recs, heads, n_items):
-        self.keys, self.recs, self.heads = keys, recs, heads
+    def __init__(self, keys, recs, heads, n_items, items=None, stats=None):
+        self.keys, self.recs, self.heads, self.items, self.stats = keys, recs, heads, items, stats
         self.c = _lib.PullPlan(_p(keys), _p(recs), _p(heads), n_items)
 
     def record_stream(self, stream):
-        for t in (self.keys, self.recs, self.heads):
-            t.record_stream(stream)
+        for t in (self.keys, self.recs, self.heads, self.items, self.stats):
+            if t is not None:
+                t.record_stream(stream)
 
 
 def pull_plan_supported(B, N, dims, C, row_stride):
@@ -113,11 +114,14 @@ def pull_plan(points, dims, C, col, row_stride, displacement, align_corners=Fals
     keys = torch.empty(max(T, 1), device=dev, dtype=torch.int32)
     recs = torch.empty(max(T, 1), 4, device=dev, dtype=torch.int32)
     heads = torch.empty(cells + 1, device=dev, dtype=torch.int32)
+    items = torch.empty(max(T, 1), device=dev, dtype=torch.int32)       # sorted item ids: also this level's item order
+    stats = torch.zeros(2, device=dev, dtype=torch.int32)
     ws = torch.empty(l.svr_gather_pull_plan_workspace(B, N) + l.svr_gather_pull_plan_workspace_cells(B, *dims), device=dev,
                      dtype=torch.uint8)
     check(l.svr_gather_pull_plan(_p(points), B, N, dims[0], dims[1], dims[2], C, col, row_stride, int(align_corners),
-                                 displacement, _p(keys), _p(recs), _p(heads), _p(ws), _stream()), "gather_pull_plan")
-    return PullPlan(keys, recs, heads, T)
+                                 displacement, _p(keys), _p(recs), _p(heads), _p(items), _p(stats), _p(ws), _stream()),
+          "gather_pull_plan")
+    return PullPlan(keys, recs, heads, T, items, stats)
 
 
 def item_order(points, dims, displacement, align_corners=False):

@@ -77,13 +77,14 @@ def test_config3_gather_bit_exact_on_real_pyramid_and_scatter():
     rows_wide = ops.gather_fwd(levels, pg, layout, DISP, False, flags=_lib.GATHER_WIDE_OFFSETS)
     assert torch.equal(rows, rows_wide)
     del rows_wide, got
-    # ---- backward scatter at the same size, both forms: production (pull plans for levels 1-3, atomics + voxel orders
-    # for the 128-channel levels) and all-atomic (round-1 path); plan levels start from NaN: every voxel must be written
+    # ---- backward scatter at the same size in all three forms: pull plans for levels 1-3 (+ item orders for the
+    # 128-channel levels), item orders everywhere, per-displacement point orders (round-1 path); "auto" picks between the
+    # first two per level.  Plan levels start from NaN: every voxel must be written
     from svr_amd.model import ifnet as ifn
     g = torch.Generator().manual_seed(7)
     gfeat = torch.randn(B * N, layout.row_stride, generator=g).cuda()
     results = {}
-    for form in ("pull", "atomic"):
+    for form in ("pull", "items", "atomic"):
         saved_form, ifn.SCATTER_FORM = ifn.SCATTER_FORM, form
         try:
             orders, plans, ready = ifn._level_orders_async(pg, D, D, D, len(levels), False, layout, DISP)
@@ -92,15 +93,21 @@ def test_config3_gather_bit_exact_on_real_pyramid_and_scatter():
         if form == "pull":
             assert [p is not None for p in plans] == [False, True, True, True, False, False]
             assert orders[4].numel() == 7 * B * N and orders[5].numel() == 7 * B * N      # joint item orders
+        elif form == "items":
+            assert all(p is None for p in plans) and all(o.numel() == 7 * B * N for o in orders[1:])
         else:
-            assert all(p is None for p in plans) and sum(o is not None for o in orders) >= 3
+            assert all(p is None for p in plans) and sum(o is not None and o.numel() == B * N for o in orders) >= 3
         torch.cuda.current_stream().wait_event(ready)
         gvols = [torch.full_like(v, float("nan")) if plans[l] is not None else torch.zeros_like(v)
                  for l, v in enumerate(levels)]
         ops.gather_bwd(levels, gvols, pg, gfeat, layout, DISP, False, level_orders=orders, level_plans=plans)
         results[form] = gvols
     # the pull form is bit-reproducible (fixed summation order)
-    orders, plans, ready = ifn._level_orders_async(pg, D, D, D, len(levels), False, layout, DISP)
+    saved_form, ifn.SCATTER_FORM = ifn.SCATTER_FORM, "pull"
+    try:
+        orders, plans, ready = ifn._level_orders_async(pg, D, D, D, len(levels), False, layout, DISP)
+    finally:
+        ifn.SCATTER_FORM = saved_form
     torch.cuda.current_stream().wait_event(ready)
     again = [torch.empty_like(v) if plans[l] is not None else torch.zeros_like(v) for l, v in enumerate(levels)]
     ops.gather_bwd(levels, again, pg, gfeat, layout, DISP, False, level_orders=orders, level_plans=plans)

@@ -253,3 +253,32 @@ def test_no_grad_forward_does_not_prepare_the_backward():
     finally:
         ifn._level_orders_async = orig
     assert torch.equal(a, b.detach())
+
+
+def test_adaptive_scatter_form_follows_the_point_distribution():
+    """SCATTER_FORM "auto": the pull form for spread-out points, the item-order atomics for clustered ones, decided from
+    the previous step's `longest walk` statistic (no synchronisation: the first step of a shape uses the item order)."""
+    import svr_amd  # noqa: F401
+    from svr_amd import ops
+    from svr_amd.model import ifnet as ifn
+    assert ifn.SCATTER_FORM == "auto"
+    layout = ops.FeatureLayout([1, 16, 32, 64, 128, 128])
+    disp = float(np.float32(0.0722))
+    g = torch.Generator().manual_seed(3)
+    B, N, D = 2, 1500, 32
+    uniform = (torch.rand(B, N, 3, generator=g) - 0.5).cuda()
+    clustered = (torch.randn(B, N, 3, generator=g) * 0.002).clamp(-0.5, 0.5).cuda()     # everything inside a few voxels
+    ifn._pull_hint.clear()
+    for pts, expect_pull in ((uniform, True), (clustered, False)):
+        forms = []
+        for step in range(3):
+            orders, plans, ready = ifn._level_orders_async(pts, D, D, D, 6, False, layout, disp)
+            torch.cuda.synchronize()
+            forms.append([p is not None for p in plans[1:4]])
+            assert all(o is not None and o.numel() == 7 * B * N for o in orders[4:])
+            assert all((plans[l] is None) != (orders[l] is None) for l in (1, 2, 3))
+        if expect_pull:
+            assert forms[0] == [False, False, False] and forms[-1][0] and forms[-1][1], forms   # level 1/2: short walks
+        else:
+            assert forms[-1] == [False, False, False], forms
+    ifn._pull_hint.clear()

@@ -14,7 +14,11 @@ for i, c in enumerate(chans):
     vols.append(torch.randn(B, d, d, d, c, device=dev))
     if i >= 1:
         d //= 2
-pts = torch.rand(B, N, 3, device=dev) - 0.5
+if "--surface" in sys.argv:      # the clustered distribution of bench.py --dist surface (points around random planes)
+    from bench import synth_batch
+    pts = synth_batch(103, B, 8, N, dev, "surface")["points"].contiguous()
+else:
+    pts = torch.rand(B, N, 3, device=dev) - 0.5
 order = ops.morton_order(pts).long()
 pts_sorted = pts.reshape(-1, 3)[order].view(B, N, 3).contiguous()
 layout = ops.FeatureLayout(chans)
@@ -69,18 +73,24 @@ for l in (1, 2, 3):
     gv1 = [None] * 6
     gv1[l] = torch.empty_like(vols[l])
     tk = timeit(lambda: ops.gather_bwd(vols, gv1, p, gfeat, layout, disp, False, level_plans=pl))
-    print(f"  level {l} (C={chans[l]}, S={dims[0]}): plan {t:.3f} ms, pull scatter {tk:.3f} ms")
+    print(f"  level {l} (C={chans[l]}, S={dims[0]}): plan {t:.3f} ms, pull scatter {tk:.3f} ms, longest walk {int(plans[l].stats[0])}")
 lo = [None] * 6
-for l in (4, 5):
+for l in (1, 2, 3, 4, 5):
     dims = tuple(vols[l].shape[1:4])
     t = timeit(lambda: ops.item_order(p, dims, disp, False))
     lo[l] = ops.item_order(p, dims, disp, False)
+    if l <= 3:
+        plans_keep = plans[l]
     l1 = [None] * 6
     l1[l] = lo[l]
     gv1 = [None] * 6
     gv1[l] = torch.zeros_like(vols[l])
     tk = timeit(lambda: ops.gather_bwd(vols, gv1, p, gfeat, layout, disp, False, level_orders=l1))
     print(f"  level {l} (C={chans[l]}, S={dims[0]}): item order {t:.3f} ms, atomic scatter over items {tk:.3f} ms")
+lo45 = [None, None, None, None, lo[4], lo[5]]
 gv = [None] + [torch.empty_like(v) if plans[l] is not None else torch.zeros_like(v) for l, v in enumerate(vols) if l >= 1]
+gz = [None] + [torch.zeros_like(v) for v in vols[1:]]
+print("  all levels atomic over item orders: %.3f ms" % timeit(lambda: ops.gather_bwd(vols, gz, p, gfeat, layout, disp, False, level_orders=lo)))
+lo = lo45
 print("  levels 1-3 pull + 4-5 atomic (item orders): %.3f ms" % timeit(
     lambda: ops.gather_bwd(vols, gv, p, gfeat, layout, disp, False, level_orders=lo, level_plans=plans)))

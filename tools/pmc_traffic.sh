@@ -30,7 +30,8 @@ for f in glob.glob(f"{R}/gpurun_out/pmc_traffic_*/**/*counter_collection.csv", r
     rd = csv.DictReader(open(f))
     for r in rd:
         n = r["Kernel_Name"]
-        for key in ("gather_fwd_fused_kernel", "gather_bwd_fused_kernel", "gather_bwd_brick_kernel"):
+        for key in ("gather_fwd_fused_kernel", "gather_bwd_fused_kernel", "gather_bwd_pull_kernel<16", "gather_bwd_pull_kernel<32",
+                    "gather_bwd_pull_kernel<64"):
             if key in n:
                 agg[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
                 rows[r["Counter_Name"]].append(r)
@@ -51,12 +52,14 @@ if "FETCH_SIZE_KB" in f and "WRITE_SIZE_KB" in f:
     out["fetch_bytes_corrected_x2"] = 2 * fetch     # gfx950: FETCH_SIZE counts 128-B requests at 64 B (guide, section HBM)
     out["write_bytes"] = f["WRITE_SIZE_KB"] * 1024
     out["hbm_bytes_per_launch"] = 2 * fetch + f["WRITE_SIZE_KB"] * 1024
-bw = 0.0
-for k in ("gather_bwd_fused_kernel", "gather_bwd_brick_kernel"):
-    if "WRITE_SIZE_KB" in out.get(k, {}):
-        bw += out[k]["WRITE_SIZE_KB"] * 1024
+hbm = 0.0
+for k in list(out):
+    if k.startswith("gather_bwd_") and isinstance(out[k], dict) and "WRITE_SIZE_KB" in out[k] and "FETCH_SIZE_KB" in out[k]:
+        hbm += 2 * out[k]["FETCH_SIZE_KB"] * 1024 + out[k]["WRITE_SIZE_KB"] * 1024     # all kernels of the backward scatter
+if hbm:
+    out["gather_bwd_hbm_bytes"] = hbm
 if "gather_bwd_fused_kernel" in out:
-    out["gather_bwd_write_bytes"] = out["gather_bwd_fused_kernel"].get("WRITE_SIZE_KB", 0.0) * 1024   # = atomics issued
+    out["gather_bwd_write_bytes"] = out["gather_bwd_fused_kernel"].get("WRITE_SIZE_KB", 0.0) * 1024   # = float atomics issued
 out["source"] = (f"separate rocprofv3 --pmc passes (FETCH_SIZE; WRITE_SIZE) of `bench.py --steps 2 --warmup 1 {' '.join(extra)}` "
                  f"(tools/pmc_traffic.sh), averaged over the dispatches of each kernel; rows kept in profiles/{tag}_pmc_*_gather_rows.csv")
 json.dump(out, open(f"{R}/gpurun_out/gather_traffic.json", "w"), indent=1)
