@@ -396,12 +396,19 @@ __device__ __forceinline__ bf16x8 tr_frag(const uint32_t *plane, int byte0, int 
 
 // Both operands row-major through the transposing read: dY needs no pre-pass either (ATR); the bias gradient is the
 // column sum of the dY rows the K-tile-0 workgroups load anyway.
-__global__ __launch_bounds__(256) void linear_tn_x3_tr_kernel(const float *__restrict__ dY, int64_t lddy,
+// STAGES = 2: two LDS stages, ONE barrier per k-step -- the split + LDS stores of step k+1 sit in the same barrier
+// interval as the MFMAs of step k (the forward kernel's pipeline); STAGES = 1: store after the MFMAs, two barriers.
+// Measured at 400 000 x 256 x 2592 (round 2): 2.57 vs 2.59 ms -- and two register sets on top (loads two MFMA phases
+// ahead, 246 VGPRs) 2.57 vs 2.51, three sets spill (10.8 ms).  Neither the barrier count nor the load latency binds
+// this kernel; per k-step a wave issues ~110 VALU instructions for the bf16 splits and 16 ds_write_b64 against 24 MFMAs
+// (768 cycles), and the LDS pipe of a CU is ~80 % busy relative to its matrix pipes.  SVR_TN_STAGES=2 selects it.
+template <int STAGES>
+__global__ __launch_bounds__(256, 2) void linear_tn_x3_tr_kernel(const float *__restrict__ dY, int64_t lddy,
                                                               const float *__restrict__ X, int64_t ldx,
                                                               float *__restrict__ slab, float *__restrict__ dbpart,
                                                               int64_t M, int64_t N, int64_t K, int64_t rows_per_split,
                                                               int splits) {
-  __shared__ __attribute__((aligned(16))) uint32_t lds[4 * TR_XPLANE];  // dY hi, dY mid, X hi, X mid: [32 m][128 cols]
+  __shared__ __attribute__((aligned(16))) uint32_t lds[STAGES * 4 * TR_XPLANE];  // per stage: dY hi, dY mid, X hi, X mid: [32 m][128 cols]
   uint32_t *la = lds, *lx = lds + 2 * TR_XPLANE;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int wr = wave >> 1, wc = wave & 1, lh = lane >> 5;
@@ -426,7 +433,8 @@ __global__ __launch_bounds__(256) void linear_tn_x3_tr_kernel(const float *__res
   };
   const bool want_db = dbpart != nullptr && j0 == 0;
   float4 dbs = make_float4(0.f, 0.f, 0.f, 0.f);
-  auto lstore = [&](int64_t k0) {
+  auto lstore = [&](int64_t k0, int stage) {
+    uint32_t *la = lds + stage * 4 * TR_XPLANE, *lx = la + 2 * TR_XPLANE;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int r = (t >> 5) + 8 * i;
@@ -466,36 +474,52 @@ __global__ __launch_bounds__(256) void linear_tn_x3_tr_kernel(const float *__res
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  if (kbeg < kend) {
-    gload(kbeg);
-    lstore(kbeg);
-    __syncthreads();
-    for (int64_t k0 = kbeg; k0 < kend; k0 += XK) {
-      const bool more = k0 + XK < kend;
-      if (more) gload(k0 + XK);
-      __builtin_amdgcn_sched_barrier(0);
+  auto mma = [&](int stage) {
+    const uint32_t *la = lds + stage * 4 * TR_XPLANE, *lx = la + 2 * TR_XPLANE;
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        bf16x8 ah[2], am[2], bh[2], bm[2];
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 ah[2], am[2], bh[2], bm[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        ah[j] = tr_frag(la, aoff[ks][j][0], aoff[ks][j][1]);
+        am[j] = tr_frag(la + TR_XPLANE, aoff[ks][j][0], aoff[ks][j][1]);
+        bh[j] = tr_frag(lx, boff[ks][j][0], boff[ks][j][1]);
+        bm[j] = tr_frag(lx + TR_XPLANE, boff[ks][j][0], boff[ks][j][1]);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-          ah[j] = tr_frag(la, aoff[ks][j][0], aoff[ks][j][1]);
-          am[j] = tr_frag(la + TR_XPLANE, aoff[ks][j][0], aoff[ks][j][1]);
-          bh[j] = tr_frag(lx, boff[ks][j][0], boff[ks][j][1]);
-          bm[j] = tr_frag(lx + TR_XPLANE, boff[ks][j][0], boff[ks][j][1]);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[i], bh[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bm[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
         }
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[i], bh[j], acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bm[j], acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-          }
+    }
+  };
+  if (kbeg < kend) {
+    gload(kbeg);
+    lstore(kbeg, 0);
+    __syncthreads();
+    if constexpr (STAGES == 2) {
+      if (kbeg + XK < kend) gload(kbeg + XK);   // registers hold step k+1 while step k is multiplied
+      int st = 0;
+      for (int64_t k0 = kbeg; k0 < kend; k0 += XK, st ^= 1) {
+        const bool more = k0 + XK < kend;
+        if (more) lstore(k0 + XK, st ^ 1);       // stage st^1 was last read in step k-1: free since the barrier
+        if (k0 + 2 * XK < kend) gload(k0 + 2 * XK);
+        mma(st);
+        __syncthreads();
       }
-      __syncthreads();  // every wave has read its fragments
-      if (more) lstore(k0 + XK);
-      __syncthreads();
+    } else {
+      for (int64_t k0 = kbeg; k0 < kend; k0 += XK) {
+        const bool more = k0 + XK < kend;
+        if (more) gload(k0 + XK);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(0);
+        __syncthreads();  // every wave has read its fragments
+        if (more) lstore(k0 + XK, 0);
+        __syncthreads();
+      }
     }
   }
   float *out = slab + split * N * K;
@@ -663,8 +687,13 @@ extern "C" int svr_linear_bwd_weight_bf16x3(const float *dY, int64_t lddy, const
   dim3 grid(xcd_grid(cdiv(K, TN_TN) * cdiv(N, TN_TM) * splits));
   if (K % 4 == 0 && ldx % 4 == 0 && ((uintptr_t)X & 15) == 0 && N >= 4 && K >= 4) {
     // both operands row-major, transposing LDS reads: no pre-pass over dY; db from the K-tile-0 workgroups
-    hipLaunchKernelGGL(linear_tn_x3_tr_kernel, grid, dim3(256), 0, s, dY, lddy, X, ldx, slab, db ? dbpart : nullptr, M, N, K, rps,
-                       splits);
+    static const int tr_stages = getenv("SVR_TN_STAGES") ? atoi(getenv("SVR_TN_STAGES")) : 1;   // measurement switch
+    if (tr_stages == 2)
+      hipLaunchKernelGGL(linear_tn_x3_tr_kernel<2>, grid, dim3(256), 0, s, dY, lddy, X, ldx, slab, db ? dbpart : nullptr, M, N, K,
+                         rps, splits);
+    else
+      hipLaunchKernelGGL(linear_tn_x3_tr_kernel<1>, grid, dim3(256), 0, s, dY, lddy, X, ldx, slab, db ? dbpart : nullptr, M, N, K,
+                         rps, splits);
     hipLaunchKernelGGL(slab_reduce_x3_kernel, dim3((unsigned)cdiv(N * K, 256)), dim3(256), 0, s, slab, dW, N, K, lddw, splits);
     if (db) hipLaunchKernelGGL(dy_db_reduce_kernel, dim3((unsigned)N), dim3(256), 0, s, dbpart, db, N, (int64_t)splits);
     return launch_status("linear_bwd_weight_bf16x3");
