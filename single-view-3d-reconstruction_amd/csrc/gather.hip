@@ -487,13 +487,16 @@ __device__ __forceinline__ void gather_bwd_runs_body(const LevelArgs L, const fl
 // and the kernel is bound by reading the gradient rows (1.43 GB per 128-channel level).
 constexpr int kItemReps = 4;
 
-template <int C>
+// CPL = channels per lane: 2 for C >= 32 (lane l owns channels l and l + CW: half the lanes per item, so the geometry
+// broadcast, the run logic and the shuffles are paid once per two channels: levels 3/4/5 0.45/0.53/0.51 -> 0.36/0.43/0.38 ms
+// at config 3)
+template <int C, int CPL>
 __device__ __forceinline__ void gather_bwd_items_body(const LevelArgs L, const float *__restrict__ points,
                                                       const float *__restrict__ gfeat, int64_t T, int N, int row_stride,
                                                       float disp, int ac, int64_t witem, int64_t waves) {
-  constexpr int CW = C < 64 ? C : 64;  // channels per lane group
+  constexpr int CW = (C / CPL) < 64 ? (C / CPL) : 64;  // lanes per group; lane l owns channels l, l + CW, ...
   constexpr int G = 64 / CW;           // independent runs per wave
-  constexpr int CG = C / CW;           // channel groups per sample
+  constexpr int CG = C / (CW * CPL);   // channel groups per sample
   constexpr int PG = 2 * CW;           // items per repetition and run group
   if (witem >= waves) return;
   const int lane = threadIdx.x & 63;
@@ -503,21 +506,23 @@ __device__ __forceinline__ void gather_bwd_items_body(const LevelArgs L, const f
   const int64_t cperm = ((witem / CG) * 1000003LL) % nchunks;  // spread concurrently running waves over distant cells
   const int64_t base_i = (cperm * G + grp) * (int64_t)(PG * kItemReps);
   const int64_t vol = (int64_t)L.D * L.H * L.W;
-  float *gl = L.gvol + cg * CW + ch;
+  float *gl = L.gvol + cg * CW * CPL + ch;
 
-  float acc0[8], acc1[8];
+  float acc0[8 * CPL], acc1[8 * CPL];   // [corner][channel of the lane]
 #pragma unroll
-  for (int k = 0; k < 8; ++k) acc0[k] = acc1[k] = 0.f;
+  for (int k = 0; k < 8 * CPL; ++k) acc0[k] = acc1[k] = 0.f;
   int cur0 = -1, cur1 = -1, b0 = 0, b1 = 0;  // open runs: base-voxel key and sample
-  auto flush = [&](int cur, int bb, const float (&acc)[8], int skip) {
+  auto flush = [&](int cur, int bb, const float (&acc)[8 * CPL], int skip) {
     if (cur >= 0) {
       const int x0 = (cur & 1023) - 1, y0 = ((cur >> 10) & 1023) - 1, z0 = (cur >> 20) - 1;
       float *gb = gl + (size_t)bb * vol * C;
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
         const int z = z0 + (k >> 2), y = y0 + ((k >> 1) & 1), x = x0 + (k & 1);
-        if (!((skip >> k) & 1) && z >= 0 && z < L.D && y >= 0 && y < L.H && x >= 0 && x < L.W)
-          atomicAdd(gb + (((size_t)z * L.H + y) * L.W + x) * C, acc[k]);
+        if (!((skip >> k) & 1) && z >= 0 && z < L.D && y >= 0 && y < L.H && x >= 0 && x < L.W) {
+#pragma unroll
+          for (int p = 0; p < CPL; ++p) atomicAdd(gb + (((size_t)z * L.H + y) * L.W + x) * C + p * CW, acc[k * CPL + p]);
+        }
       }
     }
   };
@@ -525,12 +530,20 @@ __device__ __forceinline__ void gather_bwd_items_body(const LevelArgs L, const f
     int skip = 0;
     if (cur1 >= 0 && cur0 >= 0 && b0 == b1) {
       const int d = cur0 - cur1;
-      if (d == 1) { acc0[0] += acc1[1]; acc0[2] += acc1[3]; acc0[4] += acc1[5]; acc0[6] += acc1[7]; skip = 0xAA; }
-      else if (d == -1) { acc0[1] += acc1[0]; acc0[3] += acc1[2]; acc0[5] += acc1[4]; acc0[7] += acc1[6]; skip = 0x55; }
-      else if (d == 1024) { acc0[0] += acc1[2]; acc0[1] += acc1[3]; acc0[4] += acc1[6]; acc0[5] += acc1[7]; skip = 0xCC; }
-      else if (d == -1024) { acc0[2] += acc1[0]; acc0[3] += acc1[1]; acc0[6] += acc1[4]; acc0[7] += acc1[5]; skip = 0x33; }
-      else if (d == (1 << 20)) { acc0[0] += acc1[4]; acc0[1] += acc1[5]; acc0[2] += acc1[6]; acc0[3] += acc1[7]; skip = 0xF0; }
-      else if (d == -(1 << 20)) { acc0[4] += acc1[0]; acc0[5] += acc1[1]; acc0[6] += acc1[2]; acc0[7] += acc1[3]; skip = 0x0F; }
+      // acc0[to] += acc1[from] for the four corners of the shared face (compile-time indices: a lambda taking them as
+      // arguments made the accumulators dynamically indexed -> 144 B/lane of scratch)
+#define SVR_HAND(T0, F0, T1, F1, T2, F2, T3, F3)                                                     \
+  _Pragma("unroll") for (int p = 0; p < CPL; ++p) {                                                  \
+    acc0[T0 * CPL + p] += acc1[F0 * CPL + p]; acc0[T1 * CPL + p] += acc1[F1 * CPL + p];              \
+    acc0[T2 * CPL + p] += acc1[F2 * CPL + p]; acc0[T3 * CPL + p] += acc1[F3 * CPL + p];              \
+  }
+      if (d == 1) { SVR_HAND(0, 1, 2, 3, 4, 5, 6, 7) skip = 0xAA; }
+      else if (d == -1) { SVR_HAND(1, 0, 3, 2, 5, 4, 7, 6) skip = 0x55; }
+      else if (d == 1024) { SVR_HAND(0, 2, 1, 3, 4, 6, 5, 7) skip = 0xCC; }
+      else if (d == -1024) { SVR_HAND(2, 0, 3, 1, 6, 4, 7, 5) skip = 0x33; }
+      else if (d == (1 << 20)) { SVR_HAND(0, 4, 1, 5, 2, 6, 3, 7) skip = 0xF0; }
+      else if (d == -(1 << 20)) { SVR_HAND(4, 0, 5, 1, 6, 2, 7, 3) skip = 0x0F; }
+#undef SVR_HAND
     }
     flush(cur1, b1, acc1, skip);
   };
@@ -568,15 +581,16 @@ __device__ __forceinline__ void gather_bwd_items_body(const LevelArgs L, const f
     // arithmetic (two register sets): with the loads of a block issued and waited for in the same block every 4 items
     // paid a full memory latency and the 128-channel levels ran at 0.5 ms each instead of the 0.29 ms of their reads.
     constexpr int NB = 2 * CW / UNR;
-    auto issue = [&](float (&gq)[UNR], int blk) {
+    auto issue = [&](float (&gq)[UNR * CPL], int blk) {
 #pragma unroll
       for (int u = 0; u < UNR; ++u) {
         const int t = blk * UNR + u, s = t >= CW ? 1 : 0;
         const int go = __shfl(s ? goff[1] : goff[0], grp * CW + t - s * CW);
-        gq[u] = gfeat[(t < cnt ? go : 0) + cg * CW + ch];  // unconditional load, no branch
+#pragma unroll
+        for (int p = 0; p < CPL; ++p) gq[u * CPL + p] = gfeat[(t < cnt ? go : 0) + cg * CW * CPL + ch + p * CW];  // unconditional loads
       }
     };
-    auto process = [&](const float (&gq)[UNR], int blk) {
+    auto process = [&](const float (&gq)[UNR * CPL], int blk) {
 #pragma unroll
       for (int u = 0; u < UNR; ++u) {
         const int t = blk * UNR + u, s = t >= CW ? 1 : 0, src = grp * CW + t - s * CW;
@@ -589,13 +603,13 @@ __device__ __forceinline__ void gather_bwd_items_body(const LevelArgs L, const f
         if (kk != cur0 || bqu != b0) {
           if (kk == cur1 && bqu == b1) {  // hit on the older run: make it the most recent
 #pragma unroll
-            for (int k = 0; k < 8; ++k) { const float tt = acc0[k]; acc0[k] = acc1[k]; acc1[k] = tt; }
+            for (int k = 0; k < 8 * CPL; ++k) { const float tt = acc0[k]; acc0[k] = acc1[k]; acc1[k] = tt; }
             cur1 = cur0;
             b1 = b0;
           } else {                        // miss: retire the older run, age the recent one, open a new one
             retire();
 #pragma unroll
-            for (int k = 0; k < 8; ++k) { acc1[k] = acc0[k]; acc0[k] = 0.f; }
+            for (int k = 0; k < 8 * CPL; ++k) { acc1[k] = acc0[k]; acc0[k] = 0.f; }
             cur1 = cur0;
             b1 = b0;
           }
@@ -603,15 +617,19 @@ __device__ __forceinline__ void gather_bwd_items_body(const LevelArgs L, const f
           b0 = bqu;
         }
         const float wx1 = xq, wx0 = 1.f - wx1, wy1 = yq, wy0 = 1.f - wy1, wz1 = zq, wz0 = 1.f - wz1;
-        const float g = gq[u];
-        const float a00 = wy0 * wz0 * g, a10 = wy1 * wz0 * g, a01 = wy0 * wz1 * g, a11 = wy1 * wz1 * g;
-        acc0[0] += wx0 * a00; acc0[1] += wx1 * a00;
-        acc0[2] += wx0 * a10; acc0[3] += wx1 * a10;
-        acc0[4] += wx0 * a01; acc0[5] += wx1 * a01;
-        acc0[6] += wx0 * a11; acc0[7] += wx1 * a11;
+        const float w00 = wy0 * wz0, w10 = wy1 * wz0, w01 = wy0 * wz1, w11 = wy1 * wz1;
+#pragma unroll
+        for (int p = 0; p < CPL; ++p) {
+          const float g = gq[u * CPL + p];
+          const float a00 = w00 * g, a10 = w10 * g, a01 = w01 * g, a11 = w11 * g;
+          acc0[0 * CPL + p] += wx0 * a00; acc0[1 * CPL + p] += wx1 * a00;
+          acc0[2 * CPL + p] += wx0 * a10; acc0[3 * CPL + p] += wx1 * a10;
+          acc0[4 * CPL + p] += wx0 * a01; acc0[5 * CPL + p] += wx1 * a01;
+          acc0[6 * CPL + p] += wx0 * a11; acc0[7 * CPL + p] += wx1 * a11;
+        }
       }
     };
-    float gA[UNR], gB[UNR];
+    float gA[UNR * CPL], gB[UNR * CPL];
     issue(gA, 0);
     for (int blk = 0; blk < NB; blk += 2) {  // all conditions are uniform within the lane group
       if ((blk + 1) * UNR < cnt) issue(gB, blk + 1);
@@ -626,10 +644,14 @@ __device__ __forceinline__ void gather_bwd_items_body(const LevelArgs L, const f
   flush(cur0, b0, acc0, 0);
 }
 
+// channels per lane of the item scatter.  (4 for C >= 64: 186 VGPRs for the whole fused kernel, 2 waves/SIMD, all levels
+// slower: 2.81 vs 2.65 ms uniform, 2.19 vs 1.84 surface)
+__host__ __device__ inline int items_cpl(int C) { return C >= 32 ? 2 : 1; }
+
 __host__ __device__ inline int64_t bwd_items_waves(int C, int64_t T) {
-  const int cw = C < 64 ? C : 64;
+  const int cpl = items_cpl(C), cw = (C / cpl) < 64 ? (C / cpl) : 64;
   const int64_t per = (int64_t)(64 / cw) * 2 * cw * kItemReps;  // items per wave
-  return svr::cdiv(T, per) * (C / cw);
+  return svr::cdiv(T, per) * (C / (cw * cpl));
 }
 
 __host__ __device__ inline int64_t bwd_runs_waves(int C, int B, int N) {
@@ -650,10 +672,10 @@ __global__ __launch_bounds__(256) void gather_bwd_fused_kernel(FusedArgs A, cons
   if (L.items) {  // joint item order of this level
     const int64_t T = (int64_t)7 * B * N, iw = bwd_items_waves(L.C, T);
     switch (L.C) {
-      case 16: gather_bwd_items_body<16>(L, points, gfeat, T, N, row_stride, disp, ac, item, iw); break;
-      case 32: gather_bwd_items_body<32>(L, points, gfeat, T, N, row_stride, disp, ac, item, iw); break;
-      case 64: gather_bwd_items_body<64>(L, points, gfeat, T, N, row_stride, disp, ac, item, iw); break;
-      case 128: gather_bwd_items_body<128>(L, points, gfeat, T, N, row_stride, disp, ac, item, iw); break;
+      case 16: gather_bwd_items_body<16, 1>(L, points, gfeat, T, N, row_stride, disp, ac, item, iw); break;
+      case 32: gather_bwd_items_body<32, 2>(L, points, gfeat, T, N, row_stride, disp, ac, item, iw); break;
+      case 64: gather_bwd_items_body<64, 2>(L, points, gfeat, T, N, row_stride, disp, ac, item, iw); break;
+      case 128: gather_bwd_items_body<128, 2>(L, points, gfeat, T, N, row_stride, disp, ac, item, iw); break;
     }
     return;
   }
