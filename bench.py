@@ -346,8 +346,9 @@ def main():
             # compulsory traffic of the scatter: the gradient rows once + the gradient volumes (levels 1..5) once
             bwd_comp = a.batch * (a.points * 2583 * 4 + (vol_elems - a.grid ** 3) * 4)
             rate = bwd_hbm_bytes / (bwd_ms * 1e-3) / 1e9 if bwd_hbm_bytes else None
-            kernels.append({"kernel": "gather_bwd (svr_gather_trilinear_bwd: pull-form scatter of levels 1-3 + atomic scatter of "
-                                      "the 128-channel levels, 4 launches)", "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBPS,
+            kernels.append({"kernel": "gather_bwd (svr_gather_trilinear_bwd: per level the atomic-free pull form or the atomic "
+                                      "scatter over the joint item order, chosen from the point distribution)", "bound": "hbm",
+                            "unit": "GB/s", "peak": HBM_PEAK_GBPS,
                             "achieved": rate, "frac": (rate / HBM_PEAK_GBPS) if rate else None, "ms_per_launch": bwd_ms,
                             "traffic": bwd_hbm_bytes, "float_atomic_bytes": bwd_atomic_bytes,
                             "algorithmic_bytes_per_launch": npts * GATHER_BWD_BYTES_PER_POINT_F32,

@@ -15,6 +15,9 @@ import torch.nn.functional as F
 from .. import ops
 
 
+SMALL_M = 1024      # output pixels (times batch) up to which a layer's forward product runs as a split-reduction GEMM
+
+
 class _ConvBlockFn(torch.autograd.Function):
     """y (B,Ho,Wo,Cout) = conv_k( [upsample x2]( act( cat(src0, src1) ) ) ) + bias, channels-last."""
 
@@ -32,7 +35,16 @@ class _ConvBlockFn(torch.autograd.Function):
         else:
             b = bias.detach()
         wp = wp.contiguous()
-        y = ops.linear_fwd(col, wp, b, relu=False)
+        M, K = col.shape
+        if M <= SMALL_M and M % 4 == 0 and K >= 1024:
+            # deep layers (1x1 .. 16x16 pixels): Y = col W^T has a handful of output tiles and a reduction of 2 304 - 4 608,
+            # i.e. 8 workgroups walking ~290 k-steps (0.19 ms each, latency bound).  Y^T = (W^T)^T col^T is the shape of the
+            # weight-gradient GEMM: reduction over the ROWS, split over workgroups, slabs summed in a fixed order --
+            # the exact-f32 MFMA kernel (the FLOPs are negligible here).
+            yT, _ = ops.linear_bwd_weight(wp.t().contiguous(), col.t().contiguous(), want_bias=False, mode="f32")
+            y = yT.t() + b
+        else:
+            y = ops.linear_fwd(col, wp, b, relu=False)
         ctx.save_for_backward(src0, src1, wp)
         ctx.cfg = (k, stride, act, up, Cout, npad, tuple(weight.shape))
         B = src0.shape[0]
