@@ -118,6 +118,8 @@ class DeviceSampleLoader:
             if self.cache is not None:
                 self.cache[item] = s
         torch.cuda.current_stream().wait_event(s["_ready"])
+        if s.get("_staging") is not None and s["_ready"].query():
+            s["_staging"] = None                       # the copies have landed: give the pinned staging buffers back
         pts, occ, grid = [], [], []
         for sigma in SIGMAS:
             n = s[(sigma, "points")].shape[0]

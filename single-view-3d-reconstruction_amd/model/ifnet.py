@@ -64,7 +64,7 @@ def _get_side_stream(device):
 # planes pull 1.72/1.81/3.53, items 0.65/0.56/0.49 -- longest walk 13/24/94 against 1409/1669/3282.
 SCATTER_FORM = os.environ.get("SVR_SCATTER_FORM", "auto")
 PULL_MAX_WALK = 64
-_pull_hint = {}       # (level, dims, C, B, N) -> {"use": last decision, "slots": [(pinned int32[2], event), ...]}
+_pull_hint = {}       # (device, level, dims, C, B, N) -> {"use": last decision, "slots": [(pinned int32[2], event), ...]}
 
 
 def _pull_decision(key, plan, side):
@@ -114,7 +114,7 @@ def _level_orders_async(pts, D, H, W, n_levels, align, layout=None, disp=None):
             if form in ("auto", "pull") and fits32 and ops.pull_plan_supported(B, N, dhw, C, layout.row_stride):
                 plan = ops.pull_plan(pts, dhw, C, layout.col[l], layout.row_stride, disp, align)
                 plan.record_stream(main)
-                if form == "pull" or _pull_decision((l, dhw, C, B, N), plan, side):
+                if form == "pull" or _pull_decision((pts.device.index, l, dhw, C, B, N), plan, side):
                     plans[l] = plan
                 else:
                     orders[l] = plan.items            # the plan's sorted item ids are this level's item order

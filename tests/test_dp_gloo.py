@@ -147,3 +147,19 @@ def test_ifnet_parameter_bucket_two_ranks():
         assert aliased and reduced_ok, rank
     # broadcast made parameters AND BatchNorm buffers identical, and the identical reduced gradients keep them so
     assert (res[0][5] == res[1][5]).all()
+
+
+def test_scene_trainer_bucket_is_the_config5_allreduce_size():
+    """config 5 all-reduces UNet + project.sigma + IF-Net = 12 346 021 floats (49.4 MB) in ONE bucket."""
+    import svr_amd  # noqa: F401
+    from svr_amd.dp import GradBucket
+    from svr_amd.trainer import SceneNetTrainer, default_hparams
+    tr = SceneNetTrainer(default_hparams(miopen_benchmark=False))
+    b = GradBucket(list(tr.parameters()), device="cpu")
+    assert b.numel == 12346021 and b.flat.numel() * 4 == 49384084
+    n_unet = sum(p.numel() for p in tr.unet.parameters())
+    assert n_unet == 12346021 - 2550881 - 3          # 9 795 137 UNet parameters, 3 for project.sigma
+    off = 0
+    for p in tr.parameters():
+        assert p.grad.data_ptr() == b.flat.data_ptr() + 4 * off
+        off += p.numel()
