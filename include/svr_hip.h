@@ -129,7 +129,16 @@ int svr_gather_pull_plan(const float *points, int32_t B, int32_t N, int32_t D, i
  * sample in a D x H x W volume) order; items that touch no voxel come last.  For svr_level.item_order.
  * workspace: svr_gather_pull_plan_workspace(B, N) bytes.                                                     */
 int svr_gather_item_order(const float *points, int32_t B, int32_t N, int32_t D, int32_t H, int32_t W,
-                          int32_t align_corners, float displacement, int32_t *items, void *workspace, void *stream);
+                          int32_t align_corners, float displacement, int32_t with_j /* 1: order by (cell, j) */,
+                          int32_t *items, void *workspace, void *stream);
+/* Backward-only projection of a wide level (gather.hip, gather_bwd_proj_kernel): the scatter commutes with fc_0's
+ * product, so the level's 7*C feature columns need neither dX nor dW of the point MLP over all points:
+ *   dP[b][v][j][0:256] += w(item, v) * dh[(b*N+n)][0:256]   for every item (n, j) of svr_gather_item_order(with_j = 1)
+ * (dP: (B, D*H*W, 7, 256) float32, zero-initialised by the caller; dh: the gradient wrt fc_0's pre-activation, row
+ * stride lddh >= 256).  The caller finishes with two GEMMs over VOXELS: dvol = dP W0_l, dW0_l = dP^T vol.       */
+int svr_gather_project_bwd(const float *points, const float *dh, int64_t lddh, int32_t B, int32_t N, int32_t D, int32_t H,
+                           int32_t W, int32_t align_corners, float displacement, const int32_t *items, float *dP,
+                           void *stream);
 
 /* features[b*N+n][level.col + j*C + c] = trilinear sample j of channel c (zeros padding);
  * columns past the last level (up to row_stride) are written as zeros.                      */

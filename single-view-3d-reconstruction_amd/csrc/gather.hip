@@ -490,7 +490,10 @@ constexpr int kItemReps = 4;
 // CPL = channels per lane: 2 for C >= 32 (lane l owns channels l and l + CW: half the lanes per item, so the geometry
 // broadcast, the run logic and the shuffles are paid once per two channels: levels 3/4/5 0.45/0.53/0.51 -> 0.36/0.43/0.38 ms
 // at config 3)
-template <int C, int CPL>
+// PROJ (backward-only projection of a wide level, see gather_bwd_proj_kernel): the source row is the item's dh0 row (C = 256
+// values at pn * row_stride, the same for all 7 displacements), the destination is dP[b][voxel][j][C] and a run is one
+// (sample, displacement, cell): the displacement rides in the low 3 bits of the run's sample id.
+template <int C, int CPL, bool PROJ = false>
 __device__ __forceinline__ void gather_bwd_items_body(const LevelArgs L, const float *__restrict__ points,
                                                       const float *__restrict__ gfeat, int64_t T, int N, int row_stride,
                                                       float disp, int ac, int64_t witem, int64_t waves) {
@@ -515,13 +518,14 @@ __device__ __forceinline__ void gather_bwd_items_body(const LevelArgs L, const f
   auto flush = [&](int cur, int bb, const float (&acc)[8 * CPL], int skip) {
     if (cur >= 0) {
       const int x0 = (cur & 1023) - 1, y0 = ((cur >> 10) & 1023) - 1, z0 = (cur >> 20) - 1;
-      float *gb = gl + (size_t)bb * vol * C;
+      constexpr size_t VS = PROJ ? (size_t)7 * C : (size_t)C;   // floats per voxel of the destination
+      float *gb = PROJ ? gl + (size_t)(bb >> 3) * vol * VS + (size_t)(bb & 7) * C : gl + (size_t)bb * vol * C;
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
         const int z = z0 + (k >> 2), y = y0 + ((k >> 1) & 1), x = x0 + (k & 1);
         if (!((skip >> k) & 1) && z >= 0 && z < L.D && y >= 0 && y < L.H && x >= 0 && x < L.W) {
 #pragma unroll
-          for (int p = 0; p < CPL; ++p) atomicAdd(gb + (((size_t)z * L.H + y) * L.W + x) * C + p * CW, acc[k * CPL + p]);
+          for (int p = 0; p < CPL; ++p) atomicAdd(gb + (((size_t)z * L.H + y) * L.W + x) * VS + p * CW, acc[k * CPL + p]);
         }
       }
     }
@@ -547,7 +551,7 @@ __device__ __forceinline__ void gather_bwd_items_body(const LevelArgs L, const f
     }
     flush(cur1, b1, acc1, skip);
   };
-  constexpr int UNR = 4;
+  constexpr int UNR = PROJ ? 2 : 4;   // PROJ: 4 channels per lane -> 8 gradient registers per block already
   for (int rep = 0; rep < kItemReps; ++rep) {
     const int64_t i0 = base_i + (int64_t)rep * PG;
     const int cnt = (int)min((int64_t)PG, T - i0);  // items of this repetition (<= 0: none)
@@ -567,8 +571,8 @@ __device__ __forceinline__ void gather_bwd_items_body(const LevelArgs L, const f
         const float p3[3] = {points[(int64_t)pn * 3], points[(int64_t)pn * 3 + 1], points[(int64_t)pn * 3 + 2]};
         Corner c = sample_corner(p3, j, disp, L.D, L.H, L.W, ac);
         const int x0 = clamp_int(c.x0f), y0 = clamp_int(c.y0f), z0 = clamp_int(c.z0f);
-        goff[s] = pn * row_stride + L.col + j * C;
-        bb[s] = pn / N;
+        goff[s] = PROJ ? pn * row_stride : pn * row_stride + L.col + j * C;
+        bb[s] = PROJ ? (pn / N) * 8 + j : pn / N;
         if (z0 >= -1 && z0 < L.D && y0 >= -1 && y0 < L.H && x0 >= -1 && x0 < L.W) {
           key[s] = (x0 + 1) | ((y0 + 1) << 10) | ((z0 + 1) << 20);
           fx[s] = c.ix - c.x0f;
@@ -600,7 +604,17 @@ __device__ __forceinline__ void gather_bwd_items_body(const LevelArgs L, const f
                     zq = __shfl(s ? fz[1] : fz[0], src);
         const int kk = t < cnt ? kraw : -1;
         if (kk < 0) continue;  // item touches no voxel (or padding slot)
-        if (kk != cur0 || bqu != b0) {
+        if constexpr (PROJ) {
+          // items arrive sorted by (sample, cell, displacement): a run never comes back, one open run is enough (and the
+          // next run is another displacement of the same cell -- another slice of dP -- so there is nothing to hand over)
+          if (kk != cur0 || bqu != b0) {
+            flush(cur0, b0, acc0, 0);
+#pragma unroll
+            for (int k = 0; k < 8 * CPL; ++k) acc0[k] = 0.f;
+            cur0 = kk;
+            b0 = bqu;
+          }
+        } else if (kk != cur0 || bqu != b0) {
           if (kk == cur1 && bqu == b1) {  // hit on the older run: make it the most recent
 #pragma unroll
             for (int k = 0; k < 8 * CPL; ++k) { const float tt = acc0[k]; acc0[k] = acc1[k]; acc1[k] = tt; }
@@ -648,11 +662,27 @@ __device__ __forceinline__ void gather_bwd_items_body(const LevelArgs L, const f
 // slower: 2.81 vs 2.65 ms uniform, 2.19 vs 1.84 surface)
 __host__ __device__ inline int items_cpl(int C) { return C >= 32 ? 2 : 1; }
 
-__host__ __device__ inline int64_t bwd_items_waves(int C, int64_t T) {
-  const int cpl = items_cpl(C), cw = (C / cpl) < 64 ? (C / cpl) : 64;
+// Backward-only PROJECTION of a wide level l (C_l = 128).  Its feature columns are 35 % of fc_0's K each, and what the
+// scatter adds into the level's gradient volume is  dvol_l[v][c] = sum_items w * dfeat[p][(l,j,c)]  with
+// dfeat[p][(l,j,c)] = sum_n dh0[p][n] W0[n][(l,j,c)].  The sum over items commutes with the product by W0:
+//     dP_l[b][v][j][n] = sum_{items (p,j) -> v} w * dh0[p][n]        (this kernel: a scatter of 256-wide dh0 rows)
+//     dvol_l[v][c]     = sum_{j,n} dP_l[v][j][n] W0[n][(l,j,c)]      (a GEMM over voxels: 32 768 x 1792 x 128 at level 4)
+//     dW0[n][(l,j,c)]  = sum_v dP_l[v][j][n] vol_l[v][c]             (ditto)
+// so neither dX0 nor dW0 of the point MLP has to touch the level's 896 columns over 400 000 points (K 2592 -> 800 with
+// both 128-channel levels projected).  The forward pass is unchanged.  Items arrive sorted by (sample, cell, j).
+__global__ __launch_bounds__(256) void gather_bwd_proj_kernel(LevelArgs L, const float *__restrict__ points,
+                                                              const float *__restrict__ dh, int64_t T, int N, int lddh,
+                                                              float disp, int ac, int64_t waves) {
+  const int64_t witem = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
+  gather_bwd_items_body<256, 4, true>(L, points, dh, T, N, lddh, disp, ac, witem, waves);
+}
+
+__host__ __device__ inline int64_t bwd_items_waves_cpl(int C, int cpl, int64_t T) {
+  const int cw = (C / cpl) < 64 ? (C / cpl) : 64;
   const int64_t per = (int64_t)(64 / cw) * 2 * cw * kItemReps;  // items per wave
   return svr::cdiv(T, per) * (C / (cw * cpl));
 }
+__host__ __device__ inline int64_t bwd_items_waves(int C, int64_t T) { return bwd_items_waves_cpl(C, items_cpl(C), T); }
 
 __host__ __device__ inline int64_t bwd_runs_waves(int C, int B, int N) {
   int cw = C < 64 ? C : 64;
@@ -764,7 +794,7 @@ __device__ __forceinline__ bool pull_cell(const float *pt, int j, float disp, in
 
 __global__ __launch_bounds__(256) void pull_key_kernel(const float *__restrict__ points, uint32_t *__restrict__ keys,
                                                        int32_t *__restrict__ vals, int64_t total, int N, int D, int H,
-                                                       int W, float disp, int ac, uint32_t sentinel) {
+                                                       int W, float disp, int ac, uint32_t sentinel, int with_j) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;  // item = pn * 7 + j
   if (i >= total) return;
   const int64_t pn = i / 7;
@@ -773,7 +803,7 @@ __global__ __launch_bounds__(256) void pull_key_kernel(const float *__restrict__
   float fx, fy, fz;
   const float p3[3] = {points[pn * 3], points[pn * 3 + 1], points[pn * 3 + 2]};
   const bool ok = pull_cell(p3, j, disp, D, H, W, ac, (int)(pn / N), key, fx, fy, fz);
-  keys[i] = ok ? key : sentinel;
+  keys[i] = ok ? (with_j ? key * 8u + (uint32_t)j : key) : sentinel;   // with_j: (cell, displacement) order
   vals[i] = (int32_t)i;
 }
 
@@ -1129,7 +1159,7 @@ extern "C" int svr_gather_pull_plan(const float *points, int32_t B, int32_t N, i
     const uint32_t sentinel = (uint32_t)cells;
     const int bits = pull_key_bits(cells);
     hipLaunchKernelGGL(pull_key_kernel, dim3((unsigned)svr::cdiv(T, 256)), dim3(256), 0, s, points, keys_in, vals_in, T, N, D,
-                       H, W, displacement, align_corners, sentinel);
+                       H, W, displacement, align_corners, sentinel, 0);
     e = svr::sort_pairs_u32((void *)w, svr::sort_pairs_u32_temp_bytes(T, bits), keys_in, keys, vals_in, items, T, bits, s);
     SVR_CHECK(e == hipSuccess, (int)e, "pull_plan: radix sort failed: %s", hipGetErrorString(e));
     hipLaunchKernelGGL(pull_record_kernel, dim3((unsigned)svr::cdiv(T, 256)), dim3(256), 0, s, points, keys, items,
@@ -1149,15 +1179,15 @@ extern "C" int svr_gather_pull_plan(const float *points, int32_t B, int32_t N, i
 }
 
 extern "C" int svr_gather_item_order(const float *points, int32_t B, int32_t N, int32_t D, int32_t H, int32_t W,
-                                     int32_t align_corners, float displacement, int32_t *items, void *workspace,
-                                     void *stream) {
+                                     int32_t align_corners, float displacement, int32_t with_j, int32_t *items,
+                                     void *workspace, void *stream) {
   const int64_t T = (int64_t)7 * B * N;
   SVR_CHECK(B >= 0 && N >= 0 && D > 0 && H > 0 && W > 0, SVR_E_BADSHAPE, "item_order: B=%d N=%d dims %dx%dx%d", B, N, D, H, W);
   if (T == 0) return SVR_OK;
   SVR_CHECK(points && items && workspace, SVR_E_BADARG, "item_order: null pointer");
-  const int64_t cells = pull_cells(B, D, H, W);
-  SVR_CHECK(cells < (1LL << 31) - 1 && T < (1LL << 31), SVR_E_UNSUPPORTED, "item_order: %ld cells / %ld items exceed 32 bits",
-            (long)cells, (long)T);
+  const int64_t cells = pull_cells(B, D, H, W), nkeys = with_j ? cells * 8 : cells;
+  SVR_CHECK(nkeys < (1LL << 31) - 1 && T < (1LL << 31), SVR_E_UNSUPPORTED, "item_order: %ld keys / %ld items exceed 32 bits",
+            (long)nkeys, (long)T);
   hipStream_t s = (hipStream_t)stream;
   char *w = (char *)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
   uint32_t *keys_in = (uint32_t *)w;
@@ -1166,11 +1196,27 @@ extern "C" int svr_gather_item_order(const float *points, int32_t B, int32_t N, 
   w += al256(T * 4);
   uint32_t *keys_out = (uint32_t *)w;
   w += al256(T * 4);
-  const int bits = pull_key_bits(cells);
+  const int bits = pull_key_bits(nkeys);
   hipLaunchKernelGGL(pull_key_kernel, dim3((unsigned)svr::cdiv(T, 256)), dim3(256), 0, s, points, keys_in, vals_in, T, N, D, H,
-                     W, displacement, align_corners, (uint32_t)cells);
+                     W, displacement, align_corners, (uint32_t)nkeys, with_j ? 1 : 0);
   hipError_t e = svr::sort_pairs_u32((void *)w, svr::sort_pairs_u32_temp_bytes(T, bits), keys_in, keys_out, vals_in, items, T,
                                      bits, s);
   SVR_CHECK(e == hipSuccess, (int)e, "item_order: radix sort failed: %s", hipGetErrorString(e));
   return svr::launch_status("item_order");
+}
+
+extern "C" int svr_gather_project_bwd(const float *points, const float *dh, int64_t lddh, int32_t B, int32_t N, int32_t D,
+                                      int32_t H, int32_t W, int32_t align_corners, float displacement, const int32_t *items,
+                                      float *dP, void *stream) {
+  const int64_t T = (int64_t)7 * B * N;
+  if (T == 0) return SVR_OK;
+  SVR_CHECK(points && dh && items && dP, SVR_E_BADARG, "project_bwd: null pointer");
+  SVR_CHECK(D > 0 && H > 0 && W > 0 && D < 1022 && H < 1022 && W < 1022, SVR_E_BADSHAPE, "project_bwd: dims %dx%dx%d", D, H, W);
+  SVR_CHECK(T < (1LL << 31) && (int64_t)B * N * lddh < (1LL << 31) && lddh >= 256, SVR_E_UNSUPPORTED,
+            "project_bwd: needs 32-bit item / row offsets and rows of >= 256 floats");
+  LevelArgs L{nullptr, dP, 256, D, H, W, 0, nullptr, items};
+  const int64_t waves = bwd_items_waves_cpl(256, 4, T);
+  hipLaunchKernelGGL(gather_bwd_proj_kernel, dim3((unsigned)svr::cdiv(waves * 64, 256)), dim3(256), 0, (hipStream_t)stream, L, points,
+                     dh, T, N, (int)lddh, displacement, align_corners, waves);
+  return svr::launch_status("project_bwd");
 }

@@ -93,7 +93,7 @@ def _pull_decision(key, plan, side):
     return h["use"]
 
 
-def _level_orders_async(pts, D, H, W, n_levels, align, layout=None, disp=None):
+def _level_orders_async(pts, D, H, W, n_levels, align, layout=None, disp=None, proj_levels=()):
     """Backward-scatter preparation that depends only on the points, computed on a side stream beside the encoder;
     returns (orders per level, pull plans per level, ready event).  Level l has the pyramid's resolution
     (D, H, W) >> (l - 1) for l >= 1 (level 0 is the input grid, one channel: neither).  See SCATTER_FORM."""
@@ -111,7 +111,11 @@ def _level_orders_async(pts, D, H, W, n_levels, align, layout=None, disp=None):
         for l in range(1, n_levels):
             dhw = (max(D >> (l - 1), 1), max(H >> (l - 1), 1), max(W >> (l - 1), 1))
             C = layout.channels[l] if layout is not None else 0
-            if form in ("auto", "pull") and fits32 and ops.pull_plan_supported(B, N, dhw, C, layout.row_stride):
+            if l in proj_levels:                     # backward-only projection: items by (cell, displacement)
+                orders[l] = ops.item_order(pts, dhw, disp, align, with_j=True)
+                orders[l].record_stream(main)
+                launched = True
+            elif form in ("auto", "pull") and fits32 and ops.pull_plan_supported(B, N, dhw, C, layout.row_stride):
                 plan = ops.pull_plan(pts, dhw, C, layout.col[l], layout.row_stride, disp, align)
                 plan.record_stream(main)
                 if form == "pull" or _pull_decision((pts.device.index, l, dhw, C, B, N), plan, side):
@@ -134,6 +138,32 @@ def _level_orders_async(pts, D, H, W, n_levels, align, layout=None, disp=None):
     return orders, plans, ready
 
 
+# Backward-only projection of the 128-channel levels (gather.hip, gather_bwd_proj_kernel): their 2 x 896 feature columns
+# are 69 % of fc_0's K, and the scatter commutes with fc_0's product -- dh0 rows (256 wide) are scattered into
+# dP_l[b][voxel][j][256], and two GEMMs over VOXELS (32 768 rows at level 4) give the level's gradient volume and its slice
+# of dW0.  dX0 / dW0 of the point MLP then only cover the remaining 800 columns.  The forward pass is unchanged.
+PROJECT_WIDE_LEVELS = os.environ.get("SVR_NO_PROJECTION") is None
+
+
+class _ProjLink:
+    """Hand-over between the point MLP's backward (which runs first and produces dh0) and the encoder's."""
+
+    def __init__(self, levels, layout):
+        self.levels = tuple(levels)
+        self.layout = layout
+        self.dh0 = None
+        self.need_level0 = False
+        cols = sorted((layout.col[l], layout.col[l] + 7 * layout.channels[l]) for l in levels)
+        keep, start = [], 0
+        for a, b in cols:                              # complement of the projected column ranges inside the row
+            if a > start:
+                keep.append((start, a))
+            start = b
+        if start < layout.row_stride:
+            keep.append((start, layout.row_stride))
+        self.keep = keep                                # column segments dX0 / dW0 still have to cover
+
+
 class _EncoderGatherFn(torch.autograd.Function):
     """x, points, encoder parameters -> feature rows (B*N, FS) in the internal column layout.
 
@@ -142,7 +172,7 @@ class _EncoderGatherFn(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, ext, grad_mode, x, points, *params):
+    def forward(ctx, ext, grad_mode, link, w0p, x, points, *params):
         B = x.shape[0]
         D, H, W = x.shape[2:]
         training = ext.training
@@ -158,9 +188,13 @@ class _EncoderGatherFn(torch.autograd.Function):
         # only when a backward can follow: grad mode of the CALLER (it is always off inside Function.forward, and
         # needs_input_grad ignores no_grad) and something that requires grad
         will_backward = bool(grad_mode) and any(ctx.needs_input_grad)
+        ctx.link = link if (will_backward and link is not None) else None
+        if ctx.link is not None:
+            ctx.link.need_level0 = bool(ctx.needs_input_grad[4])
         if will_backward and x.is_cuda:
             ctx.level_orders, ctx.level_plans, ctx.orders_ready = _level_orders_async(
-                pts, D, H, W, nst + 1, ext._align, ext._layout, ext._disp)
+                pts, D, H, W, nst + 1, ext._align, ext._layout, ext._disp,
+                proj_levels=ctx.link.levels if ctx.link is not None else ())
         for si, (convs, bn) in enumerate(ext._stages):
             acts = []
             cur = inp
@@ -188,13 +222,17 @@ class _EncoderGatherFn(torch.autograd.Function):
             main, side = torch.cuda.current_stream(), _get_side_stream(x.device)
             with torch.cuda.stream(side):
                 # (levels with a pull plan are written by plain stores: no zero fill)
-                ctx.gvols = [None] + [torch.empty_like(v) if ctx.level_plans[l] is not None else torch.zeros_like(v)
+                proj = ctx.link.levels if ctx.link is not None else ()
+                ctx.gvols = [None] + [None if l in proj else
+                                      (torch.empty_like(v) if ctx.level_plans[l] is not None else torch.zeros_like(v))
                                       for l, v in enumerate(levels) if l >= 1]
                 for g in ctx.gvols[1:]:
-                    g.record_stream(main)
+                    if g is not None:
+                        g.record_stream(main)
                 ctx.orders_ready = torch.cuda.Event()
                 ctx.orders_ready.record(side)
         ctx.ext, ctx.saved, ctx.levels, ctx.pts = ext, saved, levels, pts
+        ctx.w0p = w0p.detach() if ctx.link is not None else None
         ctx.x_shape = x.shape
         ctx.training = training
         return feat
@@ -202,12 +240,16 @@ class _EncoderGatherFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gfeat):
         ext, saved, levels, pts = ctx.ext, ctx.saved, ctx.levels, ctx.pts
-        need_x, need_pts = ctx.needs_input_grad[2], ctx.needs_input_grad[3]
+        need_x, need_pts = ctx.needs_input_grad[4], ctx.needs_input_grad[5]
         gfeat = gfeat.contiguous()
+        link = ctx.link
+        proj = link.levels if link is not None else ()
+        if link is not None and link.dh0 is None:
+            raise RuntimeError("IF-Net HIP path: the projected backward needs dh0 from the point MLP's backward")
         level_orders, level_plans = ctx.level_orders, ctx.level_plans
         if level_orders is None:
             level_orders, level_plans, ready = _level_orders_async(pts, *levels[0].shape[1:4], len(levels), ext._align,
-                                                                   ext._layout, ext._disp)
+                                                                   ext._layout, ext._disp, proj_levels=proj)
         else:
             ready = ctx.orders_ready
         if ops.GATHER_FLAGS & ops._lib.GATHER_DETERMINISTIC:      # the serial test scatter accumulates into zeros
@@ -218,12 +260,30 @@ class _EncoderGatherFn(torch.autograd.Function):
             ctx.gvols = None
         else:
             gvols = [torch.zeros_like(levels[0]) if need_x else None] + \
-                    [torch.empty_like(v) if level_plans[l] is not None else torch.zeros_like(v)
+                    [None if l in proj else (torch.empty_like(v) if level_plans[l] is not None else torch.zeros_like(v))
                      for l, v in enumerate(levels) if l >= 1]
         if ready is not None:
             torch.cuda.current_stream().wait_event(ready)
         gpts = ops.gather_bwd(levels, gvols, pts, gfeat, ext._layout, ext._disp, ext._align, want_gpoints=need_pts,
-                              level_orders=level_orders, level_plans=level_plans)
+                              level_orders=[None if l in proj else o for l, o in enumerate(level_orders)],
+                              level_plans=level_plans)
+        dw0p = None
+        if proj:
+            # projected levels: dP = scatter of the dh0 rows, then two GEMMs over voxels (see gather_bwd_proj_kernel)
+            lay, w0p, dh0 = ext._layout, ctx.w0p, link.dh0
+            link.dh0 = None
+            dw0p = torch.zeros_like(w0p)
+            for l in proj:
+                v = levels[l]
+                B_, Dl, Hl, Wl, Cl = v.shape
+                c0 = lay.col[l]
+                dP = ops.gather_project_bwd(pts, dh0, (Dl, Hl, Wl), level_orders[l], ext._disp, ext._align)
+                dP2 = dP.view(B_ * Dl * Hl * Wl, 7 * 256)
+                wl = w0p[:, c0:c0 + 7 * Cl].reshape(256, 7, Cl).permute(1, 0, 2).reshape(7 * 256, Cl).contiguous()   # rows (j, n)
+                gvols[l] = ops.linear_bwd_data(dP2, wl).view(v.shape)
+                dwl, _ = ops.linear_bwd_weight(dP2, v.view(-1, Cl), want_bias=False)                                # (7*256, Cl)
+                dw0p[:, c0:c0 + 7 * Cl] = dwl.view(7, 256, Cl).permute(1, 0, 2).reshape(256, 7 * Cl)
+                del dP, dP2
         grads = {}
         dpooled = None
         gx = None
@@ -248,7 +308,7 @@ class _EncoderGatherFn(torch.autograd.Function):
                     gx = ops.conv3d_k3_bwd_data(dout, conv.weight.detach())
         if need_x:
             gx = (gx + gvols[0]).view(ctx.x_shape)
-        out = [None, None, gx, gpts]
+        out = [None, None, None, dw0p, gx, gpts]
         for p in ext._param_list:
             out.append(grads.get(p))
         return tuple(out)
@@ -259,7 +319,7 @@ class _PointMLPFn(torch.autograd.Function):
     (reference model/ifnet.py:55-59) on the f32 matrix cores."""
 
     @staticmethod
-    def forward(ctx, feat, row_map, w0p, b0, w1, b1, w2, b2, wo, bo):
+    def forward(ctx, feat, row_map, w0p, b0, w1, b1, w2, b2, wo, bo, link=None):
         """row_map (int32, or None): feature row m belongs to caller point row_map[m]; the logits are
         scattered back to the caller's order by the fc_out kernel."""
         h0 = ops.linear_fwd(feat, w0p, b0, relu=True)
@@ -268,6 +328,7 @@ class _PointMLPFn(torch.autograd.Function):
         logits = ops.fc_out_fwd(h2, wo, bo, row_map)
         ctx.save_for_backward(feat, w0p, w1, w2, wo, h0, h1, h2)
         ctx.row_map = row_map
+        ctx.link = link
         return logits
 
     @staticmethod
@@ -278,9 +339,25 @@ class _PointMLPFn(torch.autograd.Function):
         dh1 = ops.linear_bwd_data(dh2, w2, mask=h1)
         dw1, db1 = ops.linear_bwd_weight(dh1, h0)
         dh0 = ops.linear_bwd_data(dh1, w1, mask=h0)
-        dw0, db0 = ops.linear_bwd_weight(dh0, feat)
-        dfeat = ops.linear_bwd_data(dh0, w0p) if ctx.needs_input_grad[0] else None
-        return dfeat, None, dw0, db0, dw1, db1, dw2, db2, dwo, dbo
+        link = ctx.link
+        if link is None:
+            dw0, db0 = ops.linear_bwd_weight(dh0, feat)
+            dfeat = ops.linear_bwd_data(dh0, w0p) if ctx.needs_input_grad[0] else None
+            return dfeat, None, dw0, db0, dw1, db1, dw2, db2, dwo, dbo, None
+        # projected wide levels: dX0 / dW0 only over the columns that stay (K 2592 -> 800); the encoder's backward gets dh0
+        link.dh0 = dh0
+        dw0 = torch.zeros_like(w0p)
+        dfeat = torch.empty_like(feat)            # the projected levels' columns are never read
+        db0 = None
+        lvl0 = link.layout.col[0]
+        for a, b in link.keep:
+            dws, dbs = ops.linear_bwd_weight(dh0, feat[:, a:b], want_bias=db0 is None)
+            dw0[:, a:b] = dws
+            db0 = dbs if db0 is None else db0
+            if a <= lvl0 < b and not link.need_level0 and a == lvl0:
+                continue                          # raw-grid columns: their gradient is only needed for d(loss)/d(input)
+            ops.linear_bwd_data(dh0, w0p[:, a:b], out=dfeat[:, a:b])
+        return dfeat, None, dw0, db0, dw1, db1, dw2, db2, dwo, dbo, None
 
 
 class _ExtractorBase(nn.Module):
@@ -326,11 +403,13 @@ class _ExtractorBase(nn.Module):
     def feature_rows_from_levels(self, levels, points, order=None):
         return ops.gather_fwd(levels, points.float().contiguous(), self._layout, self._disp, self._align, order=order)
 
-    def feature_rows(self, x, points):
-        """(B*N, FS) rows in the internal column layout (what the point MLP consumes)."""
+    def feature_rows(self, x, points, link=None, w0p=None):
+        """(B*N, FS) rows in the internal column layout (what the point MLP consumes).  link / w0p: the backward-only
+        projection of the wide levels (IFNet.forward wires it; the encoder's backward then also returns its share of
+        fc_0's weight gradient)."""
         if not x.is_cuda:
             raise RuntimeError("IF-Net HIP path needs GPU tensors (no CPU fallback)")
-        return _EncoderGatherFn.apply(self, torch.is_grad_enabled(), x.float(), points.float(), *self._param_list)
+        return _EncoderGatherFn.apply(self, torch.is_grad_enabled(), link, w0p, x.float(), points.float(), *self._param_list)
 
     def forward(self, x, points):
         """Reference layout (B, sumC, 1, 7, N) -- model/ifnet.py:197; used by API-compat callers."""
@@ -470,11 +549,22 @@ class IFNet(nn.Module):
                 points = points.reshape(B * N, 3)[row_map.long()].view(B, N, 3)
             else:
                 points = sorted_pts
-        rows = self.ifnet_feature_extractor.feature_rows(x, points)
-        logits = _PointMLPFn.apply(rows, row_map, self._fc0_internal(), self.fc_0.bias,
+        ext = self.ifnet_feature_extractor
+        w0p = self._fc0_internal()
+        link = None
+        if (PROJECT_WIDE_LEVELS and torch.is_grad_enabled() and w0p.requires_grad and not points.requires_grad
+                and self.fc_0.out_channels == 256 and SCATTER_FORM != "atomic"
+                and not (ops.GATHER_FLAGS & ops._lib.GATHER_DETERMINISTIC)):
+            D, H, W = x.shape[2:]
+            wide = [l for l, c in enumerate(ext._layout.channels) if c == 128 and
+                    ops.project_bwd_supported(B, N, (max(D >> (l - 1), 1), max(H >> (l - 1), 1), max(W >> (l - 1), 1)))]
+            if wide and B * N * ext._layout.row_stride < 2 ** 31:
+                link = _ProjLink(wide, ext._layout)
+        rows = ext.feature_rows(x, points, link, w0p if link is not None else None)
+        logits = _PointMLPFn.apply(rows, row_map, w0p, self.fc_0.bias,
                                    self.fc_1.weight.squeeze(2), self.fc_1.bias,
                                    self.fc_2.weight.squeeze(2), self.fc_2.bias,
-                                   self.fc_out.weight.reshape(-1), self.fc_out.bias)
+                                   self.fc_out.weight.reshape(-1), self.fc_out.bias, link)
         return logits.view(B, N)
 
 

@@ -124,16 +124,34 @@ def pull_plan(points, dims, C, col, row_stride, displacement, align_corners=Fals
     return PullPlan(keys, recs, heads, T, items, stats)
 
 
-def item_order(points, dims, displacement, align_corners=False):
-    """(7*B*N,) int32 item ids pn*7+j sorted by (sample, base cell of the displaced sample) in a volume of `dims`."""
+def item_order(points, dims, displacement, align_corners=False, with_j=False):
+    """(7*B*N,) int32 item ids pn*7+j sorted by (sample, base cell of the displaced sample[, displacement j]) in a
+    volume of `dims`."""
     _f32(points)
     B, N, _ = points.shape
     l = _lib.lib()
     items = torch.empty(max(7 * B * N, 1), device=points.device, dtype=torch.int32)
     ws = torch.empty(l.svr_gather_pull_plan_workspace(B, N), device=points.device, dtype=torch.uint8)
-    check(l.svr_gather_item_order(_p(points), B, N, dims[0], dims[1], dims[2], int(align_corners), displacement, _p(items),
-                                  _p(ws), _stream()), "gather_item_order")
+    check(l.svr_gather_item_order(_p(points), B, N, dims[0], dims[1], dims[2], int(align_corners), displacement, int(with_j),
+                                  _p(items), _p(ws), _stream()), "gather_item_order")
     return items
+
+
+def project_bwd_supported(B, N, dims, lddh=256):
+    cells = B * (dims[0] + 1) * (dims[1] + 1) * (dims[2] + 1)
+    return N > 0 and 8 * cells < 2 ** 31 - 1 and 7 * B * N < 2 ** 31 and B * N * lddh < 2 ** 31 and max(dims) < 1022
+
+
+def gather_project_bwd(points, dh, dims, items, displacement, align_corners=False):
+    """dP (B, D*H*W, 7, 256) = scatter of the 256-wide rows of dh (B*N, >= 256) with the trilinear weights of every
+    (point, displacement) item; `items` = item_order(..., with_j=True)."""
+    _f32(points, dh)
+    B, N, _ = points.shape
+    assert dh.shape[0] == B * N and dh.shape[1] >= 256 and dh.stride(1) == 1
+    dP = torch.zeros(B, dims[0] * dims[1] * dims[2], 7, 256, device=points.device, dtype=torch.float32)
+    check(_lib.lib().svr_gather_project_bwd(_p(points), C.c_void_p(dh.data_ptr()), dh.stride(0), B, N, dims[0], dims[1], dims[2],
+                                            int(align_corners), displacement, _p(items), _p(dP), _stream()), "gather_project_bwd")
+    return dP
 
 
 def make_gather_desc(vols, gvols, layout, B, N, displacement, align_corners, order=None, level_orders=None, flags=0,

@@ -282,3 +282,46 @@ def test_adaptive_scatter_form_follows_the_point_distribution():
         else:
             assert forms[-1] == [False, False, False], forms
     ifn._pull_hint.clear()
+
+
+def test_projected_backward_equals_the_plain_backward():
+    """Backward-only projection of the 128-channel levels (scatter of dh0 rows + two GEMMs over voxels instead of dX0 / dW0
+    over their 1 792 feature columns): same forward bits, every gradient tensor equal to the plain path's within the
+    bf16x3 product noise (2e-4 in L2 norm; exact-f32 backward switches: 1e-5) -- including d(loss)/d(input grid)."""
+    import svr_amd  # noqa: F401
+    from svr_amd import ops
+    from svr_amd.model import ifnet as ifn
+    from svr_amd.trainer import bce_with_logits_sum_mean
+    z = G.load("ifnet_b3")
+    net_res, x, pts, occ = G.ifnet_inputs(z)
+    switches = ("BACKWARD_GEMM", "BACKWARD_CONV", "BACKWARD_CONV_WEIGHT")
+    saved = {k: getattr(ops, k) for k in switches}
+
+    def run(project):
+        prev, ifn.PROJECT_WIDE_LEVELS = ifn.PROJECT_WIDE_LEVELS, project
+        try:
+            m = _model(net_res, z)
+            xg = (x * 0.7 + 0.1).cuda().requires_grad_(True)
+            logits = m(xg, pts.cuda())
+            bce_with_logits_sum_mean(logits, occ.cuda()).backward()
+        finally:
+            ifn.PROJECT_WIDE_LEVELS = prev
+        grads = {n: p.grad.detach().cpu().double() for n, p in m.named_parameters()}
+        grads["input"] = xg.grad.detach().cpu().double()
+        return logits.detach().cpu(), grads
+
+    assert ifn.PROJECT_WIDE_LEVELS
+    for mode, tol in (("production", 2e-4), ("f32", 5e-5)):    # f32: float-atomic order only (1.5e-5 seen on a bias)
+        try:
+            if mode == "f32":
+                for k in switches:
+                    setattr(ops, k, "f32")
+            la, ga = run(True)
+            lb, gb = run(False)
+        finally:
+            for k, v in saved.items():
+                setattr(ops, k, v)
+        assert torch.equal(la, lb)                                    # the forward is untouched
+        for name in ga:
+            d = float((ga[name] - gb[name]).norm() / gb[name].norm().clamp_min(1e-30))
+            assert d < tol, (mode, name, d)

@@ -479,3 +479,27 @@ def test_conv_in_fused_bn_statistics():
         mean, var = flat.mean(0), flat.var(0, unbiased=False)
         assert G.rel_err(stats[:Co].cpu().numpy(), mean.cpu().numpy()) < 1e-6
         assert G.rel_err(stats[Co:].cpu().numpy(), var.cpu().numpy()) < 1e-6
+
+
+@pytest.mark.parametrize("dims,align,N,B", [((8, 8, 8), False, 3000, 2), ((5, 6, 4), True, 500, 3), ((16, 16, 16), False, 700, 1)])
+def test_projected_scatter_of_dh_rows(dims, align, N, B):
+    """svr_gather_project_bwd: dP[b][v][j][0:256] = sum over the items (n, j) that touch voxel v of w * dh[b*N+n][0:256]
+    -- the adjoint of sampling a 256-channel volume at the j-th displaced positions -- against CPU autograd of
+    grid_sample (1e-5), for the (cell, j) item order."""
+    ops = _ops()
+    net_res = 32 if align else 128
+    disp = float(np.float32(O.ARCH[net_res]["disp"]))
+    g = torch.Generator().manual_seed(61 + N)
+    pts = (torch.rand(B, N, 3, generator=g) - 0.5) * 1.2
+    dh = torch.randn(B * N, 256, generator=g)
+    items = ops.item_order(pts.cuda(), dims, disp, align, with_j=True)
+    ic = items.cpu().long()
+    assert sorted(ic.tolist()) == list(range(7 * B * N))
+    dP = ops.gather_project_bwd(pts.cuda(), dh.cuda(), dims, items, disp, align).cpu()          # (B, V, 7, 256)
+    grid = O.sample_grid(pts, net_res)                                                          # (B,1,7,N,3)
+    for j in range(7):
+        vol = torch.zeros(B, 256, *dims, requires_grad=True)
+        out = F.grid_sample(vol, grid[:, :, j:j + 1], mode="bilinear", padding_mode="zeros", align_corners=align)  # (B,256,1,1,N)
+        (out[:, :, 0, 0].permute(0, 2, 1) * dh.view(B, N, 256)).sum().backward()
+        ref = vol.grad.permute(0, 2, 3, 4, 1).reshape(B, -1, 256)
+        assert G.rel_err(dP[:, :, j].numpy(), ref.numpy()) < 1e-5, j
