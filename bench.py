@@ -209,13 +209,12 @@ def main():
         dp.step(batch)
     # live HIP-event timing of the roofline kernels on the stream they run on (installed after the warm-up)
     kt = _KernelTimer(torch)
-    def layer(x, w, *r, **k):          # fc_0 (K = 2592 feature columns) apart from the two 256 x 256 layers
-        return "fc_0" if max(w.shape[-1], x.shape[-1]) > 1024 else "fc_1+fc_2"
-
     restore = [(ops, "gather_fwd", kt.wrap(ops, "gather_fwd")), (ops, "gather_bwd", kt.wrap(ops, "gather_bwd")),
-               (ops, "linear_fwd", kt.wrap(ops, "linear_fwd", lambda *r, **k: "linear_fwd:" + layer(*r, **k))),
-               (ops, "linear_bwd_data", kt.wrap(ops, "linear_bwd_data", lambda *r, **k: "linear_bwd_data:" + layer(*r, **k))),
-               (ops, "linear_bwd_weight", kt.wrap(ops, "linear_bwd_weight", lambda *r, **k: "linear_bwd_weight:" + layer(*r, **k)))]
+               (ops, "gather_project_bwd", kt.wrap(ops, "gather_project_bwd")),
+               # linear_fwd(x (M,K), w (N,K)); linear_bwd_data(dy (M,N), w (N,K)); linear_bwd_weight(dy (M,N), x (M,K))
+               (ops, "linear_fwd", kt.wrap(ops, "linear_fwd", lambda x, w, *r, **k: f"linear_fwd:{x.shape[0]}x{w.shape[0]}x{x.shape[-1]}")),
+               (ops, "linear_bwd_data", kt.wrap(ops, "linear_bwd_data", lambda dy, w, *r, **k: f"linear_bwd_data:{dy.shape[0]}x{dy.shape[-1]}x{w.shape[-1]}")),
+               (ops, "linear_bwd_weight", kt.wrap(ops, "linear_bwd_weight", lambda dy, x, *r, **k: f"linear_bwd_weight:{dy.shape[0]}x{dy.shape[-1]}x{x.shape[-1]}"))]
     sync()
     t0 = time.perf_counter()
     for _ in range(a.steps):
@@ -357,16 +356,34 @@ def main():
                             "note": "achieved = HBM bytes of all scatter kernels (PMC FETCH_SIZE x2 + WRITE_SIZE) / live time; the "
                                     "round-1 kernel sat at the ~1.3 TB/s float-atomic rate (7.0 GB of atomics), the atomics left are "
                                     "float_atomic_bytes"})
-        flops = {"fc_0": npts * 2 * 2583 * 256, "fc_1+fc_2": npts * 2 * 2 * 256 * 256}    # f32-equivalent, per pass
-        for op, what in (("linear_fwd", "forward (f16x3)"), ("linear_bwd_data", "dX (bf16x3)"),
-                         ("linear_bwd_weight", "dW + bias gradient (bf16x3)")):
-            for lay, fl in flops.items():
-                ms = kt.ms_per_step(f"{op}:{lay}", a.steps)
-                if ms > 0:
-                    tf = fl * SPLIT_PRODUCTS / (ms * 1e-3) / 1e12
-                    kernels.append({"kernel": f"point-MLP GEMM {lay} {what}", "bound": "mfma", "unit": "TFLOP/s",
-                                    "peak": MFMA_F16_PEAK_TFLOPS, "achieved": tf, "frac": tf / MFMA_F16_PEAK_TFLOPS,
-                                    "ms_per_step": ms, "f32_equivalent_TFLOPs": tf / SPLIT_PRODUCTS})
+        proj_ms = kt.ms_per_step("gather_project_bwd", a.steps)
+        if proj_ms > 0:
+            kernels.append({"kernel": "gather_bwd_proj_kernel (svr_gather_project_bwd: fc_0's input gradient rows scattered into "
+                                      "(voxel, displacement, 256) slabs for the two 128-channel levels, incl. the slab memset)",
+                            "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBPS, "achieved": None, "frac": None,
+                            "ms_per_step": proj_ms, "launches_per_step": len(kt.ev["gather_project_bwd"]) / a.steps,
+                            "algorithmic_bytes_per_step": 2 * npts * 7 * (256 * 4 + 12), "traffic": None,
+                            "note": "reads each dh0 row (1 KB) once per displacement and level; float atomics only at run ends"})
+        # every GEMM of the step, keyed by the shape it was CALLED with: point-MLP layers have M = points, the two
+        # projected levels add voxel-row GEMMs (M = B*S^3); fc_0's backward runs over the kept column segments only
+        what = {"linear_fwd": "forward (f16x3)", "linear_bwd_data": "dX (bf16x3)", "linear_bwd_weight": "dW + bias gradient (bf16x3)"}
+        mlp_ms = 0.0
+        for key in sorted(kt.ev):
+            op, _, shape = key.partition(":")
+            if op not in what:
+                continue
+            M, N, K = (int(v) for v in shape.split("x"))
+            calls = len(kt.ev[key]) / a.steps
+            ms = kt.ms_per_step(key, a.steps)
+            if ms <= 0:
+                continue
+            mlp_ms += ms
+            tf = 2.0 * M * N * K * calls * SPLIT_PRODUCTS / (ms * 1e-3) / 1e12
+            who = "point-MLP" if M == npts else "projected-level voxel"
+            kernels.append({"kernel": f"{who} GEMM {what[op]} M={M} N={N} K={K}", "bound": "mfma", "unit": "TFLOP/s",
+                            "peak": MFMA_F16_PEAK_TFLOPS, "achieved": tf, "frac": tf / MFMA_F16_PEAK_TFLOPS,
+                            "ms_per_step": ms, "calls_per_step": calls, "f32_equivalent_TFLOPs": tf / SPLIT_PRODUCTS})
+        res["mlp_gemm_ms_per_step"] = mlp_ms
         res["roofline_kernels_note"] = ("MFMA entries: achieved counts the 3 split products actually issued on the f16 / bf16 "
                                         "matrix cores (the f32-equivalent rate is a third of it); ms = HIP-event brackets "
                                         "around the C-ABI calls on their stream, summed per step")
