@@ -14,11 +14,12 @@ Workload at every N: BASELINE.json configs[2] per GPU (128^3 grid, 50 000 points
 per-GPU shard x 8 GPUs) -> weak scaling.  Inputs are resident in HBM before the timed region.  Prints ONE JSON line
 on rank 0.
 
-Roofline block: `roofline` is the north-star kernel, the fused forward gather.  `achieved` /
-`frac` are HBM bytes actually moved per launch (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/gather_traffic.json,
-measured on this workload) / the live HIP-event time of the launch, against the 8 TB/s HBM peak -- a fraction <= 1.
-The ALGORITHMIC rate (93 000 B per query point, most of it cache hits) is reported beside it against the
-L2 roof, and the compulsory-traffic fraction too.  `roofline_kernels` carries the other dominant kernels: the
+Roofline block: `roofline` is the north-star kernel -- the forward gather, since round 2 FUSED with
+fc_0 (gather_fc0.hip: the feature rows never reach HBM).  `achieved` / `frac` are HBM bytes actually moved per launch
+(rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/gather_traffic.json, measured on this workload) / the live
+HIP-event time of the launch, against the 8 TB/s HBM peak -- a fraction <= 1.  The ALGORITHMIC rate (the
+corner reads, most of them cache hits) is reported beside it against the L2 roof, the compulsory-traffic fraction and
+the kernel's MFMA fraction too (it is bound by the vector-L1 rate of the corner reads, neither by HBM nor by MFMA).  `roofline_kernels` carries the other dominant kernels: the
 backward scatter against the float-atomic roof and the point-MLP GEMMs against the f16 / bf16 MFMA peak.
 """
 import argparse
@@ -32,6 +33,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 GATHER_BYTES_PER_POINT_F32 = 93000          # 7*8*369 reads + 7*369 writes + 12 B coords
+FUSED_BYTES_PER_POINT_F32 = 7 * 8 * 369 * 4 + 12 + 256 * 4   # fused gather+fc_0: corner reads + coords + the h0 row
+FUSED_KEPT_COLUMNS = 800                    # training: rows of the levels that are not projected (+ padding) are kept
+FC0_K_FUSED = 2592                          # fused reduction length (2583 feature columns + 9 zero columns)
 GATHER_BYTES_PER_POINT_BF16 = 46506         # the same elements at 2 B + 12 B coords
 GATHER_BWD_BYTES_PER_POINT_F32 = 92776      # 2583 gradient reads + 12 B + 7*8*368 RMW (counted once)
 HBM_PEAK_GBPS = 8000.0                       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured achievable)
@@ -211,6 +215,7 @@ def main():
     kt = _KernelTimer(torch)
     restore = [(ops, "gather_fwd", kt.wrap(ops, "gather_fwd")), (ops, "gather_bwd", kt.wrap(ops, "gather_bwd")),
                (ops, "gather_project_bwd", kt.wrap(ops, "gather_project_bwd")),
+               (ops, "gather_fc0_fwd", kt.wrap(ops, "gather_fc0_fwd")),
                # linear_fwd(x (M,K), w (N,K)); linear_bwd_data(dy (M,N), w (N,K)); linear_bwd_weight(dy (M,N), x (M,K))
                (ops, "linear_fwd", kt.wrap(ops, "linear_fwd", lambda x, w, *r, **k: f"linear_fwd:{x.shape[0]}x{w.shape[0]}x{x.shape[-1]}")),
                (ops, "linear_bwd_data", kt.wrap(ops, "linear_bwd_data", lambda dy, w, *r, **k: f"linear_bwd_data:{dy.shape[0]}x{dy.shape[-1]}x{w.shape[-1]}")),
@@ -249,7 +254,9 @@ def main():
         net = trainer.ifnet
         pts = batch["points"]
         with torch.no_grad():
-            for name, storage, gname in (("f32", "f32", "gather_fwd"), ("bf16", "bf16", "gather_fwd_bf16")):
+            from svr_amd.model import ifnet as _ifn
+            f32_gather = "gather_fc0_fwd" if _ifn.FUSE_FC0 else "gather_fwd"
+            for name, storage, gname in (("f32", "f32", f32_gather), ("bf16", "bf16", "gather_fwd_bf16")):
                 levels = net.encode(batch["input"], storage)
                 z = net.query(levels, pts, spatial_sort=True)
                 kq = _KernelTimer(torch)
@@ -261,7 +268,7 @@ def main():
                 torch.cuda.synchronize()
                 ms = (time.perf_counter() - t1) / a.steps * 1e3
                 setattr(ops, gname, orig)
-                query[name] = {"ms": ms, "gather_ms": kq.ms_per_launch(gname), "logits": z.float()}
+                query[name] = {"ms": ms, "gather_ms": kq.ms_per_launch(gname), "gather_op": gname, "logits": z.float()}
                 del levels
         zf, zb = query["f32"].pop("logits"), query["bf16"].pop("logits")
         query["bf16"]["logits_rel_dev_vs_f32_storage"] = float((zb - zf).abs().max() / zf.abs().max())
@@ -272,17 +279,22 @@ def main():
         npts = a.batch * a.points
         pts_per_step = world * npts
         value = pts_per_step * a.steps / dt
-        gather_ms = kt.ms_per_launch("gather_fwd")
-        alg_bytes = npts * GATHER_BYTES_PER_POINT_F32
+        fused = kt.ms_per_launch("gather_fc0_fwd") > 0
+        gkey = "gather_fc0_fwd" if fused else "gather_fwd"
+        gather_ms = kt.ms_per_launch(gkey)
+        kept = FUSED_KEPT_COLUMNS * 4 if fused else 0
+        alg_bytes = npts * ((FUSED_BYTES_PER_POINT_F32 + kept) if fused else GATHER_BYTES_PER_POINT_F32)
         alg_rate = alg_bytes / (gather_ms * 1e-3) / 1e9 if gather_ms > 0 else None
-        # compulsory traffic: every pyramid volume once + coordinates + the feature rows once
+        # compulsory traffic: every pyramid volume once + coordinates + what the kernel must write once
+        # (unfused: the feature rows; fused: the h0 rows and the kept columns)
         chans, d = [1, 16, 32, 64, 128, 128], a.grid
         vol_elems = 0
         for i, c in enumerate(chans):
             vol_elems += c * d ** 3
             if i >= 1:
                 d = max(d // 2, 1)
-        compulsory = a.batch * (vol_elems * 4 + a.points * 12 + a.points * 2583 * 4)
+        out_bytes = (256 * 4 + kept) if fused else 2583 * 4
+        compulsory = a.batch * (vol_elems * 4 + a.points * 12 + a.points * out_bytes)
         traffic, bwd_atomic_bytes, bwd_hbm_bytes, tsrc = None, None, None, None
         tfile = os.path.join(ROOT, "profiles", "gather_traffic.json")
         if os.path.exists(tfile):
@@ -290,7 +302,7 @@ def main():
                 t = json.load(open(tfile))
                 if t.get("batch") == a.batch and t.get("grid") == a.grid and t.get("points") == a.points \
                         and t.get("dist", "uniform") == a.dist:
-                    traffic = t.get("hbm_bytes_per_launch")
+                    traffic = t.get("fused_hbm_bytes_per_launch") if fused else t.get("hbm_bytes_per_launch")
                     bwd_atomic_bytes = t.get("gather_bwd_write_bytes")
                     bwd_hbm_bytes = t.get("gather_bwd_hbm_bytes")
                     tsrc = t.get("source")
@@ -298,7 +310,9 @@ def main():
                 traffic = None
         hbm_rate = traffic / (gather_ms * 1e-3) / 1e9 if (traffic and gather_ms > 0) else None
         roofline = {
-            "kernel": "gather_fwd_fused_kernel (svr_gather_trilinear_fwd, all 6 levels in one launch)",
+            "kernel": ("gather_fc0_kernel (svr_gather_fc0_fwd: all 6 levels gathered slab by slab into LDS and multiplied into "
+                       "fc_0's 128 x 256 tile, one launch)") if fused else
+                      "gather_fwd_fused_kernel (svr_gather_trilinear_fwd, all 6 levels in one launch)",
             "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBPS,
             # HBM bytes actually moved (PMC) / live kernel time: a true fraction of the 8 TB/s roof (null without counters)
             "achieved": hbm_rate, "frac": (hbm_rate / HBM_PEAK_GBPS) if hbm_rate else None,
@@ -309,8 +323,16 @@ def main():
             "compulsory_bytes_per_launch": compulsory,
             "compulsory_frac_of_hbm_peak": (compulsory / (gather_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if gather_ms > 0 else None,
             "traffic_over_compulsory": (traffic / compulsory) if traffic else None,
-            "note": "algorithmic bytes (93 000 B/point) are mostly L1/L2/Infinity-Cache hits, so they are priced against "
-                    "the L2 roof; frac is counter-measured HBM traffic against the HBM roof"}
+            "note": "algorithmic bytes are mostly L1/L2/Infinity-Cache hits, so they are priced against the L2 roof; frac is "
+                    "counter-measured HBM traffic against the HBM roof"}
+        if fused and gather_ms > 0:
+            tf = npts * 2.0 * 256 * FC0_K_FUSED * SPLIT_PRODUCTS / (gather_ms * 1e-3) / 1e12
+            roofline["mfma_TFLOPs"] = tf
+            roofline["mfma_frac_of_f16_peak"] = tf / MFMA_F16_PEAK_TFLOPS
+            roofline["note"] += ("; the kernel also carries fc_0's product (3 f16 MFMA products per f32 product): "
+                                 "mfma_frac_of_f16_peak.  It is bound by the vector-L1 rate of the corner reads "
+                                 "(64 B/clk/CU), not by HBM or the matrix cores -- the separate kernels it replaces took "
+                                 "2.05 (gather, HBM-write bound) + 2.13 ms (fc_0)")
         res = {
             "metric": "query-points/sec fwd+bwd (128^3 grid, 50k pts)", "value": value, "unit": "query-points/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
@@ -330,6 +352,8 @@ def main():
         if query is not None:
             for name, bpp in (("f32", GATHER_BYTES_PER_POINT_F32), ("bf16", GATHER_BYTES_PER_POINT_BF16)):
                 q = query[name]
+                if q["gather_op"] == "gather_fc0_fwd":
+                    bpp = FUSED_BYTES_PER_POINT_F32          # gather_ms then covers gather AND fc_0
                 q["value"] = npts / (q["ms"] * 1e-3)
                 q["unit"] = "query-points/s"
                 q["gather_algorithmic_GBps"] = npts * bpp / (q["gather_ms"] * 1e-3) / 1e9

@@ -144,6 +144,21 @@ int svr_gather_project_bwd(const float *points, const float *dh, int64_t lddh, i
  * columns past the last level (up to row_stride) are written as zeros.                      */
 int svr_gather_trilinear_fwd(const svr_gather_desc *d, const float *points /*(B,N,3)*/,
                              float *features, void *stream);
+/* Fused gather -> first point-MLP layer (gather_fc0.hip): the feature rows of svr_gather_trilinear_fwd are produced
+ * 128 points x one K-slab at a time in LDS and multiplied straight into fc_0's 128 x 256 output tile (3-product f16
+ * split, as svr_linear_fwd_f16x3), so the (B*N, row_stride) feature matrix is never written or read:
+ *   Y[b*N+n][0:n_out] = epi( features[b*N+n][:] . W[0:n_out][:]^T )         (model/ifnet.py:156-197 + :43-45,55)
+ * W (n_out, >= last used column), row stride ldw, in the feature row's column layout (svr_level.col); n_out = 256.
+ * keep_levels: bit l set = the gathered values of level l are ALSO stored to `features` (same layout as
+ * svr_gather_trilinear_fwd; with any bit set the padding columns behind the last level are zero-filled) -- the rows a
+ * backward still needs; 0 = inference, `features` may be NULL.  d->order must be NULL (sort the points instead);
+ * channel counts 1 (at most one level), 16, 32 or multiples of 64; every volume < 2^30 elements;
+ * svr_gather_fc0_supported(d) tells.  workspace: svr_gather_fc0_workspace(d, n_out) bytes.                       */
+int32_t svr_gather_fc0_supported(const svr_gather_desc *d);
+int64_t svr_gather_fc0_workspace(const svr_gather_desc *d, int32_t n_out);
+int svr_gather_fc0_fwd(const svr_gather_desc *d, const float *points, const float *W, int64_t ldw, const float *bias, float *Y,
+                       int64_t ldy, int32_t n_out, float *features, uint32_t keep_levels, int32_t epilogue, void *workspace,
+                       void *stream);
 /* gvol[level] += scatter of gfeatures (autograd of grid_sample wrt the volume);
  * levels with gvol == NULL are skipped.  gpoints (B,N,3) may be NULL; when given it is
  * OVERWRITTEN with the gradient wrt the query points.                                   */

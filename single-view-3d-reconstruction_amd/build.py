@@ -15,6 +15,7 @@ LIB = os.path.join(LIBDIR, "libsvr_hip.so")
 SOURCES = {
     "capi.cpp": [],
     "gather.hip": ["-ffp-contract=off"],
+    "gather_fc0.hip": ["-ffp-contract=off"],
     "sort.hip": [],
     "gemm.hip": [],
     "gemm_bf16x3.hip": [],

@@ -1,0 +1,504 @@
+// Fused trilinear gather -> fc_0 for gfx950: the feature rows never travel through HBM.
+//
+// Replaces, in one kernel, the six F.grid_sample calls + torch.cat of model/ifnet.py:156-197 AND the first Conv1d of the
+// point MLP (model/ifnet.py:43-45,55: fc_0 + ReLU).  The separate kernels (gather.hip's fused forward, gemm_f16x3.hip)
+// write the (B*N, 2592) feature matrix -- 4.1 GB at 128^3 x 50k x 8 -- and read it back: 2.05 + 2.13 ms, both bound by
+// those bytes.  Here a workgroup owns 128 consecutive (Morton-sorted) points and all 256 output columns:
+//   * 4 PRODUCER waves gather one K-slab (<= 64 feature columns of one level: one or two displacements x a channel
+//     range) for the 128 points -- same geometry and summation order as gather.hip, so the values are bit-identical --
+//     split it into the f16 hi / lo planes of the 3-product split (f16x3.h) and store it in LDS;
+//   * 4 CONSUMER waves (one per SIMD, 128 x 64 outputs each) multiply the previous slab from the other LDS buffer with
+//     W's pre-split planes, which they read straight from L2 in MFMA fragment layout (no LDS staging, no redundancy
+//     between the consumers), three v_mfma_f32_32x32x16_f16 per 32 x 32 x 16 block;
+//   * one s_barrier per slab hands the buffers over.
+// The kernel is bound by the bytes the producers pull through the vector L1 (93 KB per point of corner reads, most of
+// them cache hits) -- the matrix cores wait for the gather, not the other way round.
+// Levels whose rows the backward still needs (the ones that are not projected, ifnet.py) are ALSO written to the
+// feature matrix, in gather.hip's layout: 800 of 2592 columns at the 128-architecture.
+//
+// Build with -ffp-contract=off (gather_common.h).
+#include "common.h"
+#include "gather_common.h"
+#include "f16x3.h"
+#include <algorithm>
+#include <cstdlib>
+
+using namespace svr;
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#define GLOBAL_AS __attribute__((address_space(1)))
+
+constexpr int FK = 16;                 // reduction elements per MFMA step
+constexpr int FLW = 10;                // dwords per LDS row of one k-step (16 halves + 8 B pad, as gemm_f16x3.hip)
+constexpr int FTM = 128;               // points per workgroup
+constexpr int FTN = 256;               // output columns (fc_0's width)
+constexpr int FPLANE = FTM * FLW;      // dwords per plane and k-step
+constexpr int FKSTEP = 2 * FPLANE + 20;  // hi + lo; + 20 dwords: the k-steps of one producer store land on different banks
+constexpr int FSLAB_K = 4;             // k-steps per slab buffer
+constexpr int FSLAB = FSLAB_K * FKSTEP;
+constexpr int FC_MAX_SLABS = 44;
+constexpr int FC_LDS_BYTES = 2 * FSLAB * 4;
+
+struct FcLevel {
+  const float *vol;
+  int C, D, H, W, col;
+};
+struct FcSlab {
+  unsigned char level, j0, nj, lp;  // lp: lanes per point (columns / 4); 0 marks the C == 1 slab (7 columns + 9 zeros)
+  short k0, nk;                     // first k-step and number of k-steps
+  short c0, keep;                   // first channel; keep: also store the values to the feature matrix
+};
+struct FcArgs {
+  FcLevel L[SVR_MAX_LEVELS];
+  FcSlab S[FC_MAX_SLABS];
+  int n_slabs, KF;  // KF: fused reduction length (multiple of 16)
+};
+
+// fused K order -> column of W's (= the feature row's) layout, -1 for the padding of the C == 1 slab
+__device__ __forceinline__ int fused_col(const FcArgs &A, int kk) {
+  for (int s = 0; s < A.n_slabs; ++s) {
+    const FcSlab S = A.S[s];
+    const int r = kk - S.k0 * FK;
+    if (r < 0 || r >= S.nk * FK) continue;
+    const FcLevel L = A.L[S.level];
+    if (S.lp == 0) return r < 7 ? L.col + r : -1;
+    const int nc = S.lp * 4 / S.nj;
+    return L.col + (S.j0 + r / nc) * L.C + S.c0 + r % nc;
+  }
+  return -1;
+}
+
+// Fragment-major W planes: the 16 halves x 32 rows of one MFMA B-fragment are 1 KB contiguous (lane l of the consumer wave
+// reads 16 bytes at lane * 16), k-step major: [k-step][hi / lo][row tile of 32][lane 64][8 halves].  A row-major plane
+// made every fragment load touch 32 cache lines for 32 bytes each and the L1 re-fetched every line four times.
+__device__ __forceinline__ int64_t wfrag_index(int kk, int plane, int n, int ntiles) {
+  return ((((int64_t)(kk >> 4) * 2 + plane) * ntiles + (n >> 5)) * 64 + ((kk >> 3) & 1) * 32 + (n & 31)) * 8 + (kk & 7);
+}
+
+// W[N][K] f32 -> fragment-major f16 planes in the fused K order: hi(Ws), lo(Ws)
+__global__ void split_w_fused_kernel(FcArgs A, const float *__restrict__ W, int64_t ldw, const uint32_t *__restrict__ amax,
+                                     uint16_t *__restrict__ p0, int N) {
+  const int kk = blockIdx.x * blockDim.x + threadIdx.x, n = blockIdx.y;
+  if (kk >= A.KF || n >= N) return;
+  const int src = fused_col(A, kk);
+  const float w = src >= 0 ? W[(int64_t)n * ldw + src] * w_scale(amax[0], false) : 0.f;
+  const _Float16 h = (_Float16)w;  // round to nearest even, like pack_f16
+  const _Float16 l = (_Float16)(w - (float)h);
+  p0[wfrag_index(kk, 0, n, N / 32)] = __builtin_bit_cast(uint16_t, h);
+  p0[wfrag_index(kk, 1, n, N / 32)] = __builtin_bit_cast(uint16_t, l);
+}
+
+__device__ __forceinline__ f16x8 lds_frag(const uint32_t *plane, int row, int lh) {
+  const uint2 a = *reinterpret_cast<const uint2 *>(plane + row * FLW + lh * 4);
+  const uint2 b = *reinterpret_cast<const uint2 *>(plane + row * FLW + lh * 4 + 2);
+  union { uint4 q; f16x8 v; } f;
+  f.q = make_uint4(a.x, a.y, b.x, b.y);
+  return f.v;
+}
+
+// One slab of a level with C >= 16: LP lanes per point (LP * 4 columns), NJ displacements side by side.
+// Producer wave pw owns rows [32 pw, 32 pw + 32) of the tile.  The producers are bound by the instructions they issue
+// (one wave per SIMD, 4 cycles per wave64 VALU instruction), so the per-pass code is pared down to the loads, the
+// packed multiply / add chain, the f16 split and two LDS stores:
+//   phase 1 (once per slab): lane l evaluates item (row 32 pw + l / NJ, displacement j0 + l % NJ) completely -- the eight
+//     corner weights (wx*wy)*wz with 0 for corners outside the volume, and the byte offsets of the CLAMPED corner
+//     coordinates (four (z,y) row offsets + two x offsets), so phase 2 needs neither bounds tests nor address selects;
+//   phase 2: LP / 2 passes of 64 / LP rows; the owning lane's 14 values arrive by ds_bpermute, 8 float4 loads
+//     (uniform base + 32-bit offset), sum_k v_k * w_k in ATen's corner order.  A corner outside the volume contributes
+//     v * 0 with v read from a clamped, i.e. existing, voxel: the sum is bit-identical to skipping it (ATen,
+//     gather.hip) for finite volumes.
+template <int LP, int NJ>
+__device__ __forceinline__ void produce_slab(const FcLevel L, const FcSlab S, uint32_t *__restrict__ buf,
+                                             const float *__restrict__ points, int64_t m0, int64_t M, int N, float disp,
+                                             int ac, float *__restrict__ feat, int row_stride, int pw, int lane) {
+  constexpr int PPW = 64 / LP, NP = 32 / PPW, LPI = LP / NJ, NC = LPI * 4, DEPTH = NP <= 4 ? NP : 3;  // passes in flight (the fine levels miss the caches: all of a slab's passes)
+  const int C = L.C;
+  const GLOBAL_AS char *vol = (const GLOBAL_AS char *)L.vol;
+  // ---- phase 1
+  const int irow = 32 * pw + min(lane / NJ, 31);
+  const int64_t pn = min(m0 + irow, M - 1);
+  const int b = (int)(pn / N);
+  const Corner c = sample_corner(points + pn * 3, S.j0 + lane % NJ, disp, L.D, L.H, L.W, ac);
+  const Weights w = corner_weights(c);
+  int xc[2], yc[2], zc[2];
+  bool vx[2], vy[2], vz[2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
+    vx[a] = w.x0 + a >= 0 && w.x0 + a < L.W;
+    vy[a] = w.y0 + a >= 0 && w.y0 + a < L.H;
+    vz[a] = w.z0 + a >= 0 && w.z0 + a < L.D;
+    xc[a] = min(max(w.x0 + a, 0), L.W - 1);
+    yc[a] = min(max(w.y0 + a, 0), L.H - 1);
+    zc[a] = min(max(w.z0 + a, 0), L.D - 1);
+  }
+  int wk[8], ezy[4], ex[2];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const float wt = (w.wx[k & 1] * w.wy[(k >> 1) & 1]) * w.wz[k >> 2];
+    wk[k] = __float_as_int((vx[k & 1] && vy[(k >> 1) & 1] && vz[k >> 2]) ? wt : 0.f);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) ezy[i] = (int)((uint32_t)(((b * L.D + zc[i >> 1]) * L.H + yc[i & 1]) * L.W * C) * 4u);  // host: < 2^30 elements
+#pragma unroll
+  for (int a = 0; a < 2; ++a) ex[a] = (xc[a] * C + S.c0) * 4;
+  // ---- phase 2
+  const int g = lane / LP, q = lane % LP, jj = q / LPI, c4 = (q % LPI) * 4;
+  const int src0 = (g * NJ + jj) << 2;
+  const int col = jj * NC + c4;  // column inside the slab
+  uint32_t *dstg = buf + (col >> 4) * FKSTEP + ((col & 15) >> 1) + (32 * pw + g) * FLW;
+  GLOBAL_AS char *featt = (GLOBAL_AS char *)(feat + m0 * row_stride);
+  const uint32_t fo0 = (uint32_t)((32 * pw + g) * row_stride + L.col + (S.j0 + jj) * C + S.c0 + c4) * 4u;
+  const int live = M - m0 < FTM ? (int)(M - m0) : FTM;
+  struct Iter {
+    f32x4 v[8];
+    float w[8];
+  };
+  auto fetch = [&](Iter &I, int it) {
+    const int src = src0 + it * (PPW * NJ * 4);
+    uint32_t zy[4], x[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) zy[i] = (uint32_t)__builtin_amdgcn_ds_bpermute(src, ezy[i]);
+#pragma unroll
+    for (int a = 0; a < 2; ++a) x[a] = (uint32_t)__builtin_amdgcn_ds_bpermute(src, ex[a]) + (uint32_t)(c4 * 4);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) I.w[k] = __int_as_float(__builtin_amdgcn_ds_bpermute(src, wk[k]));
+#pragma unroll
+    for (int k = 0; k < 8; ++k) I.v[k] = *reinterpret_cast<const GLOBAL_AS f32x4 *>(vol + (zy[k >> 1] + x[k & 1]));
+  };
+  auto finish = [&](const Iter &I, int it) {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc = acc + I.v[k] * I.w[k];
+    uint32_t h0, l0, h1, l1;
+    split_x(acc.x, acc.y, h0, l0);
+    split_x(acc.z, acc.w, h1, l1);
+    uint32_t *d = dstg + it * (PPW * FLW);
+    *reinterpret_cast<uint2 *>(d) = make_uint2(h0, h1);
+    *reinterpret_cast<uint2 *>(d + FPLANE) = make_uint2(l0, l1);
+    if (S.keep && 32 * pw + it * PPW + g < live)
+      *reinterpret_cast<GLOBAL_AS f32x4 *>(featt + (fo0 + (uint32_t)(it * PPW * row_stride * 4))) = acc;
+  };
+  Iter I[DEPTH];
+#pragma unroll
+  for (int it = 0; it < DEPTH; ++it) fetch(I[it], it);
+#pragma unroll
+  for (int it = 0; it < NP; ++it) {
+    finish(I[it % DEPTH], it);
+    if (it + DEPTH < NP) fetch(I[it % DEPTH], it + DEPTH);
+  }
+}
+
+// The C == 1 level (the raw input grid): 7 columns + 9 zero columns, one k-step.  One (row, displacement) item per
+// producer thread and round (4 rounds of 256; "displacement 7" stands for the zero columns), all 8 x 4 loads in flight.
+__device__ __forceinline__ void produce_c1(const FcLevel L, const FcSlab S, uint32_t *__restrict__ buf,
+                                           const float *__restrict__ points, int64_t m0, int64_t M, int N, float disp, int ac,
+                                           float *__restrict__ feat, int row_stride, int tp) {
+  const GLOBAL_AS float *vol = (const GLOBAL_AS float *)L.vol;
+  float u[4][8], wk[4][8];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int item = r * 256 + tp, row = item >> 3, j = item & 7;
+    const int64_t pn = min(m0 + row, M - 1);
+    const uint32_t vb = (uint32_t)(pn / N) * (uint32_t)(L.D * L.H * L.W);
+    const Corner c = sample_corner(points + pn * 3, j < 7 ? j : 0, disp, L.D, L.H, L.W, ac);
+    const Weights w = corner_weights(c);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int z = w.z0 + (k >> 2), y = w.y0 + ((k >> 1) & 1), x = w.x0 + (k & 1);
+      const bool valid = z >= 0 && z < L.D && y >= 0 && y < L.H && x >= 0 && x < L.W && j < 7;
+      const int zc = min(max(z, 0), L.D - 1), yc = min(max(y, 0), L.H - 1), xc = min(max(x, 0), L.W - 1);
+      wk[r][k] = valid ? (w.wx[k & 1] * w.wy[(k >> 1) & 1]) * w.wz[k >> 2] : 0.f;
+      u[r][k] = vol[vb + (uint32_t)((zc * L.H + yc) * L.W + xc)];
+    }
+  }
+  uint16_t *b16 = reinterpret_cast<uint16_t *>(buf);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int item = r * 256 + tp, row = item >> 3, j = item & 7;
+    float acc = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc = acc + u[r][k] * wk[r][k];
+    if (j == 7) acc = 0.f;  // (a volume with non-finite values must not leak into the zero columns)
+    const _Float16 h = (_Float16)acc;
+    const _Float16 l = (_Float16)((acc - (float)h) * 2048.f);
+    if (j < 7) {
+      b16[(row * FLW) * 2 + j] = __builtin_bit_cast(uint16_t, h);
+      b16[(FPLANE + row * FLW) * 2 + j] = __builtin_bit_cast(uint16_t, l);
+      if (S.keep && m0 + row < M) feat[(m0 + row) * row_stride + L.col + j] = acc;
+    } else {  // halves 7 .. 15 of the row: zeros
+      b16[(row * FLW) * 2 + 7] = 0;
+      b16[(FPLANE + row * FLW) * 2 + 7] = 0;
+#pragma unroll
+      for (int p = 4; p < 8; ++p) {
+        buf[row * FLW + p] = 0u;
+        buf[FPLANE + row * FLW + p] = 0u;
+      }
+    }
+  }
+}
+
+__device__ __forceinline__ void produce(const FcArgs &A, int s, uint32_t *buf, const float *points, int64_t m0, int64_t M,
+                                        int N, float disp, int ac, float *feat, int row_stride, int pw, int lane, int dbg) {
+  const FcSlab S = A.S[s];
+  const FcLevel L = A.L[S.level];
+  if ((dbg >> (8 + S.level)) & 1) return;
+  if (S.lp == 0) {
+    produce_c1(L, S, buf, points, m0, M, N, disp, ac, feat, row_stride, pw * 64 + lane);
+    return;
+  }
+  switch (S.lp * 4 + S.nj) {
+    case 16 * 4 + 1: produce_slab<16, 1>(L, S, buf, points, m0, M, N, disp, ac, feat, row_stride, pw, lane); break;
+    case 16 * 4 + 2: produce_slab<16, 2>(L, S, buf, points, m0, M, N, disp, ac, feat, row_stride, pw, lane); break;
+    case 8 * 4 + 1: produce_slab<8, 1>(L, S, buf, points, m0, M, N, disp, ac, feat, row_stride, pw, lane); break;
+    case 8 * 4 + 2: produce_slab<8, 2>(L, S, buf, points, m0, M, N, disp, ac, feat, row_stride, pw, lane); break;
+    case 4 * 4 + 1: produce_slab<4, 1>(L, S, buf, points, m0, M, N, disp, ac, feat, row_stride, pw, lane); break;
+  }
+}
+
+__device__ __forceinline__ void slab_barrier() {  // LDS stores of this wave done, then the workgroup barrier
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// The slab table is read from DEVICE memory (args_store_kernel copies the by-value struct there): kernel arguments live in
+// uncached host-visible memory, and one dynamically indexed s_load from them per slab cost ~0.8 us (0.4 ms per launch).
+__global__ void args_store_kernel(FcArgs A, FcArgs *__restrict__ dst) {
+  const uint32_t *src = reinterpret_cast<const uint32_t *>(&A);
+  for (unsigned i = threadIdx.x; i < sizeof(FcArgs) / 4; i += blockDim.x) reinterpret_cast<uint32_t *>(dst)[i] = src[i];
+}
+
+__global__ __launch_bounds__(512, 1) void gather_fc0_kernel(const FcArgs *__restrict__ Ap, const float *__restrict__ points,
+                                                            const uint16_t *__restrict__ W0,
+                                                            const uint32_t *__restrict__ amax, const float *__restrict__ bias,
+                                                            float *__restrict__ Y, int64_t ldy, float *__restrict__ feat,
+                                                            int row_stride, int pad_start, int64_t M, int N, float disp, int ac,
+                                                            int relu, int dbg) {
+  extern __shared__ uint32_t lds[];
+  const FcArgs &A = *Ap;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int64_t m0 = (int64_t)blockIdx.x * FTM;
+  const int S = A.n_slabs;
+  if (dbg & 8) return;
+  if (wave >= 4) {
+    // ------------------------------------------------------------------ producers
+    const int pw = wave - 4;
+    if (pad_start >= 0 && t - 256 < FTM && m0 + (t - 256) < M)  // kept rows: the padding columns behind the last level are zeros
+      for (int cc = pad_start; cc < row_stride; ++cc) feat[(m0 + (t - 256)) * row_stride + cc] = 0.f;
+    if (!(dbg & 1)) produce(A, 0, lds, points, m0, M, N, disp, ac, feat, row_stride, pw, lane, dbg);
+    slab_barrier();
+    for (int s = 0; s < S; ++s) {
+      if (s + 1 < S && !(dbg & 1)) produce(A, s + 1, lds + ((s + 1) & 1) * FSLAB, points, m0, M, N, disp, ac, feat, row_stride, pw, lane, dbg);
+      slab_barrier();
+    }
+    return;
+  }
+  // -------------------------------------------------------------------- consumers: wave wc -> columns [64 wc, 64 wc + 64)
+  const int wc = wave, l31 = lane & 31, lh = lane >> 5;
+  const int KF = A.KF, nk = KF / FK;
+  const uint16_t *wp = W0 + ((2 * wc) * 64 + lane) * 8;  // + jt * 512 halves, + plane * 8 * 512, + k-step * 2 * 8 * 512
+  // W fragments of four k-steps in registers, rotating by NAME (a copy would have to wait for the load it moves)
+  uint4 b0[2][2], b1[2][2], b2[2][2], b3[2][2];  // [tile][hi / lo]
+  auto loadb = [&](uint4 (&r)[2][2], int kidx) {
+    const uint16_t *q = wp + (kidx < nk ? kidx : nk - 1) * (2 * (FTN / 32) * 512);
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt) {
+      r[jt][0] = *reinterpret_cast<const uint4 *>(q + jt * 512);
+      r[jt][1] = *reinterpret_cast<const uint4 *>(q + (FTN / 32) * 512 + jt * 512);
+    }
+  };
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  loadb(b0, 0);
+  loadb(b1, 1);
+  loadb(b2, 2);
+  slab_barrier();  // slab 0 is in LDS
+  int s = 0, kin = 0, ksl = A.S[0].nk, kidx = 0;
+  // k-step kidx on the fragments `cur`; `fre` (used one step ago) is refilled with step kidx + 3
+  auto step = [&](const uint4 (&cur)[2][2], uint4 (&fre)[2][2]) {
+    if (!(dbg & 2)) {
+      loadb(fre, kidx + 3);
+      const uint32_t *pa = lds + (s & 1) * FSLAB + kin * FKSTEP;
+      f16x8 b[3][2];
+#pragma unroll
+      for (int jt = 0; jt < 2; ++jt) {
+        union { uint4 q; f16x8 v; } u0, u1;
+        u0.q = cur[jt][0];
+        u1.q = cur[jt][1];
+        b[0][jt] = u0.v;
+        b[1][jt] = u1.v;
+        b[2][jt] = scale_2m11(u0.v);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const f16x8 ah = lds_frag(pa, i * 32 + l31, lh), al = lds_frag(pa + FPLANE, i * 32 + l31, lh);
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt) {
+          acc[i][jt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, b[2][jt], acc[i][jt], 0, 0, 0);  // lo(x) hi(w)
+          acc[i][jt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, b[1][jt], acc[i][jt], 0, 0, 0);  // hi(x) lo(w)
+          acc[i][jt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, b[0][jt], acc[i][jt], 0, 0, 0);  // hi(x) hi(w)
+        }
+      }
+    }
+    ++kidx;
+    if (++kin == ksl) {  // slab consumed: hand the buffer back, the next one is ready behind the barrier
+      slab_barrier();
+      ++s;
+      kin = 0;
+      ksl = s < S ? A.S[s].nk : 0;
+    }
+  };
+  while (kidx < nk) {
+    step(b0, b3);
+    if (kidx >= nk) break;
+    step(b1, b0);
+    if (kidx >= nk) break;
+    step(b2, b1);
+    if (kidx >= nk) break;
+    step(b3, b2);
+  }
+  if (dbg & 4) return;
+  const float inv = w_scale(amax[0], true);
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt) {
+      const int n = 64 * wc + jt * 32 + l31;
+      const float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t m = m0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (m < M) {
+          float v = acc[i][jt][r] * inv + bv;
+          if (relu) v = fmaxf(v, 0.f);
+          Y[m * ldy + n] = v;
+        }
+      }
+    }
+}
+
+// slab table of a descriptor; false if a level's channel count has no slab shape
+bool build_slabs(const svr_gather_desc *d, uint32_t keep_mask, FcArgs &A) {
+  int ns = 0, k = 0;
+  auto add = [&](int level, int j0, int nj, int lp, int c0, int cols) {
+    if (ns >= FC_MAX_SLABS) return false;
+    FcSlab &S = A.S[ns++];
+    S.level = (unsigned char)level;
+    S.j0 = (unsigned char)j0;
+    S.nj = (unsigned char)nj;
+    S.lp = (unsigned char)lp;
+    S.k0 = (short)k;
+    S.nk = (short)(cols / FK);
+    S.c0 = (short)c0;
+    S.keep = (short)((keep_mask >> level) & 1);
+    k += cols / FK;
+    return true;
+  };
+  // the C == 1 level first: the only slab that is not overlapped with MFMAs should be the cheapest
+  for (int pass = 0; pass < 2; ++pass)
+    for (int l = 0; l < d->n_levels; ++l) {
+      const svr_level &lv = d->level[l];
+      A.L[l] = FcLevel{lv.vol, lv.C, lv.D, lv.H, lv.W, lv.col};
+      const int C = lv.C;
+      if ((C == 1) != (pass == 0)) continue;
+      bool ok = true;
+      if (C == 1) {
+        ok = add(l, 0, 7, 0, 0, 16);
+      } else if (C == 16) {
+        for (int j = 0; j < 6 && ok; j += 2) ok = add(l, j, 2, 8, 0, 32);
+        ok = ok && add(l, 6, 1, 4, 0, 16);
+      } else if (C == 32) {
+        for (int j = 0; j < 6 && ok; j += 2) ok = add(l, j, 2, 16, 0, 64);
+        ok = ok && add(l, 6, 1, 8, 0, 32);
+      } else if (C >= 64 && C % 64 == 0) {
+        for (int j = 0; j < 7 && ok; ++j)
+          for (int c0 = 0; c0 < C && ok; c0 += 64) ok = add(l, j, 1, 16, c0, 64);
+      } else {
+        return false;
+      }
+      if (!ok) return false;
+    }
+  A.n_slabs = ns;
+  A.KF = k * FK;
+  return ns > 0;
+}
+
+int check_desc(const svr_gather_desc *d, const char *who) {
+  SVR_CHECK(d && d->n_levels >= 1 && d->n_levels <= SVR_MAX_LEVELS && d->B > 0 && d->N >= 0, SVR_E_BADARG, "%s: bad descriptor", who);
+  SVR_CHECK(d->order == nullptr, SVR_E_UNSUPPORTED, "%s: a processing order is not supported (sort the points instead)", who);
+  int n_c1 = 0;
+  for (int l = 0; l < d->n_levels; ++l) {
+    const svr_level &lv = d->level[l];
+    SVR_CHECK(lv.vol && lv.D > 0 && lv.H > 0 && lv.W > 0, SVR_E_BADARG, "%s: level %d: bad volume", who, l);
+    SVR_CHECK((int64_t)d->B * lv.D * lv.H * lv.W * lv.C < (1LL << 30), SVR_E_UNSUPPORTED, "%s: level %d has >= 2^30 elements", who, l);
+    SVR_CHECK(((uintptr_t)lv.vol & 15) == 0 || lv.C == 1, SVR_E_ALIGN, "%s: level %d: volume must be 16-byte aligned", who, l);
+    SVR_CHECK(lv.C == 1 || lv.col % 4 == 0, SVR_E_ALIGN, "%s: level %d: column %d", who, l, lv.col);
+    n_c1 += lv.C == 1;
+  }
+  SVR_CHECK(n_c1 <= 1, SVR_E_UNSUPPORTED, "%s: more than one single-channel level", who);
+  return SVR_OK;
+}
+
+}  // namespace
+
+extern "C" int32_t svr_gather_fc0_supported(const svr_gather_desc *d) {
+  if (!d || d->n_levels < 1 || d->n_levels > SVR_MAX_LEVELS || d->order) return 0;
+  FcArgs A;
+  if (!build_slabs(d, 0, A)) return 0;
+  for (int l = 0; l < d->n_levels; ++l)
+    if ((int64_t)d->B * d->level[l].D * d->level[l].H * d->level[l].W * d->level[l].C >= (1LL << 30)) return 0;
+  return 1;
+}
+
+extern "C" int64_t svr_gather_fc0_workspace(const svr_gather_desc *d, int32_t n_out) {
+  FcArgs A;
+  if (!d || !build_slabs(d, 0, A)) return 0;
+  return 2 * (int64_t)n_out * A.KF * (int64_t)sizeof(uint16_t) + 1024 + (int64_t)sizeof(FcArgs);
+}
+
+extern "C" int svr_gather_fc0_fwd(const svr_gather_desc *d, const float *points, const float *W, int64_t ldw, const float *bias,
+                                  float *Y, int64_t ldy, int32_t n_out, float *feat, uint32_t keep_levels, int32_t epilogue,
+                                  void *workspace, void *stream) {
+  int rc = check_desc(d, "gather_fc0_fwd");
+  if (rc != SVR_OK) return rc;
+  const int64_t M = (int64_t)d->B * d->N;
+  if (M == 0) return SVR_OK;
+  SVR_CHECK(points && W && Y && workspace, SVR_E_BADARG, "gather_fc0_fwd: null pointer");
+  SVR_CHECK(n_out == FTN, SVR_E_UNSUPPORTED, "gather_fc0_fwd: %d output columns (the kernel is built for %d)", n_out, FTN);
+  SVR_CHECK(epilogue == SVR_EPI_NONE || ((epilogue == SVR_EPI_BIAS || epilogue == SVR_EPI_BIAS_RELU) && bias), SVR_E_BADARG,
+            "gather_fc0_fwd: epilogue %d", epilogue);
+  SVR_CHECK(keep_levels == 0 || (feat && d->row_stride % 4 == 0 && ((uintptr_t)feat & 15) == 0 && M * d->row_stride < (1LL << 31)),
+            SVR_E_BADARG, "gather_fc0_fwd: keep_levels needs a 16-byte aligned feature matrix with < 2^31 elements");
+  FcArgs A;
+  SVR_CHECK(build_slabs(d, keep_levels, A), SVR_E_UNSUPPORTED, "gather_fc0_fwd: a level's channel count has no slab shape (1, 16, 32, 64 k)");
+  for (int l = 0; l < d->n_levels; ++l)
+    if (d->level[l].C == 1 && ((keep_levels >> l) & 1))
+      SVR_CHECK(d->level[l].col + 7 <= d->row_stride, SVR_E_BADSHAPE, "gather_fc0_fwd: level %d does not fit the row", l);
+  hipStream_t s = (hipStream_t)stream;
+  uint32_t *amax = (uint32_t *)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+  uint16_t *p0 = (uint16_t *)(amax + 64);
+  uint16_t *p1 = p0 + (int64_t)n_out * A.KF;
+  FcArgs *Ad = (FcArgs *)(((uintptr_t)(p1 + (int64_t)n_out * A.KF) + 255) & ~(uintptr_t)255);
+  // W's columns: every column of the layout the slabs cover (the row's padding columns never enter the product)
+  int64_t kw = 0;
+  for (int l = 0; l < d->n_levels; ++l) kw = std::max<int64_t>(kw, d->level[l].col + 7 * d->level[l].C);
+  (void)hipMemsetAsync(amax, 0, sizeof(uint32_t), s);
+  hipLaunchKernelGGL(w_amax_kernel, dim3((unsigned)std::min<int64_t>(cdiv(n_out * kw, 1024), 1024)), dim3(256), 0, s, W, ldw,
+                     (int64_t)n_out, kw, amax);
+  hipLaunchKernelGGL(split_w_fused_kernel, dim3((unsigned)cdiv(A.KF, 64), (unsigned)n_out), dim3(64), 0, s, A, W, ldw, amax, p0, (int)n_out);
+  hipLaunchKernelGGL(args_store_kernel, dim3(1), dim3(256), 0, s, A, Ad);
+  hipError_t e = hipFuncSetAttribute((const void *)gather_fc0_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FC_LDS_BYTES);
+  SVR_CHECK(e == hipSuccess, (int)e, "gather_fc0_fwd: cannot reserve %d bytes of LDS: %s", FC_LDS_BYTES, hipGetErrorString(e));
+  const float *eb = epilogue == SVR_EPI_NONE ? nullptr : bias;
+  const int relu = epilogue == SVR_EPI_BIAS_RELU ? 1 : 0;
+  hipLaunchKernelGGL(gather_fc0_kernel, dim3((unsigned)cdiv(M, FTM)), dim3(512), FC_LDS_BYTES, s, Ad, points, p0, amax, eb, Y,
+                     ldy, feat, d->row_stride, keep_levels ? (int)kw : -1, M, d->N, d->displacement, d->align_corners, relu,
+                     getenv("SVR_FC0_DBG") ? atoi(getenv("SVR_FC0_DBG")) : 0);
+  return launch_status("gather_fc0_fwd");
+}

@@ -143,6 +143,24 @@ def _level_orders_async(pts, D, H, W, n_levels, align, layout=None, disp=None, p
 # dP_l[b][voxel][j][256], and two GEMMs over VOXELS (32 768 rows at level 4) give the level's gradient volume and its slice
 # of dW0.  dX0 / dW0 of the point MLP then only cover the remaining 800 columns.  The forward pass is unchanged.
 PROJECT_WIDE_LEVELS = os.environ.get("SVR_NO_PROJECTION") is None
+# Fused gather -> fc_0 forward (gather_fc0.hip): the feature rows are never written to HBM; only the columns a backward
+# still needs (the levels that are not projected) are kept.  SVR_NO_FUSED_FC0=1 restores the two separate kernels.
+FUSE_FC0 = os.environ.get("SVR_NO_FUSED_FC0") is None
+
+
+def _fc0_fusable(channels, B, dims, n_out):
+    """Shapes gather_fc0.hip is built for (svr_gather_fc0_supported): 256 outputs, channel counts 1 (once), 16, 32 or
+    multiples of 64, every level's volume below 2^30 elements (32-bit byte offsets)."""
+    if n_out != 256 or sum(1 for c in channels if c == 1) > 1:
+        return False
+    D, H, W = dims
+    for l, c in enumerate(channels):
+        if not (c in (1, 16, 32) or c % 64 == 0):
+            return False
+        s = max(l - 1, 0)
+        if B * max(D >> s, 1) * max(H >> s, 1) * max(W >> s, 1) * c >= 2 ** 30:
+            return False
+    return True
 
 
 class _ProjLink:
@@ -172,7 +190,10 @@ class _EncoderGatherFn(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, ext, grad_mode, link, w0p, x, points, *params):
+    def forward(ctx, ext, grad_mode, link, w0p, b0, x, points, *params):
+        """b0 given (with link and w0p): FUSED form -- the output is h0 = relu(fc_0(rows)) straight from the gather
+        (gather_fc0.hip), the rows of the levels that are not projected are kept for the backward, and backward()
+        takes the gradient wrt fc_0's PRE-activation (what _PointMLPFn's headless form returns for its input)."""
         B = x.shape[0]
         D, H, W = x.shape[2:]
         training = ext.training
@@ -190,7 +211,7 @@ class _EncoderGatherFn(torch.autograd.Function):
         will_backward = bool(grad_mode) and any(ctx.needs_input_grad)
         ctx.link = link if (will_backward and link is not None) else None
         if ctx.link is not None:
-            ctx.link.need_level0 = bool(ctx.needs_input_grad[4])
+            ctx.link.need_level0 = bool(ctx.needs_input_grad[5])
         if will_backward and x.is_cuda:
             ctx.level_orders, ctx.level_plans, ctx.orders_ready = _level_orders_async(
                 pts, D, H, W, nst + 1, ext._align, ext._layout, ext._disp,
@@ -214,7 +235,14 @@ class _EncoderGatherFn(torch.autograd.Function):
             levels.append(y)
             saved.append((inp, acts, argmax, ss, mean))
             inp = pooled
-        feat = ops.gather_fwd(levels, pts, ext._layout, ext._disp, ext._align)
+        ctx.fused = b0 is not None
+        if ctx.fused:
+            keep = [l for l in range(len(levels)) if ctx.link is None or l not in ctx.link.levels] if will_backward else []
+            out, feat = ops.gather_fc0_fwd(levels, pts, ext._layout, ext._disp, ext._align, w0p.detach(), b0.detach(), relu=True,
+                                           keep_levels=keep)
+            ctx.feat = feat
+        else:
+            out = feat = ops.gather_fwd(levels, pts, ext._layout, ext._disp, ext._align)
         # the zero-initialised gradient volumes of the backward scatter (1.45 GB of memset at config 3) are prepared on
         # the side stream too, beside the point MLP, instead of in front of the scatter
         ctx.gvols = None
@@ -232,18 +260,37 @@ class _EncoderGatherFn(torch.autograd.Function):
                 ctx.orders_ready = torch.cuda.Event()
                 ctx.orders_ready.record(side)
         ctx.ext, ctx.saved, ctx.levels, ctx.pts = ext, saved, levels, pts
-        ctx.w0p = w0p.detach() if ctx.link is not None else None
+        ctx.w0p = w0p.detach() if (ctx.link is not None or ctx.fused) else None
         ctx.x_shape = x.shape
         ctx.training = training
-        return feat
+        return out
 
     @staticmethod
     def backward(ctx, gfeat):
         ext, saved, levels, pts = ctx.ext, ctx.saved, ctx.levels, ctx.pts
-        need_x, need_pts = ctx.needs_input_grad[4], ctx.needs_input_grad[5]
+        need_x, need_pts = ctx.needs_input_grad[5], ctx.needs_input_grad[6]
         gfeat = gfeat.contiguous()
         link = ctx.link
         proj = link.levels if link is not None else ()
+        dw0_keep = db0 = None
+        if ctx.fused:
+            # fused forward: fc_0's backward lives here.  gfeat is dz0 (B*N, 256); dW0 / dX0 only over the kept columns
+            dh0, feat, w0p = gfeat, ctx.feat, ctx.w0p
+            ctx.feat = None
+            keep = link.keep if link is not None else [(0, ext._layout.row_stride)]
+            dw0_keep = torch.zeros_like(w0p)
+            gfeat = torch.empty_like(feat)           # the projected levels' columns are never read
+            lvl0 = ext._layout.col[0]
+            for a, b in keep:
+                dws, dbs = ops.linear_bwd_weight(dh0, feat[:, a:b], want_bias=db0 is None)
+                dw0_keep[:, a:b] = dws
+                db0 = dbs if db0 is None else db0
+                if a == lvl0 and not need_x and link is not None:
+                    continue                         # raw-grid columns: their gradient is only needed for d(loss)/d(input)
+                ops.linear_bwd_data(dh0, w0p[:, a:b], out=gfeat[:, a:b])
+            del feat
+            if link is not None:
+                link.dh0 = dh0
         if link is not None and link.dh0 is None:
             raise RuntimeError("IF-Net HIP path: the projected backward needs dh0 from the point MLP's backward")
         level_orders, level_plans = ctx.level_orders, ctx.level_plans
@@ -272,7 +319,7 @@ class _EncoderGatherFn(torch.autograd.Function):
             # projected levels: dP = scatter of the dh0 rows, then two GEMMs over voxels (see gather_bwd_proj_kernel)
             lay, w0p, dh0 = ext._layout, ctx.w0p, link.dh0
             link.dh0 = None
-            dw0p = torch.zeros_like(w0p)
+            dw0p = dw0_keep if dw0_keep is not None else torch.zeros_like(w0p)
             for l in proj:
                 v = levels[l]
                 B_, Dl, Hl, Wl, Cl = v.shape
@@ -308,7 +355,9 @@ class _EncoderGatherFn(torch.autograd.Function):
                     gx = ops.conv3d_k3_bwd_data(dout, conv.weight.detach())
         if need_x:
             gx = (gx + gvols[0]).view(ctx.x_shape)
-        out = [None, None, None, dw0p, gx, gpts]
+        if dw0p is None:
+            dw0p = dw0_keep
+        out = [None, None, None, dw0p, db0, gx, gpts]
         for p in ext._param_list:
             out.append(grads.get(p))
         return tuple(out)
@@ -321,7 +370,19 @@ class _PointMLPFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, feat, row_map, w0p, b0, w1, b1, w2, b2, wo, bo, link=None):
         """row_map (int32, or None): feature row m belongs to caller point row_map[m]; the logits are
-        scattered back to the caller's order by the fc_out kernel."""
+        scattered back to the caller's order by the fc_out kernel.
+        w0p None: HEADLESS form -- `feat` is already h0 = relu(fc_0(rows)) (the fused gather produced it) and the
+        gradient returned for it is the one wrt fc_0's pre-activation (h0's ReLU mask applied), the contract of
+        _EncoderGatherFn's fused backward."""
+        ctx.headless = w0p is None
+        if ctx.headless:
+            h0 = feat
+            h1 = ops.linear_fwd(h0, w1, b1, relu=True)
+            h2 = ops.linear_fwd(h1, w2, b2, relu=True)
+            logits = ops.fc_out_fwd(h2, wo, bo, row_map)
+            ctx.save_for_backward(w1, w2, wo, h0, h1, h2)
+            ctx.row_map = row_map
+            return logits
         h0 = ops.linear_fwd(feat, w0p, b0, relu=True)
         h1 = ops.linear_fwd(h0, w1, b1, relu=True)
         h2 = ops.linear_fwd(h1, w2, b2, relu=True)
@@ -333,6 +394,14 @@ class _PointMLPFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dlogits):
+        if ctx.headless:
+            w1, w2, wo, h0, h1, h2 = ctx.saved_tensors
+            dh2, dwo, dbo = ops.fc_out_bwd(h2, wo, dlogits.contiguous(), ctx.row_map)
+            dw2, db2 = ops.linear_bwd_weight(dh2, h1)
+            dh1 = ops.linear_bwd_data(dh2, w2, mask=h1)
+            dw1, db1 = ops.linear_bwd_weight(dh1, h0)
+            dz0 = ops.linear_bwd_data(dh1, w1, mask=h0)
+            return dz0, None, None, None, dw1, db1, dw2, db2, dwo, dbo, None
         feat, w0p, w1, w2, wo, h0, h1, h2 = ctx.saved_tensors
         dh2, dwo, dbo = ops.fc_out_bwd(h2, wo, dlogits.contiguous(), ctx.row_map)   # dh2 already masked by h2 > 0
         dw2, db2 = ops.linear_bwd_weight(dh2, h1)
@@ -403,13 +472,13 @@ class _ExtractorBase(nn.Module):
     def feature_rows_from_levels(self, levels, points, order=None):
         return ops.gather_fwd(levels, points.float().contiguous(), self._layout, self._disp, self._align, order=order)
 
-    def feature_rows(self, x, points, link=None, w0p=None):
+    def feature_rows(self, x, points, link=None, w0p=None, b0=None):
         """(B*N, FS) rows in the internal column layout (what the point MLP consumes).  link / w0p: the backward-only
         projection of the wide levels (IFNet.forward wires it; the encoder's backward then also returns its share of
         fc_0's weight gradient)."""
         if not x.is_cuda:
             raise RuntimeError("IF-Net HIP path needs GPU tensors (no CPU fallback)")
-        return _EncoderGatherFn.apply(self, torch.is_grad_enabled(), link, w0p, x.float(), points.float(), *self._param_list)
+        return _EncoderGatherFn.apply(self, torch.is_grad_enabled(), link, w0p, b0, x.float(), points.float(), *self._param_list)
 
     def forward(self, x, points):
         """Reference layout (B, sumC, 1, 7, N) -- model/ifnet.py:197; used by API-compat callers."""
@@ -527,8 +596,12 @@ class IFNet(nn.Module):
             row_map, points = ops.morton_order(points, want_sorted=True)
         if levels[0].dtype == torch.bfloat16:
             return self._query_bf16(levels, points, row_map)
-        rows = self.ifnet_feature_extractor.feature_rows_from_levels(levels, points)
-        h = ops.linear_fwd(rows, self._fc0_internal(), self.fc_0.bias, relu=True)
+        ext = self.ifnet_feature_extractor
+        if FUSE_FC0 and ops.gather_fc0_supported(levels, points, ext._layout, ext._disp, ext._align, self.fc_0.out_channels):
+            h, _ = ops.gather_fc0_fwd(levels, points, ext._layout, ext._disp, ext._align, self._fc0_internal(), self.fc_0.bias)
+        else:
+            rows = ext.feature_rows_from_levels(levels, points)
+            h = ops.linear_fwd(rows, self._fc0_internal(), self.fc_0.bias, relu=True)
         h = ops.linear_fwd(h, self.fc_1.weight.squeeze(2), self.fc_1.bias, relu=True)
         h = ops.linear_fwd(h, self.fc_2.weight.squeeze(2), self.fc_2.bias, relu=True)
         return ops.fc_out_fwd(h, self.fc_out.weight.reshape(-1).contiguous(), self.fc_out.bias, row_map).view(B, N)
@@ -560,6 +633,14 @@ class IFNet(nn.Module):
                     ops.project_bwd_supported(B, N, (max(D >> (l - 1), 1), max(H >> (l - 1), 1), max(W >> (l - 1), 1)))]
             if wide and B * N * ext._layout.row_stride < 2 ** 31:
                 link = _ProjLink(wide, ext._layout)
+        if (FUSE_FC0 and not points.requires_grad and B * N * ext._layout.row_stride < 2 ** 31
+                and _fc0_fusable(ext._layout.channels, B, x.shape[2:], self.fc_0.out_channels)):
+            h0 = ext.feature_rows(x, points, link, w0p, self.fc_0.bias)
+            logits = _PointMLPFn.apply(h0, row_map, None, None,
+                                       self.fc_1.weight.squeeze(2), self.fc_1.bias,
+                                       self.fc_2.weight.squeeze(2), self.fc_2.bias,
+                                       self.fc_out.weight.reshape(-1), self.fc_out.bias, None)
+            return logits.view(B, N)
         rows = ext.feature_rows(x, points, link, w0p if link is not None else None)
         logits = _PointMLPFn.apply(rows, row_map, w0p, self.fc_0.bias,
                                    self.fc_1.weight.squeeze(2), self.fc_1.bias,

@@ -201,6 +201,39 @@ def gather_fwd(vols, points, layout, displacement, align_corners, out=None, orde
     return out
 
 
+def gather_fc0_supported(vols, points, layout, displacement, align_corners, n_out=256):
+    B, N, _ = points.shape
+    if n_out != 256 or not points.is_cuda:
+        return False
+    d = make_gather_desc(vols, None, layout, B, N, displacement, align_corners)
+    return bool(_lib.lib().svr_gather_fc0_supported(C.byref(d)))
+
+
+def gather_fc0_fwd(vols, points, layout, displacement, align_corners, w, bias, relu=True, keep_levels=()):
+    """h0 (B*N, 256) = [relu](feature_rows(vols, points) @ w.T + bias) without materialising the feature rows (gather_fc0.hip).
+    keep_levels: levels whose gathered columns are also stored -> (h0, rows) with rows (B*N, row_stride) valid ONLY in
+    those levels' columns and the padding columns (the rest is uninitialised memory); () -> (h0, None)."""
+    B, N, _ = points.shape
+    _f32(points, w, bias)
+    d = make_gather_desc(vols, None, layout, B, N, displacement, align_corners)
+    l = _lib.lib()
+    n_out = w.shape[0]
+    assert w.stride(1) == 1 and w.shape[1] >= layout.width
+    ws_bytes = l.svr_gather_fc0_workspace(C.byref(d), n_out)
+    if ws_bytes <= 0:
+        raise RuntimeError("gather_fc0_fwd: unsupported level shapes (see svr_gather_fc0_supported)")
+    ws = torch.empty(ws_bytes, device=points.device, dtype=torch.uint8)
+    out = torch.empty(B * N, n_out, device=points.device, dtype=torch.float32)
+    mask = 0
+    for lv in keep_levels:
+        mask |= 1 << lv
+    rows = torch.empty(B * N, layout.row_stride, device=points.device, dtype=torch.float32) if mask else None
+    epi = EPI_NONE if bias is None else (EPI_BIAS_RELU if relu else EPI_BIAS)
+    check(l.svr_gather_fc0_fwd(C.byref(d), _p(points), C.c_void_p(w.data_ptr()), w.stride(0), _p(bias), _p(out), out.stride(0),
+                               n_out, _p(rows), mask, epi, _p(ws), _stream()), "gather_fc0_fwd")
+    return out, rows
+
+
 def gather_bwd(vols, gvols, points, gfeat, layout, displacement, align_corners, want_gpoints=False, order=None,
                level_orders=None, flags=0, level_plans=None):
     """level_plans[l] (PullPlan or None): that level is scattered atomic-free in pull form and its gvol OVERWRITTEN

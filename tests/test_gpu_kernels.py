@@ -503,3 +503,40 @@ def test_projected_scatter_of_dh_rows(dims, align, N, B):
         (out[:, :, 0, 0].permute(0, 2, 1) * dh.view(B, N, 256)).sum().backward()
         ref = vol.grad.permute(0, 2, 3, 4, 1).reshape(B, -1, 256)
         assert G.rel_err(dP[:, :, j].numpy(), ref.numpy()) < 1e-5, j
+
+
+@pytest.mark.parametrize("chans,ac", [([1, 16, 32, 64, 128, 128], False), ([1, 32, 64, 128], True)], ids=["arch128", "arch32"])
+@pytest.mark.parametrize("B,dims,N,spread", [(2, (16, 16, 16), 777, 1.0), (1, (35, 26, 28), 500, 1.3), (3, (32, 32, 32), 1, 1.0),
+                                             (2, (24, 24, 24), 1280, 1.05)])
+def test_fused_gather_fc0_equals_gather_then_linear(B, dims, N, spread, chans, ac):
+    """gather_fc0.hip against the two kernels it fuses (model/ifnet.py:156-197 + fc_0 :43-45,55): the kept feature
+    columns are bit-identical to svr_gather_trilinear_fwd's (same geometry, same corner order), h0 agrees with
+    svr_linear_fwd_f16x3 on those rows to f32 rounding of a different summation order over K (1e-6 of the row scale),
+    and with the float64 product of the oracle's grid_sample features to 2e-6 (the gate of the GEMM itself)."""
+    ops = _ops()
+    vols = _rand_levels(B, dims, chans, 15)
+    g = torch.Generator().manual_seed(16)
+    pts = ((torch.rand(B, N, 3, generator=g) - 0.5) * spread).cuda()
+    layout = ops.FeatureLayout(chans)
+    vols_g = [_cl(v) for v in vols]
+    disp = float(np.float32(0.0722))
+    w = (torch.randn(256, layout.row_stride, generator=g) / 30).cuda()
+    w[:, layout.width:] = 0
+    bias = torch.randn(256, generator=g).cuda()
+    assert ops.gather_fc0_supported(vols_g, pts, layout, disp, ac)
+    rows = ops.gather_fwd(vols_g, pts, layout, disp, ac)
+    want = ops.linear_fwd(rows, w, bias, relu=True)
+    keep = [l for l, c in enumerate(chans) if c < 128]
+    h0, kept = ops.gather_fc0_fwd(vols_g, pts, layout, disp, ac, w, bias, relu=True, keep_levels=keep)
+    for l in keep:
+        a, b = layout.col[l], layout.col[l] + 7 * chans[l]
+        assert torch.equal(kept[:, a:b], rows[:, a:b]), f"level {l}"
+    assert torch.all(kept[:, layout.width:] == 0)
+    scale = float(want.abs().max())
+    assert float((h0 - want).abs().max()) <= 1e-6 * scale
+    ref = torch.relu(rows.double().cpu() @ w.double().cpu().t() + bias.double().cpu())
+    assert float((h0.cpu().double() - ref).abs().max()) <= 2e-6 * scale
+    # inference form: no rows, no ReLU
+    h0n, none = ops.gather_fc0_fwd(vols_g, pts, layout, disp, ac, w, bias, relu=False)
+    assert none is None
+    assert torch.equal(torch.relu(h0n), h0)

@@ -30,7 +30,7 @@ for f in glob.glob(f"{R}/gpurun_out/pmc_traffic_*/**/*counter_collection.csv", r
     rd = csv.DictReader(open(f))
     for r in rd:
         n = r["Kernel_Name"]
-        for key in ("gather_fwd_fused_kernel", "gather_bwd_fused_kernel", "gather_bwd_pull_kernel<16", "gather_bwd_pull_kernel<32",
+        for key in ("gather_fc0_kernel", "gather_bwd_proj_kernel", "gather_fwd_fused_kernel", "gather_bwd_fused_kernel", "gather_bwd_pull_kernel<16", "gather_bwd_pull_kernel<32",
                     "gather_bwd_pull_kernel<64"):
             if key in n:
                 agg[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
@@ -52,6 +52,11 @@ if "FETCH_SIZE_KB" in f and "WRITE_SIZE_KB" in f:
     out["fetch_bytes_corrected_x2"] = 2 * fetch     # gfx950: FETCH_SIZE counts 128-B requests at 64 B (guide, section HBM)
     out["write_bytes"] = f["WRITE_SIZE_KB"] * 1024
     out["hbm_bytes_per_launch"] = 2 * fetch + f["WRITE_SIZE_KB"] * 1024
+g = out.get("gather_fc0_kernel", {})
+if "FETCH_SIZE_KB" in g and "WRITE_SIZE_KB" in g:
+    out["fused_fetch_bytes_corrected_x2"] = 2 * g["FETCH_SIZE_KB"] * 1024
+    out["fused_write_bytes"] = g["WRITE_SIZE_KB"] * 1024
+    out["fused_hbm_bytes_per_launch"] = 2 * g["FETCH_SIZE_KB"] * 1024 + g["WRITE_SIZE_KB"] * 1024
 hbm = 0.0
 for k in list(out):
     if k.startswith("gather_bwd_") and isinstance(out[k], dict) and "WRITE_SIZE_KB" in out[k] and "FETCH_SIZE_KB" in out[k]:
