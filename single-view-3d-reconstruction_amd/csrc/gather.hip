@@ -486,6 +486,9 @@ __device__ __forceinline__ void gather_bwd_runs_body(const LevelArgs L, const fl
 // two runs kept open across the repetitions: the atomics issued for the 128-channel levels drop from ~0.8 GB to ~0.15 GB
 // and the kernel is bound by reading the gradient rows (1.43 GB per 128-channel level).
 constexpr int kItemReps = 4;
+// the projected scatter (one wave per 128 items and repetition): shorter walks -- 2.7 rounds of workgroups instead of 1.3
+// with a two-thirds empty second one
+constexpr int kProjReps = 2;
 
 // CPL = channels per lane: 2 for C >= 32 (lane l owns channels l and l + CW: half the lanes per item, so the geometry
 // broadcast, the run logic and the shuffles are paid once per two channels: levels 3/4/5 0.45/0.53/0.51 -> 0.36/0.43/0.38 ms
@@ -493,7 +496,7 @@ constexpr int kItemReps = 4;
 // PROJ (backward-only projection of a wide level, see gather_bwd_proj_kernel): the source row is the item's dh0 row (C = 256
 // values at pn * row_stride, the same for all 7 displacements), the destination is dP[b][voxel][j][C] and a run is one
 // (sample, displacement, cell): the displacement rides in the low 3 bits of the run's sample id.
-template <int C, int CPL, bool PROJ = false>
+template <int C, int CPL, bool PROJ = false, int REPS = kItemReps>
 __device__ __forceinline__ void gather_bwd_items_body(const LevelArgs L, const float *__restrict__ points,
                                                       const float *__restrict__ gfeat, int64_t T, int N, int row_stride,
                                                       float disp, int ac, int64_t witem, int64_t waves) {
@@ -507,7 +510,7 @@ __device__ __forceinline__ void gather_bwd_items_body(const LevelArgs L, const f
   const int cg = (int)(witem % CG);
   const int64_t nchunks = waves / CG;
   const int64_t cperm = ((witem / CG) * 1000003LL) % nchunks;  // spread concurrently running waves over distant cells
-  const int64_t base_i = (cperm * G + grp) * (int64_t)(PG * kItemReps);
+  const int64_t base_i = (cperm * G + grp) * (int64_t)(PG * REPS);
   const int64_t vol = (int64_t)L.D * L.H * L.W;
   float *gl = L.gvol + cg * CW * CPL + ch;
 
@@ -551,8 +554,8 @@ __device__ __forceinline__ void gather_bwd_items_body(const LevelArgs L, const f
     }
     flush(cur1, b1, acc1, skip);
   };
-  constexpr int UNR = PROJ ? 2 : 4;   // PROJ: 4 channels per lane -> 8 gradient registers per block already
-  for (int rep = 0; rep < kItemReps; ++rep) {
+  constexpr int UNR = 4;   // items per block of loads; two blocks in flight (the dh rows come from the Infinity Cache / HBM: latency bound)
+  for (int rep = 0; rep < REPS; ++rep) {
     const int64_t i0 = base_i + (int64_t)rep * PG;
     const int cnt = (int)min((int64_t)PG, T - i0);  // items of this repetition (<= 0: none)
     if (cnt <= 0) break;                            // uniform within the group
@@ -632,14 +635,35 @@ __device__ __forceinline__ void gather_bwd_items_body(const LevelArgs L, const f
         }
         const float wx1 = xq, wx0 = 1.f - wx1, wy1 = yq, wy0 = 1.f - wy1, wz1 = zq, wz0 = 1.f - wz1;
         const float w00 = wy0 * wz0, w10 = wy1 * wz0, w01 = wy0 * wz1, w11 = wy1 * wz1;
+        // the walk is bound by the VALU instructions it issues (one item = 8 corners x CPL channels): explicit FMAs
+        // (the file is built with contraction off for the index arithmetic; a scatter has no summation order to keep)
+        // and, for an even CPL, channel PAIRS so they become v_pk_mul_f32 / v_pk_fma_f32
+        if constexpr (CPL % 2 == 0) {
+          typedef float f2 __attribute__((ext_vector_type(2)));
 #pragma unroll
-        for (int p = 0; p < CPL; ++p) {
-          const float g = gq[u * CPL + p];
-          const float a00 = w00 * g, a10 = w10 * g, a01 = w01 * g, a11 = w11 * g;
-          acc0[0 * CPL + p] += wx0 * a00; acc0[1 * CPL + p] += wx1 * a00;
-          acc0[2 * CPL + p] += wx0 * a10; acc0[3 * CPL + p] += wx1 * a10;
-          acc0[4 * CPL + p] += wx0 * a01; acc0[5 * CPL + p] += wx1 * a01;
-          acc0[6 * CPL + p] += wx0 * a11; acc0[7 * CPL + p] += wx1 * a11;
+          for (int p = 0; p < CPL; p += 2) {
+            const f2 g = {gq[u * CPL + p], gq[u * CPL + p + 1]};
+            const f2 a00 = g * w00, a10 = g * w10, a01 = g * w01, a11 = g * w11;
+#define SVR_ACC2(K, WX, A)                                                                     \
+  {                                                                                            \
+    const f2 r = __builtin_elementwise_fma(f2{WX, WX}, A, f2{acc0[K * CPL + p], acc0[K * CPL + p + 1]}); \
+    acc0[K * CPL + p] = r.x;                                                                   \
+    acc0[K * CPL + p + 1] = r.y;                                                               \
+  }
+            SVR_ACC2(0, wx0, a00) SVR_ACC2(1, wx1, a00) SVR_ACC2(2, wx0, a10) SVR_ACC2(3, wx1, a10)
+            SVR_ACC2(4, wx0, a01) SVR_ACC2(5, wx1, a01) SVR_ACC2(6, wx0, a11) SVR_ACC2(7, wx1, a11)
+#undef SVR_ACC2
+          }
+        } else {
+#pragma unroll
+          for (int p = 0; p < CPL; ++p) {
+            const float g = gq[u * CPL + p];
+            const float a00 = w00 * g, a10 = w10 * g, a01 = w01 * g, a11 = w11 * g;
+            acc0[0 * CPL + p] = __builtin_fmaf(wx0, a00, acc0[0 * CPL + p]); acc0[1 * CPL + p] = __builtin_fmaf(wx1, a00, acc0[1 * CPL + p]);
+            acc0[2 * CPL + p] = __builtin_fmaf(wx0, a10, acc0[2 * CPL + p]); acc0[3 * CPL + p] = __builtin_fmaf(wx1, a10, acc0[3 * CPL + p]);
+            acc0[4 * CPL + p] = __builtin_fmaf(wx0, a01, acc0[4 * CPL + p]); acc0[5 * CPL + p] = __builtin_fmaf(wx1, a01, acc0[5 * CPL + p]);
+            acc0[6 * CPL + p] = __builtin_fmaf(wx0, a11, acc0[6 * CPL + p]); acc0[7 * CPL + p] = __builtin_fmaf(wx1, a11, acc0[7 * CPL + p]);
+          }
         }
       }
     };
@@ -674,12 +698,12 @@ __global__ __launch_bounds__(256) void gather_bwd_proj_kernel(LevelArgs L, const
                                                               const float *__restrict__ dh, int64_t T, int N, int lddh,
                                                               float disp, int ac, int64_t waves) {
   const int64_t witem = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
-  gather_bwd_items_body<256, 4, true>(L, points, dh, T, N, lddh, disp, ac, witem, waves);
+  gather_bwd_items_body<256, 4, true, kProjReps>(L, points, dh, T, N, lddh, disp, ac, witem, waves);
 }
 
-__host__ __device__ inline int64_t bwd_items_waves_cpl(int C, int cpl, int64_t T) {
+__host__ __device__ inline int64_t bwd_items_waves_cpl(int C, int cpl, int64_t T, int reps = kItemReps) {
   const int cw = (C / cpl) < 64 ? (C / cpl) : 64;
-  const int64_t per = (int64_t)(64 / cw) * 2 * cw * kItemReps;  // items per wave
+  const int64_t per = (int64_t)(64 / cw) * 2 * cw * reps;  // items per wave
   return svr::cdiv(T, per) * (C / (cw * cpl));
 }
 __host__ __device__ inline int64_t bwd_items_waves(int C, int64_t T) { return bwd_items_waves_cpl(C, items_cpl(C), T); }
@@ -1215,7 +1239,7 @@ extern "C" int svr_gather_project_bwd(const float *points, const float *dh, int6
   SVR_CHECK(T < (1LL << 31) && (int64_t)B * N * lddh < (1LL << 31) && lddh >= 256, SVR_E_UNSUPPORTED,
             "project_bwd: needs 32-bit item / row offsets and rows of >= 256 floats");
   LevelArgs L{nullptr, dP, 256, D, H, W, 0, nullptr, items};
-  const int64_t waves = bwd_items_waves_cpl(256, 4, T);
+  const int64_t waves = bwd_items_waves_cpl(256, 4, T, kProjReps);
   hipLaunchKernelGGL(gather_bwd_proj_kernel, dim3((unsigned)svr::cdiv(waves * 64, 256)), dim3(256), 0, (hipStream_t)stream, L, points,
                      dh, T, N, (int)lddh, displacement, align_corners, waves);
   return svr::launch_status("project_bwd");
