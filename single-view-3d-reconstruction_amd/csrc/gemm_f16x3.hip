@@ -44,9 +44,15 @@ __device__ __forceinline__ f16x8 read_frag(const uint32_t *plane, int row, int l
   return f.v;
 }
 
-// W[N][K] f32 -> planes [N][K] f16: hi(Ws), lo(Ws)
+// W[N][K] f32 -> f16 planes hi(Ws), lo(Ws), K-STEP MAJOR: [k-step][hi / lo][n][16 halves].  A workgroup's W tile of one
+// k-step is then one contiguous 4 KB block per plane (16 bytes per thread); row-major planes [N][K] gave every thread a
+// 16-byte piece of a different 128-byte line, of which only 32 bytes belong to the k-step, and the three workgroups
+// of a CU evicted the lines from the 32 KB L1 before the next k-step came back for them: 4x the W bytes through L2.
+__device__ __forceinline__ int64_t wplane_index(int64_t k, int plane, int64_t n, int64_t N) {
+  return (((k >> 4) * 2 + plane) * N + n) * 16 + (k & 15);
+}
 __global__ void split_w_kernel(const float *__restrict__ W, int64_t ldw, const uint32_t *__restrict__ amax,
-                               uint16_t *__restrict__ p0, uint16_t *__restrict__ p1, int64_t N, int64_t K) {
+                               uint16_t *__restrict__ p0, int64_t N, int64_t K) {
   int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // over (n, k/2)
   if (idx >= N * (K / 2)) return;
   const int64_t n = idx / (K / 2), k = (idx % (K / 2)) * 2;
@@ -54,8 +60,8 @@ __global__ void split_w_kernel(const float *__restrict__ W, int64_t ldw, const u
   const float w0 = W[n * ldw + k] * sc, w1 = W[n * ldw + k + 1] * sc;
   const uint32_t hi = pack_f16(w0, w1);
   const f32x2 h = unpack_f16(hi);
-  *reinterpret_cast<uint32_t *>(p0 + n * K + k) = hi;
-  *reinterpret_cast<uint32_t *>(p1 + n * K + k) = pack_f16(w0 - h.x, w1 - h.y);
+  *reinterpret_cast<uint32_t *>(p0 + wplane_index(k, 0, n, N)) = hi;
+  *reinterpret_cast<uint32_t *>(p0 + wplane_index(k, 1, n, N)) = pack_f16(w0 - h.x, w1 - h.y);
 }
 
 
@@ -68,7 +74,7 @@ __global__ void split_w_kernel(const float *__restrict__ W, int64_t ldw, const u
 // as the MFMAs of step k and can be issued between them (MFMA co-execution); one barrier per step.
 template <int TN, int NX, int SCHED>
 __global__ __launch_bounds__(2 * TN, 1024 / (2 * TN) >= 4 ? 3 : 2) void linear_nt_h3_kernel(
-    const float *__restrict__ X, int64_t ldx, const uint16_t *__restrict__ W0, const uint16_t *__restrict__ W1,
+    const float *__restrict__ X, int64_t ldx, const uint16_t *__restrict__ W0,
     const uint32_t *__restrict__ amax, const float *__restrict__ bias, float *__restrict__ Y, int64_t ldy, int64_t M,
     int64_t N, int64_t K, int relu) {
   constexpr int NT = 2 * TN, BPLANE = TN * YLW, XPT = 512 / NT, STAGE = 2 * APLANE + 2 * BPLANE;
@@ -92,7 +98,7 @@ __global__ __launch_bounds__(2 * TN, 1024 / (2 * TN) >= 4 ? 3 : 2) void linear_n
   }
   int64_t wrow = n0 + (t >> 1);
   wrow = wrow < N ? wrow : N - 1;
-  const int64_t woff = wrow * K + (t & 1) * 8;      // TN rows x 16 halves per plane: 16 bytes per thread
+  const int64_t woff = wrow * 16 + (t & 1) * 8;     // TN rows x 16 halves per plane and k-step: 16 bytes per thread, contiguous
   struct Regs {
     float4 x[XPT];
     uint4 w[2];
@@ -111,8 +117,9 @@ __global__ __launch_bounds__(2 * TN, 1024 / (2 * TN) >= 4 ? 3 : 2) void linear_n
         r.x[i] = *reinterpret_cast<const float4 *>(xp[i] + k0);
       }
     }
-    r.w[0] = *reinterpret_cast<const uint4 *>(W0 + woff + k0);
-    r.w[1] = *reinterpret_cast<const uint4 *>(W1 + woff + k0);
+    const uint16_t *wk = W0 + (k0 >> 4) * (2 * N * 16) + woff;  // k-step major planes (split_w_kernel)
+    r.w[0] = *reinterpret_cast<const uint4 *>(wk);
+    r.w[1] = *reinterpret_cast<const uint4 *>(wk + N * 16);
   };
   auto store = [&](const Regs &r, uint32_t *st) {
 #pragma unroll
@@ -222,20 +229,19 @@ extern "C" int svr_linear_fwd_f16x3(const float *X, int64_t ldx, const float *W,
   hipStream_t s = (hipStream_t)stream;
   uint32_t *amax = (uint32_t *)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
   uint16_t *p0 = (uint16_t *)(amax + 64);
-  uint16_t *p1 = p0 + N * K;
   (void)hipMemsetAsync(amax, 0, sizeof(uint32_t), s);
   hipLaunchKernelGGL(w_amax_kernel, dim3((unsigned)std::min<int64_t>(cdiv(N * K, 1024), 1024)), dim3(256), 0, s, W, ldw, N, K, amax);
-  hipLaunchKernelGGL(split_w_kernel, dim3((unsigned)cdiv(N * (K / 2), 256)), dim3(256), 0, s, W, ldw, amax, p0, p1, N, K);
+  hipLaunchKernelGGL(split_w_kernel, dim3((unsigned)cdiv(N * (K / 2), 256)), dim3(256), 0, s, W, ldw, amax, p0, N, K);
   const float *eb = epilogue == SVR_EPI_NONE ? nullptr : bias;
   const int relu = epilogue == SVR_EPI_BIAS_RELU ? 1 : 0;
   // SCHED = 2 (one MFMA, a slice of the split, one LDS store, ...): 2.39 ms at 400 000 x 2592 x 256 against 2.49 for
   // the compiler's own order and 2.50 for iglp_opt(0)
   if (N <= 64) {  // narrow outputs (the UNet's 32- and 64-channel layers): 128 x 64 tiles, two waves, half the wasted columns
     dim3 grid(xcd_grid(cdiv(N, 64) * cdiv(M, TM)));
-    hipLaunchKernelGGL((linear_nt_h3_kernel<64, 0, 2>), grid, dim3(128), 0, s, X, ldx, p0, p1, amax, eb, Y, ldy, M, N, K, relu);
+    hipLaunchKernelGGL((linear_nt_h3_kernel<64, 0, 2>), grid, dim3(128), 0, s, X, ldx, p0, amax, eb, Y, ldy, M, N, K, relu);
     return launch_status("linear_fwd_f16x3");
   }
   dim3 grid(xcd_grid(cdiv(N, 128) * cdiv(M, TM)));
-  hipLaunchKernelGGL((linear_nt_h3_kernel<128, 0, 2>), grid, dim3(256), 0, s, X, ldx, p0, p1, amax, eb, Y, ldy, M, N, K, relu);
+  hipLaunchKernelGGL((linear_nt_h3_kernel<128, 0, 2>), grid, dim3(256), 0, s, X, ldx, p0, amax, eb, Y, ldy, M, N, K, relu);
   return launch_status("linear_fwd_f16x3");
 }

@@ -12,6 +12,7 @@ Every arithmetic step runs in the HIP kernels of libsvr_hip.so (include/svr_hip.
 nn.Conv3d / nn.BatchNorm3d / nn.Conv1d submodules only HOLD the parameters and buffers; their
 torch forward is never called.  There is no CPU fallback.
 """
+import contextlib
 import os
 
 import torch
@@ -146,6 +147,8 @@ PROJECT_WIDE_LEVELS = os.environ.get("SVR_NO_PROJECTION") is None
 # Fused gather -> fc_0 forward (gather_fc0.hip): the feature rows are never written to HBM; only the columns a backward
 # still needs (the levels that are not projected) are kept.  SVR_NO_FUSED_FC0=1 restores the two separate kernels.
 FUSE_FC0 = os.environ.get("SVR_NO_FUSED_FC0") is None
+# Fused + projected backward: the kept-column branch on the side stream beside the projected branch (SVR_NO_BWD_OVERLAP=1: serial)
+OVERLAP_BACKWARD = os.environ.get("SVR_NO_BWD_OVERLAP") is None
 
 
 def _fc0_fusable(channels, B, dims, n_out):
@@ -273,26 +276,6 @@ class _EncoderGatherFn(torch.autograd.Function):
         link = ctx.link
         proj = link.levels if link is not None else ()
         dw0_keep = db0 = None
-        if ctx.fused:
-            # fused forward: fc_0's backward lives here.  gfeat is dz0 (B*N, 256); dW0 / dX0 only over the kept columns
-            dh0, feat, w0p = gfeat, ctx.feat, ctx.w0p
-            ctx.feat = None
-            keep = link.keep if link is not None else [(0, ext._layout.row_stride)]
-            dw0_keep = torch.zeros_like(w0p)
-            gfeat = torch.empty_like(feat)           # the projected levels' columns are never read
-            lvl0 = ext._layout.col[0]
-            for a, b in keep:
-                dws, dbs = ops.linear_bwd_weight(dh0, feat[:, a:b], want_bias=db0 is None)
-                dw0_keep[:, a:b] = dws
-                db0 = dbs if db0 is None else db0
-                if a == lvl0 and not need_x and link is not None:
-                    continue                         # raw-grid columns: their gradient is only needed for d(loss)/d(input)
-                ops.linear_bwd_data(dh0, w0p[:, a:b], out=gfeat[:, a:b])
-            del feat
-            if link is not None:
-                link.dh0 = dh0
-        if link is not None and link.dh0 is None:
-            raise RuntimeError("IF-Net HIP path: the projected backward needs dh0 from the point MLP's backward")
         level_orders, level_plans = ctx.level_orders, ctx.level_plans
         if level_orders is None:
             level_orders, level_plans, ready = _level_orders_async(pts, *levels[0].shape[1:4], len(levels), ext._align,
@@ -309,16 +292,57 @@ class _EncoderGatherFn(torch.autograd.Function):
             gvols = [torch.zeros_like(levels[0]) if need_x else None] + \
                     [None if l in proj else (torch.empty_like(v) if level_plans[l] is not None else torch.zeros_like(v))
                      for l, v in enumerate(levels) if l >= 1]
-        if ready is not None:
-            torch.cuda.current_stream().wait_event(ready)
-        gpts = ops.gather_bwd(levels, gvols, pts, gfeat, ext._layout, ext._disp, ext._align, want_gpoints=need_pts,
-                              level_orders=[None if l in proj else o for l, o in enumerate(level_orders)],
-                              level_plans=level_plans)
+        main = torch.cuda.current_stream() if gfeat.is_cuda else None
+        # Fused forward + projection: the backward of the KEPT columns (dW0 / dX0 over 800 columns, then the scatter of
+        # levels 1-3) and the backward of the PROJECTED levels (row scatter + voxel GEMMs) only share dh0 as an input;
+        # neither saturates the chip (GEMMs at 2-3x their memory floor, scatters latency / atomics bound), so the kept
+        # branch runs on the side stream beside the projected one and the two join in front of the encoder's backward.
+        fork = (ctx.fused and link is not None and main is not None and OVERLAP_BACKWARD
+                and not torch.cuda.is_current_stream_capturing())      # (a captured step keeps the serial order)
+        keep_stream = _get_side_stream(gfeat.device) if fork else main
+        if ctx.fused:
+            # fused forward: fc_0's backward lives here.  gfeat is dz0 (B*N, 256); dW0 / dX0 only over the kept columns
+            dh0, feat, w0p = gfeat, ctx.feat, ctx.w0p
+            ctx.feat = None
+            keep = link.keep if link is not None else [(0, ext._layout.row_stride)]
+            dw0_keep = torch.zeros_like(w0p)
+            if fork:
+                keep_stream.wait_stream(main)
+                for t in (dh0, feat, w0p, dw0_keep, pts) + tuple(g for g in gvols if g is not None):
+                    t.record_stream(keep_stream)
+            with torch.cuda.stream(keep_stream) if fork else contextlib.nullcontext():
+                gfeat = torch.empty_like(feat)           # the projected levels' columns are never read
+                lvl0 = ext._layout.col[0]
+                for a, b in keep:
+                    dws, dbs = ops.linear_bwd_weight(dh0, feat[:, a:b], want_bias=db0 is None)
+                    dw0_keep[:, a:b] = dws
+                    db0 = dbs if db0 is None else db0
+                    if a == lvl0 and not need_x and link is not None:
+                        continue                         # raw-grid columns: their gradient is only needed for d(loss)/d(input)
+                    ops.linear_bwd_data(dh0, w0p[:, a:b], out=gfeat[:, a:b])
+            del feat
+            if link is not None:
+                link.dh0 = dh0
+        if link is not None and link.dh0 is None:
+            raise RuntimeError("IF-Net HIP path: the projected backward needs dh0 from the point MLP's backward")
+        with torch.cuda.stream(keep_stream) if fork else contextlib.nullcontext():
+            if ready is not None:
+                torch.cuda.current_stream().wait_event(ready)
+            gpts = ops.gather_bwd(levels, gvols, pts, gfeat, ext._layout, ext._disp, ext._align, want_gpoints=need_pts,
+                                  level_orders=[None if l in proj else o for l, o in enumerate(level_orders)],
+                                  level_plans=level_plans)
+            if fork:
+                keep_done = torch.cuda.Event()
+                keep_done.record(keep_stream)
+                for t in (db0, gfeat) + tuple(g for g in gvols if g is not None):
+                    t.record_stream(main)
         dw0p = None
         if proj:
             # projected levels: dP = scatter of the dh0 rows, then two GEMMs over voxels (see gather_bwd_proj_kernel)
             lay, w0p, dh0 = ext._layout, ctx.w0p, link.dh0
             link.dh0 = None
+            if fork and ready is not None:
+                main.wait_event(ready)
             dw0p = dw0_keep if dw0_keep is not None else torch.zeros_like(w0p)
             for l in proj:
                 v = levels[l]
@@ -331,6 +355,8 @@ class _EncoderGatherFn(torch.autograd.Function):
                 dwl, _ = ops.linear_bwd_weight(dP2, v.view(-1, Cl), want_bias=False)                                # (7*256, Cl)
                 dw0p[:, c0:c0 + 7 * Cl] = dwl.view(7, 256, Cl).permute(1, 0, 2).reshape(256, 7 * Cl)
                 del dP, dP2
+        if fork:
+            main.wait_event(keep_done)
         grads = {}
         dpooled = None
         gx = None
