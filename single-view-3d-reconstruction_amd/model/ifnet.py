@@ -42,16 +42,18 @@ def _displacements(d):
     return torch.tensor(rows)
 
 
-_side_stream = None
+_side_streams = {}
 
 
-def _get_side_stream(device):
-    global _side_stream
+def _get_side_stream(device, which=0):
+    """Side stream `which` of a device (0: plans / orders in the forward and the kept-column branch of the backward;
+    1: the kept columns' weight gradient)."""
     if os.environ.get("SVR_NO_SIDE_STREAM"):      # measurement switch: everything on the caller's stream
         return torch.cuda.current_stream(device)
-    if _side_stream is None or _side_stream.device != device:
-        _side_stream = torch.cuda.Stream(device=device)
-    return _side_stream
+    key = (torch.device(device).index, which)
+    if key not in _side_streams:
+        _side_streams[key] = torch.cuda.Stream(device=device)
+    return _side_streams[key]
 
 
 # Backward scatter form per level (gather.hip):
@@ -310,13 +312,23 @@ class _EncoderGatherFn(torch.autograd.Function):
                 keep_stream.wait_stream(main)
                 for t in (dh0, feat, w0p, dw0_keep, pts) + tuple(g for g in gvols if g is not None):
                     t.record_stream(keep_stream)
-            with torch.cuda.stream(keep_stream) if fork else contextlib.nullcontext():
-                gfeat = torch.empty_like(feat)           # the projected levels' columns are never read
-                lvl0 = ext._layout.col[0]
+            lvl0 = ext._layout.col[0]
+            # dW0 over the kept columns is a leaf (needed at the return only): third stream
+            w_stream = _get_side_stream(gfeat.device, 1) if fork else main
+            if fork:
+                w_stream.wait_stream(main)
+                for t in (dh0, feat, dw0_keep):
+                    t.record_stream(w_stream)
+            with torch.cuda.stream(w_stream) if fork else contextlib.nullcontext():
                 for a, b in keep:
                     dws, dbs = ops.linear_bwd_weight(dh0, feat[:, a:b], want_bias=db0 is None)
                     dw0_keep[:, a:b] = dws
                     db0 = dbs if db0 is None else db0
+                if fork:
+                    db0.record_stream(main)
+            with torch.cuda.stream(keep_stream) if fork else contextlib.nullcontext():
+                gfeat = torch.empty_like(feat)           # the projected levels' columns are never read
+                for a, b in keep:
                     if a == lvl0 and not need_x and link is not None:
                         continue                         # raw-grid columns: their gradient is only needed for d(loss)/d(input)
                     ops.linear_bwd_data(dh0, w0p[:, a:b], out=gfeat[:, a:b])
@@ -334,7 +346,7 @@ class _EncoderGatherFn(torch.autograd.Function):
             if fork:
                 keep_done = torch.cuda.Event()
                 keep_done.record(keep_stream)
-                for t in (db0, gfeat) + tuple(g for g in gvols if g is not None):
+                for t in (gfeat,) + tuple(g for g in gvols if g is not None):
                     t.record_stream(main)
         dw0p = None
         if proj:
@@ -357,6 +369,7 @@ class _EncoderGatherFn(torch.autograd.Function):
                 del dP, dP2
         if fork:
             main.wait_event(keep_done)
+            main.wait_stream(w_stream)
         grads = {}
         dpooled = None
         gx = None
