@@ -15,7 +15,8 @@ LIB = os.path.join(LIBDIR, "libsvr_hip.so")
 SOURCES = {
     "capi.cpp": [],
     "gather.hip": ["-ffp-contract=off"],
-    "gather_fc0.hip": ["-ffp-contract=off"],
+    "gather_fc0.hip": ["-ffp-contract=off"] + [f"-D{k}={os.environ[e]}" for k, e in (("FC_TM", "SVR_FC_TM"), ("FC_DEPTH", "SVR_FC_DEPTH"))
+                                               if os.environ.get(e)],   # tile-shape experiments
     "sort.hip": [],
     "gemm.hip": [],
     "gemm_bf16x3.hip": [],

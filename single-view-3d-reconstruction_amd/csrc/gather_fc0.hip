@@ -33,13 +33,24 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int FK = 16;                 // reduction elements per MFMA step
 constexpr int FLW = 10;                // dwords per LDS row of one k-step (16 halves + 8 B pad, as gemm_f16x3.hip)
-constexpr int FTM = 128;               // points per workgroup
+#ifndef FC_TM
+#define FC_TM 64
+#endif
+constexpr int FTM = FC_TM;             // points per workgroup.  64 (two workgroups per CU: 128 VGPRs, 42 KB of LDS each,
+                                       // 16 waves per CU hide the producers' load latency; one pass in flight per producer
+                                       // wave) 2.58 ms at config 3 against 2.83 for 128 (one workgroup per CU, 255 VGPRs,
+                                       // three passes in flight): W is read twice as often (every 64 points), still faster
+constexpr int RPW = FTM / 4;           // rows per producer wave
+constexpr int FMT = FTM / 32;          // 32-row MFMA tiles per consumer wave
 constexpr int FTN = 256;               // output columns (fc_0's width)
 constexpr int FPLANE = FTM * FLW;      // dwords per plane and k-step
 constexpr int FKSTEP = 2 * FPLANE + 20;  // hi + lo; + 20 dwords: the k-steps of one producer store land on different banks
 constexpr int FSLAB_K = 4;             // k-steps per slab buffer
 constexpr int FSLAB = FSLAB_K * FKSTEP;
 constexpr int FC_MAX_SLABS = 44;
+#ifndef FC_DEPTH
+#define FC_DEPTH 1
+#endif
 constexpr int FC_LDS_BYTES = 2 * FSLAB * 4;
 
 struct FcLevel {
@@ -114,11 +125,11 @@ template <int LP, int NJ>
 __device__ __forceinline__ void produce_slab(const FcLevel L, const FcSlab S, uint32_t *__restrict__ buf,
                                              const float *__restrict__ points, int64_t m0, int64_t M, int N, float disp,
                                              int ac, float *__restrict__ feat, int row_stride, int pw, int lane) {
-  constexpr int PPW = 64 / LP, NP = 32 / PPW, LPI = LP / NJ, NC = LPI * 4, DEPTH = NP <= 4 ? NP : 3;  // passes in flight (the fine levels miss the caches: all of a slab's passes)
+  constexpr int PPW0 = 64 / LP, PPW = PPW0 < RPW ? PPW0 : RPW, NP = RPW / PPW, LPI = LP / NJ, NC = LPI * 4, DEPTH = NP <= FC_DEPTH ? NP : (FC_DEPTH < 3 ? FC_DEPTH : 3);  // passes in flight (the fine levels miss the caches: all of a slab's passes)
   const int C = L.C;
   const GLOBAL_AS char *vol = (const GLOBAL_AS char *)L.vol;
   // ---- phase 1
-  const int irow = 32 * pw + min(lane / NJ, 31);
+  const int irow = RPW * pw + min(lane / NJ, RPW - 1);
   const int64_t pn = min(m0 + irow, M - 1);
   const int b = (int)(pn / N);
   const Corner c = sample_corner(points + pn * 3, S.j0 + lane % NJ, disp, L.D, L.H, L.W, ac);
@@ -148,9 +159,9 @@ __device__ __forceinline__ void produce_slab(const FcLevel L, const FcSlab S, ui
   const int g = lane / LP, q = lane % LP, jj = q / LPI, c4 = (q % LPI) * 4;
   const int src0 = (g * NJ + jj) << 2;
   const int col = jj * NC + c4;  // column inside the slab
-  uint32_t *dstg = buf + (col >> 4) * FKSTEP + ((col & 15) >> 1) + (32 * pw + g) * FLW;
+  uint32_t *dstg = buf + (col >> 4) * FKSTEP + ((col & 15) >> 1) + (RPW * pw + g) * FLW;
   GLOBAL_AS char *featt = (GLOBAL_AS char *)(feat + m0 * row_stride);
-  const uint32_t fo0 = (uint32_t)((32 * pw + g) * row_stride + L.col + (S.j0 + jj) * C + S.c0 + c4) * 4u;
+  const uint32_t fo0 = (uint32_t)((RPW * pw + g) * row_stride + L.col + (S.j0 + jj) * C + S.c0 + c4) * 4u;
   const int live = M - m0 < FTM ? (int)(M - m0) : FTM;
   struct Iter {
     f32x4 v[8];
@@ -178,7 +189,7 @@ __device__ __forceinline__ void produce_slab(const FcLevel L, const FcSlab S, ui
     uint32_t *d = dstg + it * (PPW * FLW);
     *reinterpret_cast<uint2 *>(d) = make_uint2(h0, h1);
     *reinterpret_cast<uint2 *>(d + FPLANE) = make_uint2(l0, l1);
-    if (S.keep && 32 * pw + it * PPW + g < live)
+    if (S.keep && (PPW0 <= RPW || g < RPW) && RPW * pw + it * PPW + g < live)
       *reinterpret_cast<GLOBAL_AS f32x4 *>(featt + (fo0 + (uint32_t)(it * PPW * row_stride * 4))) = acc;
   };
   Iter I[DEPTH];
@@ -197,9 +208,10 @@ __device__ __forceinline__ void produce_c1(const FcLevel L, const FcSlab S, uint
                                            const float *__restrict__ points, int64_t m0, int64_t M, int N, float disp, int ac,
                                            float *__restrict__ feat, int row_stride, int tp) {
   const GLOBAL_AS float *vol = (const GLOBAL_AS float *)L.vol;
-  float u[4][8], wk[4][8];
+  constexpr int C1R = FTM * 8 / 256;  // rounds of 256 (row, displacement) items
+  float u[C1R][8], wk[C1R][8];
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
+  for (int r = 0; r < C1R; ++r) {
     const int item = r * 256 + tp, row = item >> 3, j = item & 7;
     const int64_t pn = min(m0 + row, M - 1);
     const uint32_t vb = (uint32_t)(pn / N) * (uint32_t)(L.D * L.H * L.W);
@@ -216,7 +228,7 @@ __device__ __forceinline__ void produce_c1(const FcLevel L, const FcSlab S, uint
   }
   uint16_t *b16 = reinterpret_cast<uint16_t *>(buf);
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
+  for (int r = 0; r < C1R; ++r) {
     const int item = r * 256 + tp, row = item >> 3, j = item & 7;
     float acc = 0.f;
 #pragma unroll
@@ -269,7 +281,7 @@ __global__ void args_store_kernel(FcArgs A, FcArgs *__restrict__ dst) {
   for (unsigned i = threadIdx.x; i < sizeof(FcArgs) / 4; i += blockDim.x) reinterpret_cast<uint32_t *>(dst)[i] = src[i];
 }
 
-__global__ __launch_bounds__(512, 1) void gather_fc0_kernel(const FcArgs *__restrict__ Ap, const float *__restrict__ points,
+__global__ __launch_bounds__(512, FTM == 64 ? 4 : 2) void gather_fc0_kernel(const FcArgs *__restrict__ Ap, const float *__restrict__ points,
                                                             const uint16_t *__restrict__ W0,
                                                             const uint32_t *__restrict__ amax, const float *__restrict__ bias,
                                                             float *__restrict__ Y, int64_t ldy, float *__restrict__ feat,
@@ -308,22 +320,25 @@ __global__ __launch_bounds__(512, 1) void gather_fc0_kernel(const FcArgs *__rest
       r[jt][1] = *reinterpret_cast<const uint4 *>(q + (FTN / 32) * 512 + jt * 512);
     }
   };
-  f32x16 acc[4][2];
+  f32x16 acc[FMT][2];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < FMT; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  constexpr int BDIST = FTM == 64 ? 1 : 3;  // k-steps the W loads run ahead (2 or 4 register sets)
   loadb(b0, 0);
-  loadb(b1, 1);
-  loadb(b2, 2);
+  if constexpr (BDIST == 3) {
+    loadb(b1, 1);
+    loadb(b2, 2);
+  }
   slab_barrier();  // slab 0 is in LDS
   int s = 0, kin = 0, ksl = A.S[0].nk, kidx = 0;
   // k-step kidx on the fragments `cur`; `fre` (used one step ago) is refilled with step kidx + 3
   auto step = [&](const uint4 (&cur)[2][2], uint4 (&fre)[2][2]) {
     if (!(dbg & 2)) {
-      loadb(fre, kidx + 3);
+      loadb(fre, kidx + BDIST);
       const uint32_t *pa = lds + (s & 1) * FSLAB + kin * FKSTEP;
       f16x8 b[3][2];
 #pragma unroll
@@ -336,7 +351,7 @@ __global__ __launch_bounds__(512, 1) void gather_fc0_kernel(const FcArgs *__rest
         b[2][jt] = scale_2m11(u0.v);
       }
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < FMT; ++i) {
         const f16x8 ah = lds_frag(pa, i * 32 + l31, lh), al = lds_frag(pa + FPLANE, i * 32 + l31, lh);
 #pragma unroll
         for (int jt = 0; jt < 2; ++jt) {
@@ -355,18 +370,24 @@ __global__ __launch_bounds__(512, 1) void gather_fc0_kernel(const FcArgs *__rest
     }
   };
   while (kidx < nk) {
-    step(b0, b3);
-    if (kidx >= nk) break;
-    step(b1, b0);
-    if (kidx >= nk) break;
-    step(b2, b1);
-    if (kidx >= nk) break;
-    step(b3, b2);
+    if constexpr (BDIST == 3) {
+      step(b0, b3);
+      if (kidx >= nk) break;
+      step(b1, b0);
+      if (kidx >= nk) break;
+      step(b2, b1);
+      if (kidx >= nk) break;
+      step(b3, b2);
+    } else {
+      step(b0, b1);
+      if (kidx >= nk) break;
+      step(b1, b0);
+    }
   }
   if (dbg & 4) return;
   const float inv = w_scale(amax[0], true);
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < FMT; ++i)
 #pragma unroll
     for (int jt = 0; jt < 2; ++jt) {
       const int n = 64 * wc + jt * 32 + l31;
