@@ -83,6 +83,12 @@ class DataParallelTrainer:
         self.bucket = GradBucket(list(trainer.parameters()))
         self.optimizer = optimizer if optimizer is not None else trainer.configure_optimizers()[0][0]
 
+    # The host enqueues a step in ~3.5 ms, the GPU runs it in ~18: unthrottled, the host runs many steps ahead.  Blocks that
+    # were used on a second stream (record_stream: gradient volumes, scatter plans) cannot be handed out again before the
+    # GPU has passed them, so every step the host is ahead costs the caching allocator another set of multi-GB blocks
+    # (hipMalloc: tens of ms each, seen as 40-70 ms steps until the pools had grown).  MAX_STEPS_IN_FLIGHT bounds it.
+    MAX_STEPS_IN_FLIGHT = 2
+
     def step(self, batch, batch_idx=0):
         self.bucket.detach_grads()
         out = self.trainer.training_step(batch, batch_idx)
@@ -90,4 +96,12 @@ class DataParallelTrainer:
         self.bucket.collect_grads()
         self.bucket.all_reduce_mean(self.group)
         self.optimizer.step()
+        loss = out["loss"]
+        if loss.is_cuda and not torch.cuda.is_current_stream_capturing():
+            done = torch.cuda.Event()
+            done.record()
+            self._in_flight = getattr(self, "_in_flight", [])
+            self._in_flight.append(done)
+            if len(self._in_flight) > self.MAX_STEPS_IN_FLIGHT:
+                self._in_flight.pop(0).synchronize()
         return out

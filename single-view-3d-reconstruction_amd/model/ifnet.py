@@ -309,16 +309,16 @@ class _EncoderGatherFn(torch.autograd.Function):
             keep = link.keep if link is not None else [(0, ext._layout.row_stride)]
             dw0_keep = torch.zeros_like(w0p)
             if fork:
+                # (no record_stream on what the side streams read: dh0, the kept rows, the gradient volumes ... stay
+                # referenced until main has joined both streams, so the allocator cannot hand them out earlier -- and a
+                # recorded multi-GB block that is freed while the host runs a step ahead cannot be reused in time, which
+                # made the allocator grow and flush its cache: 40-70 ms steps)
                 keep_stream.wait_stream(main)
-                for t in (dh0, feat, w0p, dw0_keep, pts) + tuple(g for g in gvols if g is not None):
-                    t.record_stream(keep_stream)
             lvl0 = ext._layout.col[0]
             # dW0 over the kept columns is a leaf (needed at the return only): third stream
             w_stream = _get_side_stream(gfeat.device, 1) if fork else main
             if fork:
                 w_stream.wait_stream(main)
-                for t in (dh0, feat, dw0_keep):
-                    t.record_stream(w_stream)
             with torch.cuda.stream(w_stream) if fork else contextlib.nullcontext():
                 for a, b in keep:
                     dws, dbs = ops.linear_bwd_weight(dh0, feat[:, a:b], want_bias=db0 is None)
@@ -332,7 +332,6 @@ class _EncoderGatherFn(torch.autograd.Function):
                     if a == lvl0 and not need_x and link is not None:
                         continue                         # raw-grid columns: their gradient is only needed for d(loss)/d(input)
                     ops.linear_bwd_data(dh0, w0p[:, a:b], out=gfeat[:, a:b])
-            del feat
             if link is not None:
                 link.dh0 = dh0
         if link is not None and link.dh0 is None:
@@ -346,8 +345,6 @@ class _EncoderGatherFn(torch.autograd.Function):
             if fork:
                 keep_done = torch.cuda.Event()
                 keep_done.record(keep_stream)
-                for t in (gfeat,) + tuple(g for g in gvols if g is not None):
-                    t.record_stream(main)
         dw0p = None
         if proj:
             # projected levels: dP = scatter of the dh0 rows, then two GEMMs over voxels (see gather_bwd_proj_kernel)
@@ -370,6 +367,7 @@ class _EncoderGatherFn(torch.autograd.Function):
         if fork:
             main.wait_event(keep_done)
             main.wait_stream(w_stream)
+        feat = None      # (only now: see the note at the fork)
         grads = {}
         dpooled = None
         gx = None
