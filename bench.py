@@ -125,6 +125,7 @@ def _relaunch_under_torchrun(a):
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("GPU_MAX_HW_QUEUES", "8")
     return subprocess.call(cmd, env=env)
 
 
@@ -183,6 +184,7 @@ def main():
     if world != a.gpus:
         sys.exit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {a.gpus}")
 
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # main + two side streams + RCCL's (see the package's __init__)
     import torch
     import torch.distributed as dist
     import svr_amd  # noqa: F401
