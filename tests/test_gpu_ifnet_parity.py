@@ -325,3 +325,51 @@ def test_projected_backward_equals_the_plain_backward():
         for name in ga:
             d = float((ga[name] - gb[name]).norm() / gb[name].norm().clamp_min(1e-30))
             assert d < tol, (mode, name, d)
+
+
+def test_fused_gather_fc0_step_equals_the_two_kernel_step():
+    """FUSE_FC0 (gather -> fc_0 in one kernel, feature rows never written; fc_0's backward inside the encoder Function, the
+    backward forked over three streams) against the two separate kernels: logits equal to f32 rounding of a different
+    summation order over fc_0's K (2e-6 of the largest logit), every gradient tensor within the split-product noise in
+    L2 norm (2e-4; 5e-5 with the exact-f32 backward switches), with and without the projection, with and without the
+    stream fork -- the fork must not change a bit beyond the float-atomic order of the scatter."""
+    import svr_amd  # noqa: F401
+    from svr_amd import ops
+    from svr_amd.model import ifnet as ifn
+    from svr_amd.trainer import bce_with_logits_sum_mean
+    z = G.load("ifnet_b3")
+    net_res, x, pts, occ = G.ifnet_inputs(z)
+    switches = ("BACKWARD_GEMM", "BACKWARD_CONV", "BACKWARD_CONV_WEIGHT")
+    saved = {k: getattr(ops, k) for k in switches}
+
+    def run(fuse, project, overlap):
+        prev = ifn.FUSE_FC0, ifn.PROJECT_WIDE_LEVELS, ifn.OVERLAP_BACKWARD
+        ifn.FUSE_FC0, ifn.PROJECT_WIDE_LEVELS, ifn.OVERLAP_BACKWARD = fuse, project, overlap
+        try:
+            m = _model(net_res, z)
+            xg = (x * 0.7 + 0.1).cuda().requires_grad_(True)
+            logits = m(xg, pts.cuda())
+            bce_with_logits_sum_mean(logits, occ.cuda()).backward()
+            torch.cuda.synchronize()
+        finally:
+            ifn.FUSE_FC0, ifn.PROJECT_WIDE_LEVELS, ifn.OVERLAP_BACKWARD = prev
+        grads = {n: p.grad.detach().cpu().double() for n, p in m.named_parameters()}
+        grads["input"] = xg.grad.detach().cpu().double()
+        return logits.detach().cpu(), grads
+
+    assert ifn.FUSE_FC0 and ifn.OVERLAP_BACKWARD
+    for mode, tol in (("production", 2e-4), ("f32", 5e-5)):
+        try:
+            if mode == "f32":
+                for k in switches:
+                    setattr(ops, k, "f32")
+            l0, g0 = run(False, False, False)                          # the two-kernel, unprojected, single-stream step
+            for fuse, project, overlap in ((True, True, True), (True, True, False), (True, False, False)):
+                l1, g1 = run(fuse, project, overlap)
+                assert float((l1 - l0).abs().max()) <= 2e-6 * float(l0.abs().max()), (mode, fuse, project, overlap)
+                for name in g0:
+                    d = float((g1[name] - g0[name]).norm() / g0[name].norm().clamp_min(1e-30))
+                    assert d < tol, (mode, (fuse, project, overlap), name, d)
+        finally:
+            for k, v in saved.items():
+                setattr(ops, k, v)
