@@ -281,6 +281,9 @@ __global__ void args_store_kernel(FcArgs A, FcArgs *__restrict__ dst) {
   for (unsigned i = threadIdx.x; i < sizeof(FcArgs) / 4; i += blockDim.x) reinterpret_cast<uint32_t *>(dst)[i] = src[i];
 }
 
+// `dbg` (environment SVR_FC0_DBG, 0 in production) switches parts of the kernel OFF for measurements -- the results are
+// then wrong by construction: bit 0 producers idle, bit 1 consumers idle, bit 2 no epilogue, bit 3 return at once,
+// bit 8 + l: level l is not gathered (tools/exp/prof_fc0.sh; DESIGN.md section 5b quotes the numbers).
 __global__ __launch_bounds__(512, FTM == 64 ? 4 : 2) void gather_fc0_kernel(const FcArgs *__restrict__ Ap, const float *__restrict__ points,
                                                             const uint16_t *__restrict__ W0,
                                                             const uint32_t *__restrict__ amax, const float *__restrict__ bias,
