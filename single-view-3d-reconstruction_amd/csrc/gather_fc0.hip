@@ -57,10 +57,11 @@ struct FcLevel {
   const float *vol;
   int C, D, H, W, col;
 };
-struct FcSlab {
-  unsigned char level, j0, nj, lp;  // lp: lanes per point (columns / 4); 0 marks the C == 1 slab (7 columns + 9 zeros)
-  short k0, nk;                     // first k-step and number of k-steps
-  short c0, keep;                   // first channel; keep: also store the values to the feature matrix
+struct FcSlab {  // 32-bit fields: scalar loads.  (Sub-dword fields were fetched with VECTOR loads + s_waitcnt vmcnt(0), which
+                 // drained the consumers' W prefetch at every slab boundary.)
+  int level, j0, nj, lp;  // lp: lanes per point (columns / 4); 0 marks the C == 1 slab (7 columns + 9 zeros)
+  int k0, nk;             // first k-step and number of k-steps
+  int c0, keep;           // first channel; keep: also store the values to the feature matrix
 };
 struct FcArgs {
   FcLevel L[SVR_MAX_LEVELS];
@@ -413,14 +414,14 @@ bool build_slabs(const svr_gather_desc *d, uint32_t keep_mask, FcArgs &A) {
   auto add = [&](int level, int j0, int nj, int lp, int c0, int cols) {
     if (ns >= FC_MAX_SLABS) return false;
     FcSlab &S = A.S[ns++];
-    S.level = (unsigned char)level;
-    S.j0 = (unsigned char)j0;
-    S.nj = (unsigned char)nj;
-    S.lp = (unsigned char)lp;
-    S.k0 = (short)k;
-    S.nk = (short)(cols / FK);
-    S.c0 = (short)c0;
-    S.keep = (short)((keep_mask >> level) & 1);
+    S.level = level;
+    S.j0 = j0;
+    S.nj = nj;
+    S.lp = lp;
+    S.k0 = k;
+    S.nk = cols / FK;
+    S.c0 = c0;
+    S.keep = (int)((keep_mask >> level) & 1);
     k += cols / FK;
     return true;
   };
