@@ -36,7 +36,7 @@ extern "C" {
 
 #define SVR_MAX_LEVELS 6
 
-int svr_version(void);
+int svr_version(void); /* 100 = round 1, 200 = this header (svr_level / svr_gather_desc grew: check svr_sizeof_*) */
 const char *svr_last_error(void);
 
 /* ---------------------------------------------------------------------------------------

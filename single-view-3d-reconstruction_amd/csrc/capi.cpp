@@ -12,7 +12,7 @@ void set_error(const char *fmt, ...) {
 }
 }  // namespace svr
 
-extern "C" int svr_version(void) { return 100; }
+extern "C" int svr_version(void) { return 200; }  // 2xx: round 2 (pull plans, item orders, projection, fused gather -> fc_0, bf16 mode, mesh, sample I/O)
 extern "C" const char *svr_last_error(void) { return svr::g_err; }
 extern "C" int64_t svr_sizeof_level(void) { return (int64_t)sizeof(svr_level); }
 extern "C" int64_t svr_sizeof_gather_desc(void) { return (int64_t)sizeof(svr_gather_desc); }
