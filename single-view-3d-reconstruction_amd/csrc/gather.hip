@@ -485,7 +485,7 @@ __device__ __forceinline__ void gather_bwd_runs_body(const LevelArgs L, const fl
 // point order (level 5: ~680 consecutive items per cell), and a lane group walks REPS * PG consecutive items with its
 // two runs kept open across the repetitions: the atomics issued for the 128-channel levels drop from ~0.8 GB to ~0.15 GB
 // and the kernel is bound by reading the gradient rows (1.43 GB per 128-channel level).
-constexpr int kItemReps = 4;
+constexpr int kItemReps = 2;  // (4: a third of the workgroups ran in a mostly empty second round; 2: 18.25 -> 18.1 ms/step)
 // the projected scatter (one wave per 128 items and repetition): shorter walks -- 2.7 rounds of workgroups instead of 1.3
 // with a two-thirds empty second one
 constexpr int kProjReps = 2;
