@@ -222,3 +222,32 @@ def test_config5_per_gpu_shape_matches_oracle():
     assert np.median(ed) < 1e-4 and np.quantile(ed, 0.99) < 1e-2, (np.median(ed), np.quantile(ed, 0.99), ed.max())
     go = tr.ifnet.fc_out.weight.grad.cpu().numpy().reshape(-1)
     assert G.rel_err(go, ref_st["fc_out.weight"].grad.numpy().reshape(-1)) < 1e-5
+
+
+@pytest.mark.parametrize("clustered", [False, True], ids=["uniform", "surface"])
+def test_config3_fused_gather_fc0_equals_the_two_kernels(clustered):
+    """gather_fc0.hip at the benched size (real pyramid of the seeded model, 8 x 50 000 Morton-sorted points, and the
+    surface-clustered distribution of bench.py --dist surface): the kept feature columns bit-identical to
+    svr_gather_trilinear_fwd's, h0 equal to svr_linear_fwd_f16x3 on those rows to 2e-6 of the largest value -- three
+    times in a row (a hazard between the producer and consumer waves would be timing dependent)."""
+    import bench                                  # synth_batch: the benchmark's own inputs (repo root is on sys.path)
+    from svr_amd import ops
+    m, _ = _model()
+    batch = bench.synth_batch(103, B, D, N, torch.device("cuda"), "surface" if clustered else "uniform")
+    with torch.no_grad():
+        levels = m.encode(batch["input"])
+        _, pts = ops.morton_order(batch["points"].contiguous(), want_sorted=True)
+        ext = m.ifnet_feature_extractor
+        w0p, b0 = m._fc0_internal(), m.fc_0.bias
+        rows = ops.gather_fwd(levels, pts, ext._layout, ext._disp, ext._align)
+        want = ops.linear_fwd(rows, w0p, b0, relu=True)
+        scale = float(want.abs().max())
+        keep = [l for l, c in enumerate(ext._layout.channels) if c < 128]
+        for _ in range(3):
+            h0, kept = ops.gather_fc0_fwd(levels, pts, ext._layout, ext._disp, ext._align, w0p, b0, relu=True, keep_levels=keep)
+            for l in keep:
+                a, b = ext._layout.col[l], ext._layout.col[l] + 7 * ext._layout.channels[l]
+                assert torch.equal(kept[:, a:b], rows[:, a:b]), f"level {l}"
+            assert torch.all(kept[:, ext._layout.width:] == 0)
+            assert float((h0 - want).abs().max()) <= 2e-6 * scale
+            del h0, kept
