@@ -140,6 +140,22 @@ int svr_gather_project_bwd(const float *points, const float *dh, int64_t lddh, i
                            int32_t W, int32_t align_corners, float displacement, const int32_t *items, float *dP,
                            void *stream);
 
+/* Two-pass form of svr_gather_project_bwd (no float atomics, no memset of dP, bit-reproducible): pass 1 stores the 8 corner
+ * sums of every run -- a maximal stretch of equal (sample, cell, displacement) keys inside a 256-item chunk of the sorted
+ * items -- to partials[slot][8][256]; pass 2 gives every (voxel, displacement) row of dP the sum of the <= 8 cells that touch
+ * it, with plain stores (dP is OVERWRITTEN).  svr_gather_project_plan sorts the items (as svr_gather_item_order with_j = 1)
+ * and builds keys (7*B*N sorted u32), sidx (7*B*N + 1: run starts in front of an item) and first_slot
+ * (B*(D+1)*(H+1)*(W+1)*8 + 1); partials needs svr_gather_project_slots(...) * 8 * 256 floats (not initialised).
+ * workspace: svr_gather_project_plan_workspace(B, N) bytes.                                                              */
+int64_t svr_gather_project_plan_workspace(int32_t B, int32_t N);
+int64_t svr_gather_project_slots(int32_t B, int32_t N, int32_t D, int32_t H, int32_t W);
+int svr_gather_project_plan(const float *points, int32_t B, int32_t N, int32_t D, int32_t H, int32_t W, int32_t align_corners,
+                            float displacement, int32_t *items, uint32_t *keys, int32_t *sidx, int32_t *first_slot,
+                            void *workspace, void *stream);
+int svr_gather_project_bwd2(const float *points, const float *dh, int64_t lddh, int32_t B, int32_t N, int32_t D, int32_t H,
+                            int32_t W, int32_t align_corners, float displacement, const int32_t *items, const int32_t *sidx,
+                            const int32_t *first_slot, float *partials, float *dP, void *stream);
+
 /* features[b*N+n][level.col + j*C + c] = trilinear sample j of channel c (zeros padding);
  * columns past the last level (up to row_stride) are written as zeros.                      */
 int svr_gather_trilinear_fwd(const svr_gather_desc *d, const float *points /*(B,N,3)*/,

@@ -49,6 +49,10 @@ SIGNATURES = {
     "svr_points_voxel_order": (C.c_int, [P, P, I32, I32, I32, I32, I32, I32, P, P]),
     "svr_gather_item_order": (C.c_int, [P, I32, I32, I32, I32, I32, I32, F32, I32, P, P, P]),
     "svr_gather_project_bwd": (C.c_int, [P, P, I64, I32, I32, I32, I32, I32, I32, F32, P, P, P]),
+    "svr_gather_project_plan_workspace": (C.c_int64, [I32, I32]),
+    "svr_gather_project_slots": (C.c_int64, [I32, I32, I32, I32, I32]),
+    "svr_gather_project_plan": (C.c_int, [P, I32, I32, I32, I32, I32, I32, F32, P, P, P, P, P, P]),
+    "svr_gather_project_bwd2": (C.c_int, [P, P, I64, I32, I32, I32, I32, I32, I32, F32, P, P, P, P, P, P]),
     "svr_gather_pull_plan_workspace": (I64, [I32, I32]),
     "svr_gather_pull_plan_workspace_cells": (I64, [I32, I32, I32, I32]),
     "svr_gather_pull_plan": (C.c_int, [P, I32, I32, I32, I32, I32, I32, I32, I32, I32, F32, P, P, P, P, P, P, P]),

@@ -30,6 +30,8 @@ hipError_t sort_pairs_u32(void *tmp, size_t tmp_bytes, const uint32_t *kin, uint
                           int64_t n, int bits, hipStream_t s);
 size_t scan_max_i32_temp_bytes(int64_t n);
 hipError_t scan_max_i32(void *tmp, size_t tmp_bytes, const int32_t *in, int32_t *out, int64_t n, hipStream_t s);
+size_t scan_sum_excl_i32_temp_bytes(int64_t n);
+hipError_t scan_sum_excl_i32(void *tmp, size_t tmp_bytes, const int32_t *in, int32_t *out, int64_t n, hipStream_t s);
 }  // namespace svr
 
 #define SVR_CHECK(cond, code, ...)      \

@@ -496,7 +496,7 @@ constexpr int kProjReps = 2;
 // PROJ (backward-only projection of a wide level, see gather_bwd_proj_kernel): the source row is the item's dh0 row (C = 256
 // values at pn * row_stride, the same for all 7 displacements), the destination is dP[b][voxel][j][C] and a run is one
 // (sample, displacement, cell): the displacement rides in the low 3 bits of the run's sample id.
-template <int C, int CPL, bool PROJ = false, int REPS = kItemReps>
+template <int C, int CPL, bool PROJ = false, int REPS = kItemReps, bool STORE = false>
 __device__ __forceinline__ void gather_bwd_items_body(const LevelArgs L, const float *__restrict__ points,
                                                       const float *__restrict__ gfeat, int64_t T, int N, int row_stride,
                                                       float disp, int ac, int64_t witem, int64_t waves) {
@@ -518,8 +518,19 @@ __device__ __forceinline__ void gather_bwd_items_body(const LevelArgs L, const f
 #pragma unroll
   for (int k = 0; k < 8 * CPL; ++k) acc0[k] = acc1[k] = 0.f;
   int cur0 = -1, cur1 = -1, b0 = 0, b1 = 0;  // open runs: base-voxel key and sample
+  int slot0 = 0;                             // STORE: slot of the open run in the partial-sum buffer (L.gvol)
   auto flush = [&](int cur, int bb, const float (&acc)[8 * CPL], int skip) {
-    if (cur >= 0) {
+    if constexpr (STORE) {
+      // two-pass projected scatter: the run's 8 corner sums go to partials[slot][corner][C] with plain coalesced stores
+      // (all 8: corners outside the volume are never read back); proj_combine_kernel sums the <= 8 cells of a voxel
+      if (cur >= 0) {
+        float *pb = L.gvol + (size_t)slot0 * 8 * C + cg * CW * CPL + ch;
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+#pragma unroll
+          for (int p = 0; p < CPL; ++p) pb[k * C + p * CW] = acc[k * CPL + p];
+      }
+    } else if (cur >= 0) {
       const int x0 = (cur & 1023) - 1, y0 = ((cur >> 10) & 1023) - 1, z0 = (cur >> 20) - 1;
       constexpr size_t VS = PROJ ? (size_t)7 * C : (size_t)C;   // floats per voxel of the destination
       float *gb = PROJ ? gl + (size_t)(bb >> 3) * vol * VS + (size_t)(bb & 7) * C : gl + (size_t)bb * vol * C;
@@ -560,13 +571,14 @@ __device__ __forceinline__ void gather_bwd_items_body(const LevelArgs L, const f
     const int cnt = (int)min((int64_t)PG, T - i0);  // items of this repetition (<= 0: none)
     if (cnt <= 0) break;                            // uniform within the group
     // ---- stage 1: two items per lane
-    int key[2], bb[2], goff[2];
+    int key[2], bb[2], goff[2], sid[2];
     float fx[2], fy[2], fz[2];
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       key[s] = -1;
       bb[s] = 0;
       goff[s] = 0;
+      sid[s] = (STORE && s * CW + ch < cnt) ? L.order[i0 + s * CW + ch] : 0;   // STORE: run-start count in front of the item
       fx[s] = fy[s] = fz[s] = 0.f;
       if (s * CW + ch < cnt) {
         const int id = L.items[i0 + s * CW + ch];
@@ -616,6 +628,7 @@ __device__ __forceinline__ void gather_bwd_items_body(const LevelArgs L, const f
             for (int k = 0; k < 8 * CPL; ++k) acc0[k] = 0.f;
             cur0 = kk;
             b0 = bqu;
+            if constexpr (STORE) slot0 = __shfl(s ? sid[1] : sid[0], src);
           }
         } else if (kk != cur0 || bqu != b0) {
           if (kk == cur1 && bqu == b1) {  // hit on the older run: make it the most recent
@@ -699,6 +712,68 @@ __global__ __launch_bounds__(256) void gather_bwd_proj_kernel(LevelArgs L, const
                                                               float disp, int ac, int64_t waves) {
   const int64_t witem = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
   gather_bwd_items_body<256, 4, true, kProjReps>(L, points, dh, T, N, lddh, disp, ac, witem, waves);
+}
+
+// Two-pass form of the projected scatter (level 4 at config 3: 94 000 runs x 8 KB of run-end float atomics = 0.77 GB at
+// ~1.3 TB/s were its floor).  Pass 1 is the same walk with the run sums STORED to partials[slot][corner][256]; pass 2
+// (proj_combine_kernel) gives every (voxel, displacement) row of dP the sum of the <= 8 cells that touch it, in a fixed
+// order, with plain stores: no atomics, no memset of dP, bit-reproducible.  Slots: a run = maximal stretch of equal
+// (sample, cell, displacement) keys inside one wave's 256-item chunk; slot = number of run starts in front of it
+// (proj_flag_kernel + exclusive scan), first_slot[key] = slot of the key's first run (proj_table_kernel).
+__global__ __launch_bounds__(256) void gather_bwd_proj_store_kernel(LevelArgs L, const float *__restrict__ points,
+                                                                    const float *__restrict__ dh, int64_t T, int N, int lddh,
+                                                                    float disp, int ac, int64_t waves) {
+  const int64_t witem = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
+  gather_bwd_items_body<256, 4, true, kProjReps, true>(L, points, dh, T, N, lddh, disp, ac, witem, waves);
+}
+
+__global__ __launch_bounds__(256) void proj_flag_kernel(const uint32_t *__restrict__ keys, int32_t *__restrict__ flags, int64_t T,
+                                                        int chunk, uint32_t sentinel) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i > T) return;
+  flags[i] = (i < T && keys[i] != sentinel && (i % chunk == 0 || keys[i] != keys[i - 1])) ? 1 : 0;   // flags[T] = 0
+}
+
+__global__ __launch_bounds__(256) void proj_table_kernel(const uint32_t *__restrict__ keys, const int32_t *__restrict__ sidx,
+                                                         int32_t *__restrict__ first_slot, int64_t nkeys, int64_t T) {
+  const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (q > nkeys) return;
+  int64_t lo = 0, hi = T;  // first item with a key >= q (the items that touch no voxel carry the key nkeys)
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (keys[mid] < (uint32_t)q) lo = mid + 1; else hi = mid;
+  }
+  first_slot[q] = sidx[lo];
+}
+
+// one wave per row (sample, voxel, displacement) of dP: 64 lanes x float4 = 256 channels
+__global__ __launch_bounds__(256) void proj_combine_kernel(const float *__restrict__ partials, const int32_t *__restrict__ first_slot,
+                                                           float *__restrict__ dP, int B, int D, int H, int W) {
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t rows = (int64_t)B * D * H * W * 7;
+  if (row >= rows) return;
+  const int lane = threadIdx.x & 63;
+  const int j = (int)(row % 7);
+  int64_t v = row / 7;
+  const int x = (int)(v % W);
+  v /= W;
+  const int y = (int)(v % H);
+  v /= H;
+  const int z = (int)(v % D);
+  const int b = (int)(v / D);
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    // the cell whose corner k is this voxel: base voxel (z - dz, y - dy, x - dx), lattice coordinate = base + 1
+    const int cz = z - (k >> 2) + 1, cy = y - ((k >> 1) & 1) + 1, cx = x - (k & 1) + 1;
+    const int64_t q = ((((int64_t)b * (D + 1) + cz) * (H + 1) + cy) * (W + 1) + cx) * 8 + j;
+    const int s0 = first_slot[q], s1 = first_slot[q + 1];
+    for (int sl = s0; sl < s1; ++sl) {
+      const float4 p = *reinterpret_cast<const float4 *>(partials + ((size_t)sl * 8 + k) * 256 + lane * 4);
+      acc.x += p.x; acc.y += p.y; acc.z += p.z; acc.w += p.w;
+    }
+  }
+  *reinterpret_cast<float4 *>(dP + row * 256 + lane * 4) = acc;
 }
 
 __host__ __device__ inline int64_t bwd_items_waves_cpl(int C, int cpl, int64_t T, int reps = kItemReps) {
@@ -1243,4 +1318,72 @@ extern "C" int svr_gather_project_bwd(const float *points, const float *dh, int6
   hipLaunchKernelGGL(gather_bwd_proj_kernel, dim3((unsigned)svr::cdiv(waves * 64, 256)), dim3(256), 0, (hipStream_t)stream, L, points,
                      dh, T, N, (int)lddh, displacement, align_corners, waves);
   return svr::launch_status("project_bwd");
+}
+
+// ---- two-pass projected scatter (see gather_bwd_proj_store_kernel)
+extern "C" int64_t svr_gather_project_plan_workspace(int32_t B, int32_t N) {
+  const int64_t T = (int64_t)7 * B * N;
+  if (T <= 0) return 256;
+  return 2 * al256(T * 4) + al256((int64_t)svr::sort_pairs_u32_temp_bytes(T, 32)) + al256((T + 1) * 4) +
+         al256((int64_t)svr::scan_sum_excl_i32_temp_bytes(T + 1)) + 512;
+}
+
+extern "C" int64_t svr_gather_project_slots(int32_t B, int32_t N, int32_t D, int32_t H, int32_t W) {
+  const int64_t T = (int64_t)7 * B * N, nkeys = pull_cells(B, D, H, W) * 8;
+  return (T < nkeys ? T : nkeys) + svr::cdiv(T, 2 * 64 * kProjReps) + 1;   // distinct keys + one split per wave chunk
+}
+
+extern "C" int svr_gather_project_plan(const float *points, int32_t B, int32_t N, int32_t D, int32_t H, int32_t W,
+                                       int32_t align_corners, float displacement, int32_t *items, uint32_t *keys, int32_t *sidx,
+                                       int32_t *first_slot, void *workspace, void *stream) {
+  const int64_t T = (int64_t)7 * B * N;
+  SVR_CHECK(B >= 0 && N >= 0 && D > 0 && H > 0 && W > 0, SVR_E_BADSHAPE, "project_plan: B=%d N=%d dims %dx%dx%d", B, N, D, H, W);
+  if (T == 0) return SVR_OK;
+  SVR_CHECK(points && items && keys && sidx && first_slot && workspace, SVR_E_BADARG, "project_plan: null pointer");
+  const int64_t nkeys = pull_cells(B, D, H, W) * 8;
+  SVR_CHECK(nkeys < (1LL << 31) - 1 && T < (1LL << 31) - 1, SVR_E_UNSUPPORTED, "project_plan: %ld keys / %ld items exceed 32 bits",
+            (long)nkeys, (long)T);
+  hipStream_t s = (hipStream_t)stream;
+  char *w = (char *)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+  uint32_t *keys_in = (uint32_t *)w;
+  w += al256(T * 4);
+  int32_t *vals_in = (int32_t *)w;
+  w += al256(T * 4);
+  const int bits = pull_key_bits(nkeys);
+  void *sort_tmp = w;
+  w += al256((int64_t)svr::sort_pairs_u32_temp_bytes(T, 32));
+  int32_t *flags = (int32_t *)w;
+  w += al256((T + 1) * 4);
+  hipLaunchKernelGGL(pull_key_kernel, dim3((unsigned)svr::cdiv(T, 256)), dim3(256), 0, s, points, keys_in, vals_in, T, N, D, H,
+                     W, displacement, align_corners, (uint32_t)nkeys, 1);
+  hipError_t e = svr::sort_pairs_u32(sort_tmp, svr::sort_pairs_u32_temp_bytes(T, bits), keys_in, keys, vals_in, items, T, bits, s);
+  SVR_CHECK(e == hipSuccess, (int)e, "project_plan: radix sort failed: %s", hipGetErrorString(e));
+  hipLaunchKernelGGL(proj_flag_kernel, dim3((unsigned)svr::cdiv(T + 1, 256)), dim3(256), 0, s, (const uint32_t *)keys, flags, T,
+                     2 * 64 * kProjReps, (uint32_t)nkeys);
+  e = svr::scan_sum_excl_i32((void *)w, svr::scan_sum_excl_i32_temp_bytes(T + 1), flags, sidx, T + 1, s);
+  SVR_CHECK(e == hipSuccess, (int)e, "project_plan: scan failed: %s", hipGetErrorString(e));
+  hipLaunchKernelGGL(proj_table_kernel, dim3((unsigned)svr::cdiv(nkeys + 1, 256)), dim3(256), 0, s, (const uint32_t *)keys,
+                     (const int32_t *)sidx, first_slot, nkeys, T);
+  return svr::launch_status("project_plan");
+}
+
+extern "C" int svr_gather_project_bwd2(const float *points, const float *dh, int64_t lddh, int32_t B, int32_t N, int32_t D,
+                                       int32_t H, int32_t W, int32_t align_corners, float displacement, const int32_t *items,
+                                       const int32_t *sidx, const int32_t *first_slot, float *partials, float *dP, void *stream) {
+  const int64_t T = (int64_t)7 * B * N;
+  SVR_CHECK(dP && D > 0 && H > 0 && W > 0 && D < 1022 && H < 1022 && W < 1022, SVR_E_BADSHAPE, "project_bwd2: dims %dx%dx%d", D, H, W);
+  hipStream_t s = (hipStream_t)stream;
+  if (T > 0) {
+    SVR_CHECK(points && dh && items && sidx && first_slot && partials, SVR_E_BADARG, "project_bwd2: null pointer");
+    SVR_CHECK(T < (1LL << 31) - 1 && (int64_t)B * N * lddh < (1LL << 31) && lddh >= 256, SVR_E_UNSUPPORTED,
+              "project_bwd2: needs 32-bit item / row offsets and rows of >= 256 floats");
+    LevelArgs L{nullptr, partials, 256, D, H, W, 0, sidx, items};   // gvol = the partial-sum buffer, order = the slot numbers
+    const int64_t waves = bwd_items_waves_cpl(256, 4, T, kProjReps);
+    hipLaunchKernelGGL(gather_bwd_proj_store_kernel, dim3((unsigned)svr::cdiv(waves * 64, 256)), dim3(256), 0, s, L, points, dh, T,
+                       N, (int)lddh, displacement, align_corners, waves);
+    const int64_t rows = (int64_t)B * D * H * W * 7;
+    hipLaunchKernelGGL(proj_combine_kernel, dim3((unsigned)svr::cdiv(rows, 4)), dim3(256), 0, s, (const float *)partials, first_slot,
+                       dP, B, D, H, W);
+  }
+  return svr::launch_status("project_bwd2");
 }

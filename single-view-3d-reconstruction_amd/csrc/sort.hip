@@ -151,6 +151,16 @@ size_t scan_max_i32_temp_bytes(int64_t n) {
 hipError_t scan_max_i32(void *tmp, size_t tmp_bytes, const int32_t *in, int32_t *out, int64_t n, hipStream_t s) {
   return rocprim::inclusive_scan(tmp, tmp_bytes, in, out, (size_t)n, rocprim::maximum<int32_t>(), s);
 }
+// exclusive prefix sum (run-start flags -> slot numbers of the two-pass projected scatter)
+size_t scan_sum_excl_i32_temp_bytes(int64_t n) {
+  size_t tmp = 0;
+  rocprim::exclusive_scan(nullptr, tmp, (const int32_t *)nullptr, (int32_t *)nullptr, (int32_t)0, (size_t)n,
+                          rocprim::plus<int32_t>(), (hipStream_t)0);
+  return tmp;
+}
+hipError_t scan_sum_excl_i32(void *tmp, size_t tmp_bytes, const int32_t *in, int32_t *out, int64_t n, hipStream_t s) {
+  return rocprim::exclusive_scan(tmp, tmp_bytes, in, out, (int32_t)0, (size_t)n, rocprim::plus<int32_t>(), s);
+}
 }  // namespace svr
 
 extern "C" int64_t svr_points_morton_order_workspace(int32_t B, int32_t N) {

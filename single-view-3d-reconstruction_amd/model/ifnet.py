@@ -115,7 +115,10 @@ def _level_orders_async(pts, D, H, W, n_levels, align, layout=None, disp=None, p
             dhw = (max(D >> (l - 1), 1), max(H >> (l - 1), 1), max(W >> (l - 1), 1))
             C = layout.channels[l] if layout is not None else 0
             if l in proj_levels:                     # backward-only projection: items by (cell, displacement)
-                orders[l] = ops.item_order(pts, dhw, disp, align, with_j=True)
+                if PROJ_TWO_PASS and min(dhw) >= PROJ_TWO_PASS_MIN_DIM:
+                    orders[l] = ops.project_plan(pts, dhw, disp, align)      # two-pass form: no float atomics
+                else:
+                    orders[l] = ops.item_order(pts, dhw, disp, align, with_j=True)
                 orders[l].record_stream(main)
                 launched = True
             elif form in ("auto", "pull") and fits32 and ops.pull_plan_supported(B, N, dhw, C, layout.row_stride):
@@ -146,6 +149,13 @@ def _level_orders_async(pts, D, H, W, n_levels, align, layout=None, disp=None, p
 # dP_l[b][voxel][j][256], and two GEMMs over VOXELS (32 768 rows at level 4) give the level's gradient volume and its slice
 # of dW0.  dX0 / dW0 of the point MLP then only cover the remaining 800 columns.  The forward pass is unchanged.
 PROJECT_WIDE_LEVELS = os.environ.get("SVR_NO_PROJECTION") is None
+# Optional two-pass form of the projected scatter for levels of 16^3 voxels and more (run sums stored, then one gather-form
+# pass per dP row: no float atomics, dP written once, bit-reproducible).  At 16^3 x 8 samples there are ~270 000 runs of ~10
+# items: 2.2 GB of run-end atomics against 2.2 GB stored + read plainly, 1.53 -> 1.20 ms alone -- but only 18.25 -> 18.18 ms
+# per step inside the backward's fork (it is not on the critical stream), a 2.7 GB buffer and a longer allocator warm-up, so
+# the atomic form stays the default.  SVR_PROJ_TWO_PASS=1 selects it (at 8^3 the atomic form wins anyway: 0.49 vs 0.55 ms).
+PROJ_TWO_PASS = os.environ.get("SVR_PROJ_TWO_PASS") is not None
+PROJ_TWO_PASS_MIN_DIM = 16
 # Fused gather -> fc_0 forward (gather_fc0.hip): the feature rows are never written to HBM; only the columns a backward
 # still needs (the levels that are not projected) are kept.  SVR_NO_FUSED_FC0=1 restores the two separate kernels.
 FUSE_FC0 = os.environ.get("SVR_NO_FUSED_FC0") is None

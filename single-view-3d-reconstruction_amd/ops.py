@@ -142,12 +142,59 @@ def project_bwd_supported(B, N, dims, lddh=256):
     return N > 0 and 8 * cells < 2 ** 31 - 1 and 7 * B * N < 2 ** 31 and B * N * lddh < 2 ** 31 and max(dims) < 1022
 
 
+_proj_partials = {}
+
+
+class ProjPlan:
+    """Plan of the two-pass (atomic-free) projected scatter of one level (svr_gather_project_plan): the items sorted by
+    (sample, cell, displacement), their sorted keys, the run-start counts and the first slot of every key."""
+
+    def __init__(self, items, keys, sidx, first_slot, slots):
+        self.items, self.keys, self.sidx, self.first_slot, self.slots = items, keys, sidx, first_slot, slots
+
+    def record_stream(self, stream):
+        for t in (self.items, self.keys, self.sidx, self.first_slot):
+            t.record_stream(stream)
+
+
+def project_plan(points, dims, displacement, align_corners=False):
+    _f32(points)
+    B, N, _ = points.shape
+    l = _lib.lib()
+    T = 7 * B * N
+    nkeys = B * (dims[0] + 1) * (dims[1] + 1) * (dims[2] + 1) * 8
+    dev = points.device
+    items = torch.empty(max(T, 1), device=dev, dtype=torch.int32)
+    keys = torch.empty(max(T, 1), device=dev, dtype=torch.int32)          # uint32 bit patterns
+    sidx = torch.empty(T + 1, device=dev, dtype=torch.int32)
+    first_slot = torch.empty(nkeys + 1, device=dev, dtype=torch.int32)
+    ws = torch.empty(l.svr_gather_project_plan_workspace(B, N), device=dev, dtype=torch.uint8)
+    check(l.svr_gather_project_plan(_p(points), B, N, dims[0], dims[1], dims[2], int(align_corners), displacement, _p(items),
+                                    _p(keys), _p(sidx), _p(first_slot), _p(ws), _stream()), "gather_project_plan")
+    return ProjPlan(items, keys, sidx, first_slot, int(l.svr_gather_project_slots(B, N, dims[0], dims[1], dims[2])))
+
+
 def gather_project_bwd(points, dh, dims, items, displacement, align_corners=False):
     """dP (B, D*H*W, 7, 256) = scatter of the 256-wide rows of dh (B*N, >= 256) with the trilinear weights of every
-    (point, displacement) item; `items` = item_order(..., with_j=True)."""
+    (point, displacement) item; `items` = item_order(..., with_j=True) (float atomics into a zeroed dP) or a ProjPlan
+    (two passes, no atomics, dP written once, bit-reproducible)."""
     _f32(points, dh)
     B, N, _ = points.shape
     assert dh.shape[0] == B * N and dh.shape[1] >= 256 and dh.stride(1) == 1
+    if isinstance(items, ProjPlan):
+        plan = items
+        dP = torch.empty(B, dims[0] * dims[1] * dims[2], 7, 256, device=points.device, dtype=torch.float32)
+        # the partial-sum buffer (2.7 GB at 16^3 x 8 samples: sized for the worst case, ~85 % used) is kept between calls:
+        # as a per-step allocation it was split up by the caching allocator between two steps and re-allocated with
+        # hipMalloc every time (22 instead of 18 ms/step).  One buffer per device and stream; calls on a stream serialise.
+        key = (points.device.index, torch.cuda.current_stream(points.device).cuda_stream)
+        partials = _proj_partials.get(key)
+        if partials is None or partials.numel() < plan.slots * 8 * 256:
+            partials = _proj_partials[key] = torch.empty(plan.slots * 8 * 256, device=points.device, dtype=torch.float32)
+        check(_lib.lib().svr_gather_project_bwd2(_p(points), C.c_void_p(dh.data_ptr()), dh.stride(0), B, N, dims[0], dims[1],
+                                                 dims[2], int(align_corners), displacement, _p(plan.items), _p(plan.sidx),
+                                                 _p(plan.first_slot), _p(partials), _p(dP), _stream()), "gather_project_bwd2")
+        return dP
     dP = torch.zeros(B, dims[0] * dims[1] * dims[2], 7, 256, device=points.device, dtype=torch.float32)
     check(_lib.lib().svr_gather_project_bwd(_p(points), C.c_void_p(dh.data_ptr()), dh.stride(0), B, N, dims[0], dims[1], dims[2],
                                             int(align_corners), displacement, _p(items), _p(dP), _stream()), "gather_project_bwd")

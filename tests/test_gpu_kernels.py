@@ -506,6 +506,14 @@ def test_projected_scatter_of_dh_rows(dims, align, N, B):
         (out[:, :, 0, 0].permute(0, 2, 1) * dh.view(B, N, 256)).sum().backward()
         ref = vol.grad.permute(0, 2, 3, 4, 1).reshape(B, -1, 256)
         assert G.rel_err(dP[:, :, j].numpy(), ref.numpy()) < 1e-5, j
+    # two-pass form (svr_gather_project_plan / _bwd2: run sums stored, then one gather-form pass per voxel row): the same
+    # values without float atomics, every row of dP written (it starts as uninitialised memory), bit-reproducible
+    plan = ops.project_plan(pts.cuda(), dims, disp, align)
+    assert torch.equal(plan.items, items)
+    runs = [ops.gather_project_bwd(pts.cuda(), dh.cuda(), dims, plan, disp, align) for _ in range(2)]
+    assert torch.equal(runs[0], runs[1])
+    assert G.rel_err(runs[0].cpu().numpy(), dP.numpy()) < 1e-5
+    assert bool(torch.isfinite(runs[0]).all())
 
 
 @pytest.mark.parametrize("chans,ac", [([1, 16, 32, 64, 128, 128], False), ([1, 32, 64, 128], True)], ids=["arch128", "arch32"])

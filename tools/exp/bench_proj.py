@@ -22,3 +22,11 @@ for S in (16, 8):
     t_o = timeit(lambda: ops.item_order(pts, (S, S, S), 0.0722, False, with_j=True))
     t = timeit(lambda: ops.gather_project_bwd(pts, dh, (S, S, S), items, 0.0722, False))
     print(f"S={S}: item order {t_o:.3f} ms, projected scatter (incl. dP memset) {t:.3f} ms")
+    plan = ops.project_plan(pts, (S, S, S), 0.0722, False)
+    t_p = timeit(lambda: ops.project_plan(pts, (S, S, S), 0.0722, False))
+    t2 = timeit(lambda: ops.gather_project_bwd(pts, dh, (S, S, S), plan, 0.0722, False))
+    a = ops.gather_project_bwd(pts, dh, (S, S, S), items, 0.0722, False)
+    b = ops.gather_project_bwd(pts, dh, (S, S, S), plan, 0.0722, False)
+    slots = int(plan.sidx[-1])
+    print(f"S={S}: plan {t_p:.3f} ms, two-pass scatter {t2:.3f} ms, {slots} slots of {plan.slots}, "
+          f"max dev {float((a - b).abs().max() / a.abs().max()):.2e}")
