@@ -44,6 +44,7 @@ L2_PEAK_GBPS = 34500.0                       # MI355X_MICROARCH.md section L2: ~
 ATOMIC_PEAK_GBPS = 1300.0                    # MI355X_MICROARCH.md "Global float atomics": ~1.3 TB/s of added bytes
 MFMA_F16_PEAK_TFLOPS = 2500.0                # dense f16 / bf16 MFMA peak (spec)
 MLP_FLOP_PER_POINT = 1585152                 # forward FLOP per query point of fc_0..fc_out (f32-equivalent)
+DIAG_STEPS = 2                               # untimed single-stream steps behind the timed region (per-kernel times)
 SETUP_STEPS = 2                              # untimed steps before the W warm-up steps (allocator pools, scatter-form decision)
 SPLIT_PRODUCTS = 3                           # f16x3 / bf16x3: three MFMA products per f32-equivalent product
 
@@ -220,15 +221,10 @@ def main():
     sync()
     for _ in range(a.warmup):
         dp.step(batch)
-    # live HIP-event timing of the roofline kernels on the stream they run on (installed after the warm-up)
+    # live HIP-event timing of the roofline kernel (the forward gather, fused with fc_0) over the timed region, on the
+    # stream it runs on (installed after the warm-up)
     kt = _KernelTimer(torch)
-    restore = [(ops, "gather_fwd", kt.wrap(ops, "gather_fwd")), (ops, "gather_bwd", kt.wrap(ops, "gather_bwd")),
-               (ops, "gather_project_bwd", kt.wrap(ops, "gather_project_bwd")),
-               (ops, "gather_fc0_fwd", kt.wrap(ops, "gather_fc0_fwd")),
-               # linear_fwd(x (M,K), w (N,K)); linear_bwd_data(dy (M,N), w (N,K)); linear_bwd_weight(dy (M,N), x (M,K))
-               (ops, "linear_fwd", kt.wrap(ops, "linear_fwd", lambda x, w, *r, **k: f"linear_fwd:{x.shape[0]}x{w.shape[0]}x{x.shape[-1]}")),
-               (ops, "linear_bwd_data", kt.wrap(ops, "linear_bwd_data", lambda dy, w, *r, **k: f"linear_bwd_data:{dy.shape[0]}x{dy.shape[-1]}x{w.shape[-1]}")),
-               (ops, "linear_bwd_weight", kt.wrap(ops, "linear_bwd_weight", lambda dy, x, *r, **k: f"linear_bwd_weight:{dy.shape[0]}x{dy.shape[-1]}x{x.shape[-1]}"))]
+    restore = [(ops, "gather_fwd", kt.wrap(ops, "gather_fwd")), (ops, "gather_fc0_fwd", kt.wrap(ops, "gather_fc0_fwd"))]
     sync()
     t0 = time.perf_counter()
     for _ in range(a.steps):
@@ -237,6 +233,25 @@ def main():
     dt = time.perf_counter() - t0
     for mod, name, orig in restore:
         setattr(mod, name, orig)
+    # the other kernels of `roofline_kernels` (scatter, GEMMs): DIAG_STEPS extra, untimed steps with the backward's three
+    # streams collapsed into one (ifnet.OVERLAP_BACKWARD off), so that a HIP-event bracket holds one kernel's own time --
+    # in the measured step those kernels run side by side and their brackets stretch 1.3-3.5x
+    from svr_amd.model import ifnet as _ifn
+    kd = _KernelTimer(torch)
+    diag = [(ops, "gather_bwd", kd.wrap(ops, "gather_bwd")), (ops, "gather_project_bwd", kd.wrap(ops, "gather_project_bwd")),
+            # linear_fwd(x (M,K), w (N,K)); linear_bwd_data(dy (M,N), w (N,K)); linear_bwd_weight(dy (M,N), x (M,K))
+            (ops, "linear_fwd", kd.wrap(ops, "linear_fwd", lambda x, w, *r, **k: f"linear_fwd:{x.shape[0]}x{w.shape[0]}x{x.shape[-1]}")),
+            (ops, "linear_bwd_data", kd.wrap(ops, "linear_bwd_data", lambda dy, w, *r, **k: f"linear_bwd_data:{dy.shape[0]}x{dy.shape[-1]}x{w.shape[-1]}")),
+            (ops, "linear_bwd_weight", kd.wrap(ops, "linear_bwd_weight", lambda dy, x, *r, **k: f"linear_bwd_weight:{dy.shape[0]}x{dy.shape[-1]}x{x.shape[-1]}"))]
+    prev_overlap, _ifn.OVERLAP_BACKWARD = _ifn.OVERLAP_BACKWARD, False
+    try:
+        for _ in range(DIAG_STEPS):
+            dp.step(batch)
+        sync()
+    finally:
+        _ifn.OVERLAP_BACKWARD = prev_overlap
+        for mod, name, orig in diag:
+            setattr(mod, name, orig)
     loss = float(out["loss"].detach())
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
     if launched:
@@ -304,7 +319,7 @@ def main():
                 d = max(d // 2, 1)
         out_bytes = (256 * 4 + kept) if fused else 2583 * 4
         compulsory = a.batch * (vol_elems * 4 + a.points * 12 + a.points * out_bytes)
-        traffic, bwd_atomic_bytes, bwd_hbm_bytes, tsrc = None, None, None, None
+        traffic, bwd_atomic_bytes, bwd_hbm_bytes, tsrc, proj_hbm, proj_atomic = None, None, None, None, None, None
         tfile = os.path.join(ROOT, "profiles", "gather_traffic.json")
         if os.path.exists(tfile):
             try:
@@ -314,6 +329,8 @@ def main():
                     traffic = t.get("fused_hbm_bytes_per_launch") if fused else t.get("hbm_bytes_per_launch")
                     bwd_atomic_bytes = t.get("gather_bwd_write_bytes")
                     bwd_hbm_bytes = t.get("gather_bwd_hbm_bytes")
+                    proj_hbm = t.get("proj_hbm_bytes_per_launch")
+                    proj_atomic = t.get("proj_atomic_bytes_per_launch")
                     tsrc = t.get("source")
             except Exception:
                 traffic = None
@@ -373,41 +390,50 @@ def main():
                                  "note": "bf16 = separately named bf16-STORAGE mode (bf16 volumes / feature rows / activations, "
                                          "f32 accumulation; never the default, not held to the fp32 1e-4 gate)"}
         kernels = []
-        bwd_ms = kt.ms_per_launch("gather_bwd")
+        bwd_ms = kd.ms_per_launch("gather_bwd")
         if bwd_ms > 0:
             # compulsory traffic of the scatter: the gradient rows once + the gradient volumes (levels 1..5) once
             bwd_comp = a.batch * (a.points * 2583 * 4 + (vol_elems - a.grid ** 3) * 4)
+            if fused:   # the 128-channel levels are projected: this call scatters the 784 columns of levels 1-3 only
+                dd, ve = a.grid, 0
+                for i, c in enumerate(chans[1:4]):
+                    ve += c * dd ** 3
+                    dd = max(dd // 2, 1)
+                bwd_comp = a.batch * (a.points * 784 * 4 + ve * 4)
             rate = bwd_hbm_bytes / (bwd_ms * 1e-3) / 1e9 if bwd_hbm_bytes else None
             kernels.append({"kernel": "gather_bwd (svr_gather_trilinear_bwd: per level the atomic-free pull form or the atomic "
                                       "scatter over the joint item order, chosen from the point distribution)", "bound": "hbm",
                             "unit": "GB/s", "peak": HBM_PEAK_GBPS,
                             "achieved": rate, "frac": (rate / HBM_PEAK_GBPS) if rate else None, "ms_per_launch": bwd_ms,
                             "traffic": bwd_hbm_bytes, "float_atomic_bytes": bwd_atomic_bytes,
-                            "algorithmic_bytes_per_launch": npts * GATHER_BWD_BYTES_PER_POINT_F32,
+                            "algorithmic_bytes_per_launch": npts * (GATHER_BWD_BYTES_PER_POINT_F32 if not fused else 784 * 4 + 12 + 7 * 8 * 112 * 4),
                             "compulsory_bytes_per_launch": bwd_comp,
                             "compulsory_frac_of_hbm_peak": bwd_comp / (bwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                             "note": "achieved = HBM bytes of all scatter kernels (PMC FETCH_SIZE x2 + WRITE_SIZE) / live time; the "
                                     "round-1 kernel sat at the ~1.3 TB/s float-atomic rate (7.0 GB of atomics), the atomics left are "
                                     "float_atomic_bytes"})
-        proj_ms = kt.ms_per_step("gather_project_bwd", a.steps)
+        proj_ms = kd.ms_per_step("gather_project_bwd", DIAG_STEPS)
         if proj_ms > 0:
             kernels.append({"kernel": "gather_bwd_proj_kernel (svr_gather_project_bwd: fc_0's input gradient rows scattered into "
                                       "(voxel, displacement, 256) slabs for the two 128-channel levels, incl. the slab memset)",
-                            "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBPS, "achieved": None, "frac": None,
-                            "ms_per_step": proj_ms, "launches_per_step": len(kt.ev["gather_project_bwd"]) / a.steps,
-                            "algorithmic_bytes_per_step": 2 * npts * 7 * (256 * 4 + 12), "traffic": None,
+                            "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBPS,
+                            "achieved": (2 * proj_hbm / (proj_ms * 1e-3) / 1e9) if proj_hbm else None,
+                            "frac": (2 * proj_hbm / (proj_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if proj_hbm else None,
+                            "float_atomic_bytes_per_step": (2 * proj_atomic) if proj_atomic else None,
+                            "ms_per_step": proj_ms, "launches_per_step": len(kd.ev["gather_project_bwd"]) / DIAG_STEPS,
+                            "algorithmic_bytes_per_step": 2 * npts * 7 * (256 * 4 + 12), "traffic": (2 * proj_hbm) if proj_hbm else None,
                             "note": "reads each dh0 row (1 KB) once per displacement and level; float atomics only at run ends"})
         # every GEMM of the step, keyed by the shape it was CALLED with: point-MLP layers have M = points, the two
         # projected levels add voxel-row GEMMs (M = B*S^3); fc_0's backward runs over the kept column segments only
         what = {"linear_fwd": "forward (f16x3)", "linear_bwd_data": "dX (bf16x3)", "linear_bwd_weight": "dW + bias gradient (bf16x3)"}
         mlp_ms = 0.0
-        for key in sorted(kt.ev):
+        for key in sorted(kd.ev):
             op, _, shape = key.partition(":")
             if op not in what:
                 continue
             M, N, K = (int(v) for v in shape.split("x"))
-            calls = len(kt.ev[key]) / a.steps
-            ms = kt.ms_per_step(key, a.steps)
+            calls = len(kd.ev[key]) / DIAG_STEPS
+            ms = kd.ms_per_step(key, DIAG_STEPS)
             if ms <= 0:
                 continue
             mlp_ms += ms
@@ -419,7 +445,9 @@ def main():
         res["mlp_gemm_ms_per_step"] = mlp_ms
         res["roofline_kernels_note"] = ("MFMA entries: achieved counts the 3 split products actually issued on the f16 / bf16 "
                                         "matrix cores (the f32-equivalent rate is a third of it); ms = HIP-event brackets "
-                                        "around the C-ABI calls on their stream, summed per step")
+                                        f"around the C-ABI calls, from {DIAG_STEPS} untimed single-stream steps behind the timed "
+                                        "region (in the measured step the backward runs on three streams and the brackets "
+                                        "of concurrently running kernels stretch)")
         res["roofline_kernels"] = kernels
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(a.grid, a.points)

@@ -59,10 +59,14 @@ if "FETCH_SIZE_KB" in g and "WRITE_SIZE_KB" in g:
     out["fused_hbm_bytes_per_launch"] = 2 * g["FETCH_SIZE_KB"] * 1024 + g["WRITE_SIZE_KB"] * 1024
 hbm = 0.0
 for k in list(out):
-    if k.startswith("gather_bwd_") and isinstance(out[k], dict) and "WRITE_SIZE_KB" in out[k] and "FETCH_SIZE_KB" in out[k]:
-        hbm += 2 * out[k]["FETCH_SIZE_KB"] * 1024 + out[k]["WRITE_SIZE_KB"] * 1024     # all kernels of the backward scatter
+    if k.startswith("gather_bwd_") and "proj" not in k and isinstance(out[k], dict) and "WRITE_SIZE_KB" in out[k] and "FETCH_SIZE_KB" in out[k]:
+        hbm += 2 * out[k]["FETCH_SIZE_KB"] * 1024 + out[k]["WRITE_SIZE_KB"] * 1024     # the kernels of svr_gather_trilinear_bwd
 if hbm:
     out["gather_bwd_hbm_bytes"] = hbm
+pv = out.get("gather_bwd_proj_kernel")
+if pv and "FETCH_SIZE_KB" in pv and "WRITE_SIZE_KB" in pv:          # projected scatter: per launch (two launches per step)
+    out["proj_hbm_bytes_per_launch"] = 2 * pv["FETCH_SIZE_KB"] * 1024 + pv["WRITE_SIZE_KB"] * 1024
+    out["proj_atomic_bytes_per_launch"] = pv["WRITE_SIZE_KB"] * 1024
 if "gather_bwd_fused_kernel" in out:
     out["gather_bwd_write_bytes"] = out["gather_bwd_fused_kernel"].get("WRITE_SIZE_KB", 0.0) * 1024   # = float atomics issued
 out["source"] = (f"separate rocprofv3 --pmc passes (FETCH_SIZE; WRITE_SIZE) of `bench.py --steps 2 --warmup 1 {' '.join(extra)}` "
