@@ -130,6 +130,16 @@ def _relaunch_under_torchrun(a):
     return subprocess.call(cmd, env=env)
 
 
+def _stats(v):
+    """min / median / p90 / max / mean of a list of milliseconds."""
+    if not v:
+        return None
+    import statistics
+    w = sorted(v)
+    return {"n": len(w), "min": w[0], "median": statistics.median(w), "p90": w[min(len(w) - 1, int(round(0.9 * (len(w) - 1))))],
+            "max": w[-1], "mean": sum(w) / len(w)}
+
+
 class _KernelTimer:
     """HIP-event brackets around selected ops on the stream they are enqueued on (torch's current stream)."""
 
@@ -153,12 +163,20 @@ class _KernelTimer:
         setattr(mod, name, timed)
         return orig
 
+    def times(self, k):
+        return [e0.elapsed_time(e1) for e0, e1 in self.ev.get(k, [])]
+
     def ms_per_step(self, k, steps):
-        return sum(e0.elapsed_time(e1) for e0, e1 in self.ev.get(k, [])) / max(steps, 1)
+        return sum(self.times(k)) / max(steps, 1)
 
     def ms_per_launch(self, k):
-        v = self.ev.get(k, [])
-        return sum(e0.elapsed_time(e1) for e0, e1 in v) / max(len(v), 1)
+        v = self.times(k)
+        return sum(v) / max(len(v), 1)
+
+
+def _conv_key(op, x, co, ci):
+    B, D, H, W = x.shape[0], x.shape[1], x.shape[2], x.shape[3]
+    return f"{op}:{B}x{D}x{H}x{W}:{ci}->{co}"
 
 
 def main():
@@ -171,7 +189,8 @@ def main():
     ap.add_argument("--points", type=int, default=50000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fwd-only", action="store_true")
-    ap.add_argument("--no-query", action="store_true", help="skip the query-path (f32 / bf16 storage) measurement")
+    ap.add_argument("--no-query", action="store_true", help="skip the query-path (f32 / bf16 storage / lattice) measurement")
+    ap.add_argument("--no-diag", action="store_true", help="skip the untimed single-stream steps behind the timed region")
     ap.add_argument("--dist", choices=["uniform", "surface"], default="uniform",
                     help="query-point distribution; uniform (default) is the reported worst case")
     a = ap.parse_args()
@@ -191,6 +210,7 @@ def main():
     import svr_amd  # noqa: F401
     from svr_amd import ops
     from svr_amd.dp import DataParallelTrainer
+    from svr_amd.model import ifnet as _ifn
     from svr_amd.trainer import ImplicitRefinementTrainer
     from oracle import ifnet_oracle as O            # name-seeded weights only (checker-side helper)
 
@@ -213,50 +233,94 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # set-up, not warm-up: the first steps of a process create the side streams' allocator pools and the pinned slots, and
-    # the per-level scatter form is decided from the statistics of EARLIER steps (ifnet.SCATTER_FORM "auto") -- two steps
-    # until the path that is measured is the path that runs; then the W warm-up steps of the contract
+    # set-up, not warm-up: the first steps of a process size the step arena and the allocator pools, and the per-level
+    # scatter form is decided from the statistics of the step PULL_DECISION_LAG (3) steps back (ifnet.SCATTER_FORM "auto")
+    # -- SETUP_STEPS + the W warm-up steps of the contract run before the timed region
     for _ in range(SETUP_STEPS):
         dp.step(batch)
     sync()
     for _ in range(a.warmup):
         dp.step(batch)
-    # live HIP-event timing of the roofline kernel (the forward gather, fused with fc_0) over the timed region, on the
-    # stream it runs on (installed after the warm-up)
+    # live HIP-event timing over the timed region, on the stream the work is enqueued on: the roofline kernel (the fused
+    # gather -> fc_0 launch alone, ops.gather_fc0_run; ops.gather_fwd where the fused kernel does not apply), the gradient
+    # all-reduce, and one event per step boundary (per-step GPU times without a host synchronisation)
     kt = _KernelTimer(torch)
-    restore = [(ops, "gather_fwd", kt.wrap(ops, "gather_fwd")), (ops, "gather_fc0_fwd", kt.wrap(ops, "gather_fc0_fwd"))]
+    restore = [(ops, "gather_fwd", kt.wrap(ops, "gather_fwd")), (ops, "gather_fc0_run", kt.wrap(ops, "gather_fc0_run")),
+               (dp.bucket, "all_reduce_mean", kt.wrap(dp.bucket, "all_reduce_mean"))]
+    mem0 = torch.cuda.memory_stats(dev)
+    arena = trainer.ifnet.ifnet_feature_extractor._arena
+    grown0 = arena.grown
     sync()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]
+    host_ms = []
     t0 = time.perf_counter()
-    for _ in range(a.steps):
+    marks[0].record()
+    for i in range(a.steps):
+        h0 = time.perf_counter()
         out = dp.step(batch)
+        marks[i + 1].record()
+        host_ms.append((time.perf_counter() - h0) * 1e3)
     sync()
     dt = time.perf_counter() - t0
+    mem1 = torch.cuda.memory_stats(dev)
     for mod, name, orig in restore:
         setattr(mod, name, orig)
-    # the other kernels of `roofline_kernels` (scatter, GEMMs): DIAG_STEPS extra, untimed steps with the backward's three
-    # streams collapsed into one (ifnet.OVERLAP_BACKWARD off), so that a HIP-event bracket holds one kernel's own time --
-    # in the measured step those kernels run side by side and their brackets stretch 1.3-3.5x
-    from svr_amd.model import ifnet as _ifn
+    step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(a.steps)]
+    forms = {}
+    for key, h in _ifn._pull_hint.items():
+        forms[f"level{key[1]}"] = "pull (atomic-free)" if h["use"] else "item-order float atomics"
+    # the other kernels of `roofline_kernels` (encoder, scatter, GEMMs) and the roofline kernel stand-alone: DIAG_STEPS
+    # extra, untimed steps with the step's streams collapsed into one (ifnet.OVERLAP_BACKWARD off, SVR_NO_SIDE_STREAM), so
+    # that a HIP-event bracket holds one kernel's own time -- in the measured step those kernels run side by side and
+    # their brackets stretch 1.3-3.5x
     kd = _KernelTimer(torch)
-    diag = [(ops, "gather_bwd", kd.wrap(ops, "gather_bwd")), (ops, "gather_project_bwd", kd.wrap(ops, "gather_project_bwd")),
-            # linear_fwd(x (M,K), w (N,K)); linear_bwd_data(dy (M,N), w (N,K)); linear_bwd_weight(dy (M,N), x (M,K))
-            (ops, "linear_fwd", kd.wrap(ops, "linear_fwd", lambda x, w, *r, **k: f"linear_fwd:{x.shape[0]}x{w.shape[0]}x{x.shape[-1]}")),
-            (ops, "linear_bwd_data", kd.wrap(ops, "linear_bwd_data", lambda dy, w, *r, **k: f"linear_bwd_data:{dy.shape[0]}x{dy.shape[-1]}x{w.shape[-1]}")),
-            (ops, "linear_bwd_weight", kd.wrap(ops, "linear_bwd_weight", lambda dy, x, *r, **k: f"linear_bwd_weight:{dy.shape[0]}x{dy.shape[-1]}x{x.shape[-1]}"))]
-    prev_overlap, _ifn.OVERLAP_BACKWARD = _ifn.OVERLAP_BACKWARD, False
-    try:
-        for _ in range(DIAG_STEPS):
-            dp.step(batch)
-        sync()
-    finally:
-        _ifn.OVERLAP_BACKWARD = prev_overlap
-        for mod, name, orig in diag:
-            setattr(mod, name, orig)
+    if not a.no_diag:
+        w = kd.wrap
+        diag = [(ops, "gather_bwd", w(ops, "gather_bwd")), (ops, "gather_project_bwd", w(ops, "gather_project_bwd")),
+                (ops, "gather_fc0_run", w(ops, "gather_fc0_run")),
+                # linear_fwd(x (M,K), w (N,K)); linear_bwd_data(dy (M,N), w (N,K)); linear_bwd_weight(dy (M,N), x (M,K))
+                (ops, "linear_fwd", w(ops, "linear_fwd", lambda x, w, *r, **k: f"linear_fwd:{x.shape[0]}x{w.shape[0]}x{x.shape[-1]}")),
+                (ops, "linear_bwd_data", w(ops, "linear_bwd_data", lambda dy, w, *r, **k: f"linear_bwd_data:{dy.shape[0]}x{dy.shape[-1]}x{w.shape[-1]}")),
+                (ops, "linear_bwd_weight", w(ops, "linear_bwd_weight", lambda dy, x, *r, **k: f"linear_bwd_weight:{dy.shape[0]}x{dy.shape[-1]}x{x.shape[-1]}")),
+                # encoder: conv forward / backward-data / weight gradient keyed by volume and channels; BatchNorm passes
+                (ops, "conv3d_k3_fwd", w(ops, "conv3d_k3_fwd", lambda x, wt, *r, **k: _conv_key("conv_fwd", x, wt.shape[0], wt.shape[1]))),
+                (ops, "conv3d_c1_fwd_stats", w(ops, "conv3d_c1_fwd_stats", lambda x, wt, *r, **k: _conv_key("conv_in_fwd", x, wt.shape[0], 1))),
+                (ops, "conv3d_k3_bwd_data", w(ops, "conv3d_k3_bwd_data", lambda dy, wt, *r, **k: _conv_key("conv_bwd_data", dy, wt.shape[0], wt.shape[1]))),
+                (ops, "conv3d_k3_bwd_weight", w(ops, "conv3d_k3_bwd_weight", lambda x, dy, *r, **k: _conv_key("conv_bwd_weight", x, dy.shape[4], x.shape[4]))),
+                (ops, "bn_forward", w(ops, "bn_forward", lambda x, *r, **k: "bn_fwd:" + "x".join(str(v) for v in x.shape))),
+                (ops, "bn_backward", w(ops, "bn_backward", lambda x, *r, **k: "bn_bwd:" + "x".join(str(v) for v in x.shape)))]
+        prev_overlap, _ifn.OVERLAP_BACKWARD = _ifn.OVERLAP_BACKWARD, False
+        prev_env = os.environ.get("SVR_NO_SIDE_STREAM")
+        os.environ["SVR_NO_SIDE_STREAM"] = "1"
+        try:
+            for _ in range(DIAG_STEPS):
+                dp.step(batch)
+            sync()
+        finally:
+            _ifn.OVERLAP_BACKWARD = prev_overlap
+            if prev_env is None:
+                os.environ.pop("SVR_NO_SIDE_STREAM", None)
+            else:
+                os.environ["SVR_NO_SIDE_STREAM"] = prev_env
+            for mod, name, orig in diag:
+                setattr(mod, name, orig)
     loss = float(out["loss"].detach())
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
     if launched:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax)
+    # per-rank record (N > 1: gathered on rank 0, so that one run of the driver's 8-GPU node is diagnosable on its own)
+    mine = {"rank": rank, "local_rank": local_rank, "device": torch.cuda.current_device(),
+            "device_name": torch.cuda.get_device_name(dev), "wall_ms_per_step": dt / a.steps * 1e3,
+            "step_ms": _stats(step_ms), "host_enqueue_ms": _stats(host_ms),
+            "all_reduce_ms": _stats(kt.times("all_reduce_mean")),
+            "gather_fc0_ms": _stats(kt.times("gather_fc0_run") or kt.times("gather_fwd")),
+            "hipMalloc_calls_in_timed_region": mem1.get("num_device_alloc", 0) - mem0.get("num_device_alloc", 0),
+            "hipFree_calls_in_timed_region": mem1.get("num_device_free", 0) - mem0.get("num_device_free", 0)}
+    ranks = [mine]
+    if launched and world > 1:
+        ranks = [None] * world
+        dist.all_gather_object(ranks, mine)
 
     # forward only (no_grad, training-mode BatchNorm: the same kernels as the step's forward half), same batch
     fwd_ms = None
@@ -271,15 +335,15 @@ def main():
             fwd_ms = (time.perf_counter() - t1) / a.steps * 1e3
 
     # query path alone (cached pyramid -> gather + point MLP forward, no grad; the dense-grid-inference kernels):
-    # default f32 storage against the bf16-storage throughput mode (north_star "bf16 occupancy logits")
+    # default f32 storage against the bf16-storage throughput mode (north_star "bf16 occupancy logits"), and the f32 path
+    # on the reference's dense lattice (model/ifnet.py:202-229: C-order lattice incl. the +-0.5 planes, 32 768-point chunks)
     query = None
     if not a.no_query and rank == 0:
         query = {}
         net = trainer.ifnet
         pts = batch["points"]
         with torch.no_grad():
-            from svr_amd.model import ifnet as _ifn
-            f32_gather = "gather_fc0_fwd" if _ifn.FUSE_FC0 else "gather_fwd"
+            f32_gather = "gather_fc0_run" if _ifn.FUSE_FC0 else "gather_fwd"
             for name, storage, gname in (("f32", "f32", f32_gather), ("bf16", "bf16", "gather_fwd_bf16")):
                 levels = net.encode(batch["input"], storage)
                 z = net.query(levels, pts, spatial_sort=True)
@@ -294,167 +358,262 @@ def main():
                 setattr(ops, gname, orig)
                 query[name] = {"ms": ms, "gather_ms": kq.ms_per_launch(gname), "gather_op": gname, "logits": z.float()}
                 del levels
+            # dense lattice: one sample's pyramid, the lattice of its grid resolution in the reference's chunks
+            levels = net.encode(batch["input"][:1])
+            lat = _ifn.make_3d_grid((-0.5,) * 3, (0.5,) * 3, (a.grid,) * 3).to(dev)
+            chunk = 2048 * 16
+            prep = net.prepare_query(levels, chunk)
+
+            def lattice_pass():
+                outs = []
+                for pi in torch.split(lat, chunk):
+                    outs.append(torch.sigmoid(net.query(levels, pi.unsqueeze(0), prepared=prep)))
+                return torch.cat(outs, 1)
+            lattice_pass()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            reps = max(1, min(a.steps, 3))
+            for _ in range(reps):
+                lattice_pass()
+            torch.cuda.synchronize()
+            lms = (time.perf_counter() - t1) / reps * 1e3
+            query["lattice"] = {"ms": lms, "points": int(lat.shape[0]), "chunk": chunk, "value": lat.shape[0] / (lms * 1e-3),
+                                "unit": "query-points/s",
+                                "workload": f"one sample, {a.grid}^3 lattice incl. the +-0.5 planes (model/ifnet.py:202-229), "
+                                            f"{chunk}-point chunks, cached pyramid, fc_0 prepared once, sigmoid, values on device"}
+            del levels, lat
         zf, zb = query["f32"].pop("logits"), query["bf16"].pop("logits")
         query["bf16"]["logits_rel_dev_vs_f32_storage"] = float((zb - zf).abs().max() / zf.abs().max())
     if launched:
         dist.barrier()
 
     if rank == 0:
-        npts = a.batch * a.points
-        pts_per_step = world * npts
-        value = pts_per_step * a.steps / dt
-        fused = kt.ms_per_launch("gather_fc0_fwd") > 0
-        gkey = "gather_fc0_fwd" if fused else "gather_fwd"
-        gather_ms = kt.ms_per_launch(gkey)
-        kept = FUSED_KEPT_COLUMNS * 4 if fused else 0
-        alg_bytes = npts * ((FUSED_BYTES_PER_POINT_F32 + kept) if fused else GATHER_BYTES_PER_POINT_F32)
-        alg_rate = alg_bytes / (gather_ms * 1e-3) / 1e9 if gather_ms > 0 else None
-        # compulsory traffic: every pyramid volume once + coordinates + what the kernel must write once
-        # (unfused: the feature rows; fused: the h0 rows and the kept columns)
-        chans, d = [1, 16, 32, 64, 128, 128], a.grid
-        vol_elems = 0
-        for i, c in enumerate(chans):
-            vol_elems += c * d ** 3
-            if i >= 1:
-                d = max(d // 2, 1)
-        out_bytes = (256 * 4 + kept) if fused else 2583 * 4
-        compulsory = a.batch * (vol_elems * 4 + a.points * 12 + a.points * out_bytes)
-        traffic, bwd_atomic_bytes, bwd_hbm_bytes, tsrc, proj_hbm, proj_atomic = None, None, None, None, None, None
-        tfile = os.path.join(ROOT, "profiles", "gather_traffic.json")
-        if os.path.exists(tfile):
-            try:
-                t = json.load(open(tfile))
-                if t.get("batch") == a.batch and t.get("grid") == a.grid and t.get("points") == a.points \
-                        and t.get("dist", "uniform") == a.dist:
-                    traffic = t.get("fused_hbm_bytes_per_launch") if fused else t.get("hbm_bytes_per_launch")
-                    bwd_atomic_bytes = t.get("gather_bwd_write_bytes")
-                    bwd_hbm_bytes = t.get("gather_bwd_hbm_bytes")
-                    proj_hbm = t.get("proj_hbm_bytes_per_launch")
-                    proj_atomic = t.get("proj_atomic_bytes_per_launch")
-                    tsrc = t.get("source")
-            except Exception:
-                traffic = None
-        hbm_rate = traffic / (gather_ms * 1e-3) / 1e9 if (traffic and gather_ms > 0) else None
-        roofline = {
-            "kernel": ("gather_fc0_kernel (svr_gather_fc0_fwd: all 6 levels gathered slab by slab into LDS and multiplied into "
-                       "fc_0's 128 x 256 tile, one launch)") if fused else
-                      "gather_fwd_fused_kernel (svr_gather_trilinear_fwd, all 6 levels in one launch)",
-            "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBPS,
-            # HBM bytes actually moved (PMC) / live kernel time: a true fraction of the 8 TB/s roof (null without counters)
-            "achieved": hbm_rate, "frac": (hbm_rate / HBM_PEAK_GBPS) if hbm_rate else None,
-            "frac_of_achievable_6290": (hbm_rate / HBM_ACHIEVABLE_GBPS) if hbm_rate else None,
-            "traffic": traffic, "traffic_source": tsrc, "ms_per_launch": gather_ms,
-            "algorithmic_bytes_per_launch": alg_bytes, "algorithmic_GBps": alg_rate,
-            "algorithmic_frac_of_l2_peak_34500": (alg_rate / L2_PEAK_GBPS) if alg_rate else None,
-            "compulsory_bytes_per_launch": compulsory,
-            "compulsory_frac_of_hbm_peak": (compulsory / (gather_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if gather_ms > 0 else None,
-            "traffic_over_compulsory": (traffic / compulsory) if traffic else None,
-            "note": "algorithmic bytes are mostly L1/L2/Infinity-Cache hits, so they are priced against the L2 roof; frac is "
-                    "counter-measured HBM traffic against the HBM roof"}
-        if fused and gather_ms > 0:
-            tf = npts * 2.0 * 256 * FC0_K_FUSED * SPLIT_PRODUCTS / (gather_ms * 1e-3) / 1e12
-            roofline["mfma_TFLOPs"] = tf
-            roofline["mfma_frac_of_f16_peak"] = tf / MFMA_F16_PEAK_TFLOPS
-            roofline["note"] += ("; the kernel also carries fc_0's product (3 f16 MFMA products per f32 product): "
-                                 "mfma_frac_of_f16_peak.  It is bound by the vector-L1 rate of the corner reads "
-                                 "(64 B/clk/CU), not by HBM or the matrix cores -- the separate kernels it replaces took "
-                                 "2.05 (gather, HBM-write bound) + 2.13 ms (fc_0)")
-        res = {
-            "metric": "query-points/sec fwd+bwd (128^3 grid, 50k pts)", "value": value, "unit": "query-points/s",
-            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "setup_steps": SETUP_STEPS, "ms_per_step": dt / a.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[2] per GPU: {a.grid}^3 grid, {a.points} query points, batch "
-                                   f"{a.batch}/GPU, full 3D conv encoder + 6-level trilinear gather + occupancy MLP, "
-                                   "fwd+bwd+grad all-reduce+Adam",
-                       "global_batch": world * a.batch, "parallelism": f"dp{world}", "loss": loss, "points": a.dist,
-                       "arithmetic": "f32 storage everywhere; forward GEMMs/convs: 3-product f16 split on the f16 MFMA "
-                                     "(f32-level, ~3e-7 of f64); backward dX/dW GEMMs, conv backward-data and conv weight "
-                                     "gradients: bf16x3 split (~1.5e-5 per product); conv_in, BN, gather/scatter: exact f32"},
-            "roofline": roofline,
-        }
-        if fwd_ms is not None:
-            res["fwd_only"] = {"value": npts / (fwd_ms * 1e-3), "unit": "query-points/s", "ms_per_step": fwd_ms,
-                               "note": "rank 0, forward + loss under no_grad, training-mode BatchNorm"}
-        if query is not None:
-            for name, bpp in (("f32", GATHER_BYTES_PER_POINT_F32), ("bf16", GATHER_BYTES_PER_POINT_BF16)):
-                q = query[name]
-                if q["gather_op"] == "gather_fc0_fwd":
-                    bpp = FUSED_BYTES_PER_POINT_F32          # gather_ms then covers gather AND fc_0
-                q["value"] = npts / (q["ms"] * 1e-3)
-                q["unit"] = "query-points/s"
-                q["gather_algorithmic_GBps"] = npts * bpp / (q["gather_ms"] * 1e-3) / 1e9
-                q["gather_algorithmic_frac_of_l2_peak_34500"] = q["gather_algorithmic_GBps"] / L2_PEAK_GBPS
-            res["query_path"] = {"workload": f"cached {a.grid}^3 pyramid (batch {a.batch}), {npts} query points per pass: 6-level "
-                                             "trilinear gather + point MLP forward, no grad, points visited in Morton order (dense-grid inference kernels)",
-                                 "dtype_f32": query["f32"], "dtype_bf16": query["bf16"],
-                                 "note": "bf16 = separately named bf16-STORAGE mode (bf16 volumes / feature rows / activations, "
-                                         "f32 accumulation; never the default, not held to the fp32 1e-4 gate)"}
-        kernels = []
-        bwd_ms = kd.ms_per_launch("gather_bwd")
-        if bwd_ms > 0:
-            # compulsory traffic of the scatter: the gradient rows once + the gradient volumes (levels 1..5) once
-            bwd_comp = a.batch * (a.points * 2583 * 4 + (vol_elems - a.grid ** 3) * 4)
-            if fused:   # the 128-channel levels are projected: this call scatters the 784 columns of levels 1-3 only
-                dd, ve = a.grid, 0
-                for i, c in enumerate(chans[1:4]):
-                    ve += c * dd ** 3
-                    dd = max(dd // 2, 1)
-                bwd_comp = a.batch * (a.points * 784 * 4 + ve * 4)
-            rate = bwd_hbm_bytes / (bwd_ms * 1e-3) / 1e9 if bwd_hbm_bytes else None
-            kernels.append({"kernel": "gather_bwd (svr_gather_trilinear_bwd: per level the atomic-free pull form or the atomic "
-                                      "scatter over the joint item order, chosen from the point distribution)", "bound": "hbm",
-                            "unit": "GB/s", "peak": HBM_PEAK_GBPS,
-                            "achieved": rate, "frac": (rate / HBM_PEAK_GBPS) if rate else None, "ms_per_launch": bwd_ms,
-                            "traffic": bwd_hbm_bytes, "float_atomic_bytes": bwd_atomic_bytes,
-                            "algorithmic_bytes_per_launch": npts * (GATHER_BWD_BYTES_PER_POINT_F32 if not fused else 784 * 4 + 12 + 7 * 8 * 112 * 4),
-                            "compulsory_bytes_per_launch": bwd_comp,
-                            "compulsory_frac_of_hbm_peak": bwd_comp / (bwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-                            "note": "achieved = HBM bytes of all scatter kernels (PMC FETCH_SIZE x2 + WRITE_SIZE) / live time; the "
-                                    "round-1 kernel sat at the ~1.3 TB/s float-atomic rate (7.0 GB of atomics), the atomics left are "
-                                    "float_atomic_bytes"})
-        proj_ms = kd.ms_per_step("gather_project_bwd", DIAG_STEPS)
-        if proj_ms > 0:
-            kernels.append({"kernel": "gather_bwd_proj_kernel (svr_gather_project_bwd: fc_0's input gradient rows scattered into "
-                                      "(voxel, displacement, 256) slabs for the two 128-channel levels, incl. the slab memset)",
-                            "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBPS,
-                            "achieved": (2 * proj_hbm / (proj_ms * 1e-3) / 1e9) if proj_hbm else None,
-                            "frac": (2 * proj_hbm / (proj_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if proj_hbm else None,
-                            "float_atomic_bytes_per_step": (2 * proj_atomic) if proj_atomic else None,
-                            "ms_per_step": proj_ms, "launches_per_step": len(kd.ev["gather_project_bwd"]) / DIAG_STEPS,
-                            "algorithmic_bytes_per_step": 2 * npts * 7 * (256 * 4 + 12), "traffic": (2 * proj_hbm) if proj_hbm else None,
-                            "note": "reads each dh0 row (1 KB) once per displacement and level; float atomics only at run ends"})
-        # every GEMM of the step, keyed by the shape it was CALLED with: point-MLP layers have M = points, the two
-        # projected levels add voxel-row GEMMs (M = B*S^3); fc_0's backward runs over the kept column segments only
-        what = {"linear_fwd": "forward (f16x3)", "linear_bwd_data": "dX (bf16x3)", "linear_bwd_weight": "dW + bias gradient (bf16x3)"}
-        mlp_ms = 0.0
-        for key in sorted(kd.ev):
-            op, _, shape = key.partition(":")
-            if op not in what:
-                continue
-            M, N, K = (int(v) for v in shape.split("x"))
-            calls = len(kd.ev[key]) / DIAG_STEPS
-            ms = kd.ms_per_step(key, DIAG_STEPS)
-            if ms <= 0:
-                continue
-            mlp_ms += ms
-            tf = 2.0 * M * N * K * calls * SPLIT_PRODUCTS / (ms * 1e-3) / 1e12
-            who = "point-MLP" if M == npts else "projected-level voxel"
-            kernels.append({"kernel": f"{who} GEMM {what[op]} M={M} N={N} K={K}", "bound": "mfma", "unit": "TFLOP/s",
-                            "peak": MFMA_F16_PEAK_TFLOPS, "achieved": tf, "frac": tf / MFMA_F16_PEAK_TFLOPS,
-                            "ms_per_step": ms, "calls_per_step": calls, "f32_equivalent_TFLOPs": tf / SPLIT_PRODUCTS})
-        res["mlp_gemm_ms_per_step"] = mlp_ms
-        res["roofline_kernels_note"] = ("MFMA entries: achieved counts the 3 split products actually issued on the f16 / bf16 "
-                                        "matrix cores (the f32-equivalent rate is a third of it); ms = HIP-event brackets "
-                                        f"around the C-ABI calls, from {DIAG_STEPS} untimed single-stream steps behind the timed "
-                                        "region (in the measured step the backward runs on three streams and the brackets "
-                                        "of concurrently running kernels stretch)")
-        res["roofline_kernels"] = kernels
+        res = report(a, world, dt, loss, step_ms, host_ms, kt, kd, ranks, forms, fwd_ms, query, arena, grown0)
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(a.grid, a.points)
         print(json.dumps(res), flush=True)
     if launched:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def _backward_arithmetic():
+    from svr_amd import ops
+    modes = {ops.BACKWARD_GEMM, ops.BACKWARD_CONV, ops.BACKWARD_CONV_WEIGHT}
+    names = {"bf16x3": "bf16x3 split (~1.5e-5 per product)", "f16x3s": "scaled 3-product f16 split (f32-level)", "f32": "exact f32 MFMA"}
+    return " / ".join(names.get(m, m) for m in sorted(modes))
+
+
+def _traffic(a):
+    tfile = os.path.join(ROOT, "profiles", "gather_traffic.json")
+    if os.path.exists(tfile):
+        try:
+            t = json.load(open(tfile))
+            if t.get("batch") == a.batch and t.get("grid") == a.grid and t.get("points") == a.points \
+                    and t.get("dist", "uniform") == a.dist:
+                return t
+        except Exception:
+            pass
+    return {}
+
+
+def report(a, world, dt, loss, step_ms, host_ms, kt, kd, ranks, forms, fwd_ms, query, arena, grown0):
+    npts = a.batch * a.points
+    value = world * npts * a.steps / dt
+    fused = bool(kt.times("gather_fc0_run"))
+    gkey = "gather_fc0_run" if fused else "gather_fwd"
+    live = _stats(kt.times(gkey))                      # the launch inside the measured (multi-stream) step
+    alone = _stats(kd.times(gkey))                     # the same launch in the single-stream steps behind it
+    gather_ms = live["median"] if live else 0.0
+    kept = FUSED_KEPT_COLUMNS * 4 if fused else 0
+    alg_bytes = npts * ((FUSED_BYTES_PER_POINT_F32 + kept) if fused else GATHER_BYTES_PER_POINT_F32)
+    alg_rate = alg_bytes / (gather_ms * 1e-3) / 1e9 if gather_ms > 0 else None
+    # compulsory traffic: every pyramid volume once + coordinates + what the kernel must write once
+    # (unfused: the feature rows; fused: the h0 rows and the kept columns)
+    chans, d = [1, 16, 32, 64, 128, 128], a.grid
+    vol_elems, level_elems = 0, []
+    for i, c in enumerate(chans):
+        vol_elems += c * d ** 3
+        level_elems.append(c * d ** 3)
+        if i >= 1:
+            d = max(d // 2, 1)
+    out_bytes = (256 * 4 + kept) if fused else 2583 * 4
+    compulsory = a.batch * (vol_elems * 4 + a.points * 12 + a.points * out_bytes)
+    t = _traffic(a)
+    traffic = t.get("fused_hbm_bytes_per_launch") if fused else t.get("hbm_bytes_per_launch")
+    bwd_atomic_bytes, bwd_hbm_bytes = t.get("gather_bwd_write_bytes"), t.get("gather_bwd_hbm_bytes")
+    proj_hbm, proj_atomic, tsrc = t.get("proj_hbm_bytes_per_launch"), t.get("proj_atomic_bytes_per_launch"), t.get("source")
+    hbm_rate = traffic / (gather_ms * 1e-3) / 1e9 if (traffic and gather_ms > 0) else None
+    roofline = {
+        "kernel": ("gather_fc0_kernel (svr_gather_fc0_run: all 6 levels gathered slab by slab into LDS and multiplied into "
+                   "fc_0's 64 x 256 tile, one launch; the W split / slab table launches of svr_gather_fc0_prepare are outside "
+                   "the bracket)") if fused else
+                  "gather_fwd_fused_kernel (svr_gather_trilinear_fwd, all 6 levels in one launch)",
+        "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBPS,
+        # HBM bytes actually moved (PMC) / the MEDIAN live launch time in the timed region: a true fraction of the 8 TB/s
+        # roof (null without counters); min / max / mean of the brackets and the stand-alone time are beside it
+        "achieved": hbm_rate, "frac": (hbm_rate / HBM_PEAK_GBPS) if hbm_rate else None,
+        "frac_of_achievable_6290": (hbm_rate / HBM_ACHIEVABLE_GBPS) if hbm_rate else None,
+        "traffic": traffic, "traffic_source": tsrc, "ms_per_launch": gather_ms, "ms_per_launch_stats": live,
+        "ms_per_launch_single_stream": alone,
+        "frac_at_max_launch": (traffic / (live["max"] * 1e-3) / 1e9 / HBM_PEAK_GBPS) if (traffic and live) else None,
+        "algorithmic_bytes_per_launch": alg_bytes, "algorithmic_GBps": alg_rate,
+        "algorithmic_frac_of_l2_peak_34500": (alg_rate / L2_PEAK_GBPS) if alg_rate else None,
+        "compulsory_bytes_per_launch": compulsory,
+        "compulsory_frac_of_hbm_peak": (compulsory / (gather_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if gather_ms > 0 else None,
+        "traffic_over_compulsory": (traffic / compulsory) if traffic else None,
+        "note": "ms_per_launch = median HIP-event bracket of the kernel launch over the timed region (the side stream's plan "
+                "sorts may run beside it); algorithmic bytes are mostly L1/L2/Infinity-Cache hits, so they are priced against "
+                "the L2 roof; frac is counter-measured HBM traffic against the HBM roof"}
+    if fused and gather_ms > 0:
+        tf = npts * 2.0 * 256 * FC0_K_FUSED * SPLIT_PRODUCTS / (gather_ms * 1e-3) / 1e12
+        roofline["mfma_TFLOPs"] = tf
+        roofline["mfma_frac_of_f16_peak"] = tf / MFMA_F16_PEAK_TFLOPS
+        roofline["note"] += ("; the kernel also carries fc_0's product (3 f16 MFMA products per f32 product): "
+                             "mfma_frac_of_f16_peak.  It is bound by the vector-L1 rate of the corner reads "
+                             "(64 B/clk/CU), not by HBM or the matrix cores -- the separate kernels it replaces took "
+                             "2.05 (gather, HBM-write bound) + 2.13 ms (fc_0)")
+    st = _stats(step_ms)
+    res = {
+        "metric": "query-points/sec fwd+bwd (128^3 grid, 50k pts)", "value": value, "unit": "query-points/s",
+        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "setup_steps": SETUP_STEPS, "ms_per_step": dt / a.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"BASELINE configs[2] per GPU: {a.grid}^3 grid, {a.points} query points, batch "
+                               f"{a.batch}/GPU, full 3D conv encoder + 6-level trilinear gather + occupancy MLP, "
+                               "fwd+bwd+grad all-reduce+Adam",
+                   "global_batch": world * a.batch, "parallelism": f"dp{world}", "loss": loss, "points": a.dist,
+                   "arithmetic": "f32 storage everywhere; forward GEMMs/convs: 3-product f16 split on the f16 MFMA "
+                                 "(f32-level, ~3e-7 of f64); backward dX/dW GEMMs, conv backward-data and conv weight "
+                                 f"gradients: {_backward_arithmetic()}; conv_in, BN, gather/scatter: exact f32"},
+        # every timed step on its own (HIP events at the step boundaries on the main stream; no host synchronisation inside
+        # the region): a transient shows as max >> median, uniform contention as a shifted median
+        "step_ms": st, "step_ms_list": [round(v, 3) for v in step_ms],
+        "step_max_over_median": (st["max"] / st["median"]) if st else None,
+        "host_enqueue_ms": _stats(host_ms),
+        "allocator": {"hipMalloc_calls_in_timed_region": ranks[0]["hipMalloc_calls_in_timed_region"],
+                      "hipFree_calls_in_timed_region": ranks[0]["hipFree_calls_in_timed_region"],
+                      "arena_bytes": arena.nbytes(), "arena_buffers_grown_in_timed_region": arena.grown - grown0,
+                      "note": "the step's large cross-stream buffers (kept columns 1.28 GB, their gradient, gradient volumes, "
+                              "scatter plans) live in a per-module arena allocated in the set-up steps"},
+        "scatter_forms": forms,
+        "all_reduce_ms": ranks[0]["all_reduce_ms"],
+        "roofline": roofline,
+    }
+    if world > 1:
+        res["ranks"] = ranks
+        res["rccl"] = {"world_size": world, "backend": "nccl (RCCL)", "devices": {str(r["rank"]): r["device"] for r in ranks}}
+    if fwd_ms is not None:
+        res["fwd_only"] = {"value": npts / (fwd_ms * 1e-3), "unit": "query-points/s", "ms_per_step": fwd_ms,
+                           "note": "rank 0, forward + loss under no_grad, training-mode BatchNorm"}
+    if query is not None:
+        for name, bpp in (("f32", GATHER_BYTES_PER_POINT_F32), ("bf16", GATHER_BYTES_PER_POINT_BF16)):
+            q = query[name]
+            if q["gather_op"] == "gather_fc0_run":
+                bpp = FUSED_BYTES_PER_POINT_F32          # gather_ms then covers gather AND fc_0
+            q["value"] = npts / (q["ms"] * 1e-3)
+            q["unit"] = "query-points/s"
+            q["gather_algorithmic_GBps"] = npts * bpp / (q["gather_ms"] * 1e-3) / 1e9
+            q["gather_algorithmic_frac_of_l2_peak_34500"] = q["gather_algorithmic_GBps"] / L2_PEAK_GBPS
+        res["query_path"] = {"workload": f"cached {a.grid}^3 pyramid (batch {a.batch}), {npts} query points per pass: 6-level "
+                                         "trilinear gather + point MLP forward, no grad, points visited in Morton order (dense-grid inference kernels)",
+                             "dtype_f32": query["f32"], "dtype_bf16": query["bf16"], "lattice": query.get("lattice"),
+                             "note": "bf16 = separately named bf16-STORAGE mode (bf16 volumes / feature rows / activations, "
+                                     "f32 accumulation; never the default, not held to the fp32 1e-4 gate)"}
+    kernels = []
+    bwd_ms = kd.ms_per_launch("gather_bwd")
+    if bwd_ms > 0:
+        # compulsory traffic of the scatter: the gradient rows once + the gradient volumes (levels 1..5) once
+        bwd_comp = a.batch * (a.points * 2583 * 4 + (vol_elems - a.grid ** 3) * 4)
+        if fused:   # the 128-channel levels are projected: this call scatters the 784 columns of levels 1-3 only
+            bwd_comp = a.batch * (a.points * 784 * 4 + sum(level_elems[1:4]) * 4)
+        rate = bwd_hbm_bytes / (bwd_ms * 1e-3) / 1e9 if bwd_hbm_bytes else None
+        kernels.append({"kernel": "gather_bwd (svr_gather_trilinear_bwd: per level the atomic-free pull form or the atomic "
+                                  "scatter over the joint item order, chosen from the point distribution)", "bound": "hbm",
+                        "unit": "GB/s", "peak": HBM_PEAK_GBPS,
+                        "achieved": rate, "frac": (rate / HBM_PEAK_GBPS) if rate else None, "ms_per_launch": bwd_ms,
+                        "traffic": bwd_hbm_bytes, "float_atomic_bytes": bwd_atomic_bytes,
+                        "algorithmic_bytes_per_launch": npts * (GATHER_BWD_BYTES_PER_POINT_F32 if not fused else 784 * 4 + 12 + 7 * 8 * 112 * 4),
+                        "compulsory_bytes_per_launch": bwd_comp,
+                        "compulsory_frac_of_hbm_peak": bwd_comp / (bwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                        "note": "achieved = HBM bytes of all scatter kernels (PMC FETCH_SIZE x2 + WRITE_SIZE) / live time; the "
+                                "round-1 kernel sat at the ~1.3 TB/s float-atomic rate (7.0 GB of atomics), the atomics left are "
+                                "float_atomic_bytes"})
+    proj_ms = kd.ms_per_step("gather_project_bwd", DIAG_STEPS)
+    if proj_ms > 0:
+        kernels.append({"kernel": "gather_bwd_proj_kernel (svr_gather_project_bwd: fc_0's input gradient rows scattered into "
+                                  "(voxel, displacement, 256) slabs for the two 128-channel levels, incl. the slab memset)",
+                        "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBPS,
+                        "achieved": (2 * proj_hbm / (proj_ms * 1e-3) / 1e9) if proj_hbm else None,
+                        "frac": (2 * proj_hbm / (proj_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if proj_hbm else None,
+                        "float_atomic_bytes_per_step": (2 * proj_atomic) if proj_atomic else None,
+                        "ms_per_step": proj_ms, "launches_per_step": len(kd.ev["gather_project_bwd"]) / DIAG_STEPS,
+                        "algorithmic_bytes_per_step": 2 * npts * 7 * (256 * 4 + 12), "traffic": (2 * proj_hbm) if proj_hbm else None,
+                        "note": "reads each dh0 row (1 KB) once per displacement and level; float atomics only at run ends"})
+    # every GEMM of the step, keyed by the shape it was CALLED with: point-MLP layers have M = points, the two
+    # projected levels add voxel-row GEMMs (M = B*S^3); fc_0's backward runs over the kept columns only
+    what = {"linear_fwd": "forward (f16x3)", "linear_bwd_data": "dX", "linear_bwd_weight": "dW + bias gradient"}
+    mlp_ms, enc_ms = 0.0, {"conv_fwd": 0.0, "conv_in_fwd": 0.0, "conv_bwd_data": 0.0, "conv_bwd_weight": 0.0, "bn_fwd": 0.0, "bn_bwd": 0.0}
+    for key in sorted(kd.ev):
+        op, _, shape = key.partition(":")
+        calls = len(kd.ev[key]) / DIAG_STEPS
+        ms = kd.ms_per_step(key, DIAG_STEPS)
+        if ms <= 0:
+            continue
+        if op in what:
+            M, N, K = (int(v) for v in shape.split("x"))
+            mlp_ms += ms
+            tf = 2.0 * M * N * K * calls * SPLIT_PRODUCTS / (ms * 1e-3) / 1e12
+            who = "point-MLP" if M == npts else "projected-level voxel"
+            kernels.append({"kernel": f"{who} GEMM {what[op]} M={M} N={N} K={K}", "bound": "mfma", "unit": "TFLOP/s",
+                            "peak": MFMA_F16_PEAK_TFLOPS, "achieved": tf, "frac": tf / MFMA_F16_PEAK_TFLOPS,
+                            "ms_per_step": ms, "calls_per_step": calls, "f32_equivalent_TFLOPs": tf / SPLIT_PRODUCTS})
+        elif op in ("conv_fwd", "conv_bwd_data", "conv_bwd_weight", "conv_in_fwd"):
+            # encoder convolutions (40.8 GFLOP / sample forward at 128^3): 2 * 27 * Ci * Co FLOP per voxel,
+            # three split products issued per f32 product except conv_in's exact-f32 MFMA form
+            vol, ch = shape.split(":")
+            Bv, Dv, Hv, Wv = (int(v) for v in vol.split("x"))
+            ci, co = (int(v) for v in ch.split("->"))
+            enc_ms[op] += ms
+            flop = 2.0 * 27 * ci * co * Bv * Dv * Hv * Wv * calls
+            if op == "conv_in_fwd":          # Ci = 1: HBM bound (writes the 16-channel volume), exact f32
+                byts = Bv * Dv * Hv * Wv * (1 + co) * 4 * calls
+                rate = byts / (ms * 1e-3) / 1e9
+                kernels.append({"kernel": f"encoder conv_in forward + BatchNorm statistics {vol} 1->{co}", "bound": "hbm", "unit": "GB/s",
+                                "peak": HBM_PEAK_GBPS, "achieved": rate, "frac": rate / HBM_PEAK_GBPS, "ms_per_step": ms,
+                                "calls_per_step": calls, "algorithmic_bytes_per_step": byts})
+                continue
+            split = 1 if (ci == 1 or co == 1) else SPLIT_PRODUCTS
+            tf = flop * split / (ms * 1e-3) / 1e12
+            names = {"conv_fwd": "forward (f16x3)", "conv_bwd_data": "backward-data", "conv_bwd_weight": "weight gradient"}
+            kernels.append({"kernel": f"encoder conv {names[op]} {vol} {ci}->{co}", "bound": "mfma", "unit": "TFLOP/s",
+                            "peak": MFMA_F16_PEAK_TFLOPS if split > 1 else 157.3, "achieved": tf,
+                            "frac": tf / (MFMA_F16_PEAK_TFLOPS if split > 1 else 157.3), "ms_per_step": ms, "calls_per_step": calls,
+                            "f32_equivalent_TFLOPs": tf / split})
+        elif op in ("bn_fwd", "bn_bwd"):
+            # BatchNorm + pool passes: HBM bound.  Algorithmic bytes per element of the (B,D,H,W,C) volume: forward =
+            # statistics read (skipped where the producing conv delivers them) + apply read + write (+ pooled write / 8 and
+            # its argmax); backward = reduce pass (x, dy reads) + apply pass (x, dy reads, dx write)
+            dims = [int(v) for v in shape.split("x")]
+            elems = 1
+            for v in dims:
+                elems *= v
+            enc_ms[op] += ms
+            per_elem = (4 + 4 + 4 + 0.5 + 0.125) if op == "bn_fwd" else (8 + 8 + 4)
+            byts = elems * per_elem * calls
+            rate = byts / (ms * 1e-3) / 1e9
+            kernels.append({"kernel": f"encoder BatchNorm{'+pool forward' if op == 'bn_fwd' else ' backward (+unpool, +ReLU mask)'} {shape}",
+                            "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBPS, "achieved": rate, "frac": rate / HBM_PEAK_GBPS,
+                            "ms_per_step": ms, "calls_per_step": calls, "algorithmic_bytes_per_step": byts})
+    res["mlp_gemm_ms_per_step"] = mlp_ms
+    res["encoder_ms_per_step"] = dict(enc_ms, total=sum(enc_ms.values()),
+                                      note="single-stream steps; conv FLOPs: SURVEY 8(a6), 40.8 GFLOP / sample forward")
+    res["roofline_kernels_note"] = ("MFMA entries: achieved counts the 3 split products actually issued on the f16 / bf16 "
+                                    "matrix cores (the f32-equivalent rate is a third of it); ms = HIP-event brackets "
+                                    f"around the C-ABI calls, from {DIAG_STEPS} untimed single-stream steps behind the timed "
+                                    "region (in the measured step the backward runs on three streams and the brackets "
+                                    "of concurrently running kernels stretch)")
+    res["roofline_kernels"] = kernels
+    return res
 
 
 if __name__ == "__main__":

@@ -165,16 +165,29 @@ int svr_gather_trilinear_fwd(const svr_gather_desc *d, const float *points /*(B,
  * split, as svr_linear_fwd_f16x3), so the (B*N, row_stride) feature matrix is never written or read:
  *   Y[b*N+n][0:n_out] = epi( features[b*N+n][:] . W[0:n_out][:]^T )         (model/ifnet.py:156-197 + :43-45,55)
  * W (n_out, >= last used column), row stride ldw, in the feature row's column layout (svr_level.col); n_out = 256.
- * keep_levels: bit l set = the gathered values of level l are ALSO stored to `features` (same layout as
- * svr_gather_trilinear_fwd; with any bit set the padding columns behind the last level are zero-filled) -- the rows a
- * backward still needs; 0 = inference, `features` may be NULL.  d->order must be NULL (sort the points instead);
+ * keep_levels: bit l set = the gathered values of level l are ALSO stored to `features` -- the rows a backward still
+ * needs; 0 = inference, `features` may be NULL.  The kept matrix has row stride ldf floats (<= 0: d->row_stride) and
+ * level l starts at column keep_cols[l] (host array of n_levels entries, read at call time; NULL: svr_level.col, i.e.
+ * the layout of svr_gather_trilinear_fwd) -- a compact matrix of the kept levels only (800 columns instead of a
+ * 2592-wide row for the 128-architecture's training step).  With any bit set the columns behind the last kept level
+ * (keep_cols given) / the last level (NULL) up to ldf are zero-filled.  d->order must be NULL (sort the points instead);
  * channel counts 1 (at most one level), 16, 32 or multiples of 64; every volume < 2^30 elements;
  * svr_gather_fc0_supported(d) tells.  workspace: svr_gather_fc0_workspace(d, n_out) bytes.                       */
 int32_t svr_gather_fc0_supported(const svr_gather_desc *d);
 int64_t svr_gather_fc0_workspace(const svr_gather_desc *d, int32_t n_out);
 int svr_gather_fc0_fwd(const svr_gather_desc *d, const float *points, const float *W, int64_t ldw, const float *bias, float *Y,
-                       int64_t ldy, int32_t n_out, float *features, uint32_t keep_levels, int32_t epilogue, void *workspace,
-                       void *stream);
+                       int64_t ldy, int32_t n_out, float *features, int64_t ldf, const int32_t *keep_cols, uint32_t keep_levels,
+                       int32_t epilogue, void *workspace, void *stream);
+/* The same in two calls, for callers that query ONE pyramid with ONE weight matrix many times (dense-grid inference,
+ * model/ifnet.py:215-229: one chunk of the lattice per call): svr_gather_fc0_prepare splits W into the kernel's f16
+ * planes and stores the slab table in `workspace` (three small launches), svr_gather_fc0_run is the gather -> fc_0
+ * kernel alone and may be repeated with other points / B*N <= the prepared descriptor's, same volumes, same layout.
+ * svr_gather_fc0_fwd = prepare + run.                                                                             */
+int svr_gather_fc0_prepare(const svr_gather_desc *d, const float *W, int64_t ldw, int32_t n_out, float *features, int64_t ldf,
+                           const int32_t *keep_cols, uint32_t keep_levels, void *workspace, void *stream);
+int svr_gather_fc0_run(const svr_gather_desc *d, const float *points, const float *bias, float *Y, int64_t ldy, int32_t n_out,
+                       float *features, int64_t ldf, const int32_t *keep_cols, uint32_t keep_levels, int32_t epilogue,
+                       void *workspace, void *stream);
 /* gvol[level] += scatter of gfeatures (autograd of grid_sample wrt the volume);
  * levels with gvol == NULL are skipped.  gpoints (B,N,3) may be NULL; when given it is
  * OVERWRITTEN with the gradient wrt the query points.                                   */

@@ -1053,6 +1053,8 @@ int check_desc(const svr_gather_desc *d, bool bwd) {
     SVR_CHECK(L.C == 1 || L.C == 16 || L.C == 32 || L.C == 64 || L.C == 128, SVR_E_UNSUPPORTED,
               "gather: level %d: C=%d (supported: 1,16,32,64,128)", l, L.C);
     SVR_CHECK(L.D > 0 && L.H > 0 && L.W > 0, SVR_E_BADSHAPE, "gather: level %d: empty volume", l);
+    if (bwd && L.gvol == nullptr && L.vol == nullptr) continue;  // level skipped by the backward (e.g. a projected level: the
+                                                                 // compact kept-column matrix has no columns for it)
     SVR_CHECK(L.col >= 0 && L.col + 7 * L.C <= d->row_stride, SVR_E_BADSHAPE,
               "gather: level %d: columns [%d,%d) exceed row stride %d", l, L.col, L.col + 7 * L.C, d->row_stride);
     SVR_CHECK(L.C == 1 || L.col % 4 == 0, SVR_E_ALIGN, "gather: level %d: col %d not 16-byte aligned", l, L.col);

@@ -3,18 +3,23 @@
 // Replaces, in one kernel, the six F.grid_sample calls + torch.cat of model/ifnet.py:156-197 AND the first Conv1d of the
 // point MLP (model/ifnet.py:43-45,55: fc_0 + ReLU).  The separate kernels (gather.hip's fused forward, gemm_f16x3.hip)
 // write the (B*N, 2592) feature matrix -- 4.1 GB at 128^3 x 50k x 8 -- and read it back: 2.05 + 2.13 ms, both bound by
-// those bytes.  Here a workgroup owns 128 consecutive (Morton-sorted) points and all 256 output columns:
+// those bytes.  Here a workgroup owns FC_TM = 64 consecutive (Morton-sorted) points and all 256 output columns (two
+// workgroups per CU; 128-point tiles at one workgroup per CU are a build option, -DFC_TM=128):
 //   * 4 PRODUCER waves gather one K-slab (<= 64 feature columns of one level: one or two displacements x a channel
-//     range) for the 128 points -- same geometry and summation order as gather.hip, so the values are bit-identical --
+//     range) for the tile's points -- same geometry and summation order as gather.hip, so the values are bit-identical --
 //     split it into the f16 hi / lo planes of the 3-product split (f16x3.h) and store it in LDS;
-//   * 4 CONSUMER waves (one per SIMD, 128 x 64 outputs each) multiply the previous slab from the other LDS buffer with
+//   * 4 CONSUMER waves (one per SIMD, FC_TM x 64 outputs each) multiply the previous slab from the other LDS buffer with
 //     W's pre-split planes, which they read straight from L2 in MFMA fragment layout (no LDS staging, no redundancy
 //     between the consumers), three v_mfma_f32_32x32x16_f16 per 32 x 32 x 16 block;
 //   * one s_barrier per slab hands the buffers over.
 // The kernel is bound by the bytes the producers pull through the vector L1 (93 KB per point of corner reads, most of
 // them cache hits) -- the matrix cores wait for the gather, not the other way round.
-// Levels whose rows the backward still needs (the ones that are not projected, ifnet.py) are ALSO written to the
-// feature matrix, in gather.hip's layout: 800 of 2592 columns at the 128-architecture.
+// Levels whose rows the backward still needs (the ones that are not projected, ifnet.py) are ALSO written to a feature
+// matrix: either in gather.hip's full row layout or -- what the training step uses -- a COMPACT kept-column matrix
+// (its own column per level and row stride: 800 columns instead of a 2592-wide row at the 128-architecture).
+//
+// Measurement switches (parts of the kernel turned off: wrong results by construction) exist only in builds with
+// -DSVR_FC0_MEASURE (tools/exp/prof_fc0.sh); the production kernel carries none.
 //
 // Build with -ffp-contract=off (gather_common.h).
 #include "common.h"
@@ -56,6 +61,7 @@ constexpr int FC_LDS_BYTES = 2 * FSLAB * 4;
 struct FcLevel {
   const float *vol;
   int C, D, H, W, col;
+  int kcol;  // first column of the level in the KEPT matrix (col for the full row layout)
 };
 struct FcSlab {  // 32-bit fields: scalar loads.  (Sub-dword fields were fetched with VECTOR loads + s_waitcnt vmcnt(0), which
                  // drained the consumers' W prefetch at every slab boundary.)
@@ -162,7 +168,7 @@ __device__ __forceinline__ void produce_slab(const FcLevel L, const FcSlab S, ui
   const int col = jj * NC + c4;  // column inside the slab
   uint32_t *dstg = buf + (col >> 4) * FKSTEP + ((col & 15) >> 1) + (RPW * pw + g) * FLW;
   GLOBAL_AS char *featt = (GLOBAL_AS char *)(feat + m0 * row_stride);
-  const uint32_t fo0 = (uint32_t)((RPW * pw + g) * row_stride + L.col + (S.j0 + jj) * C + S.c0 + c4) * 4u;
+  const uint32_t fo0 = (uint32_t)((RPW * pw + g) * row_stride + L.kcol + (S.j0 + jj) * C + S.c0 + c4) * 4u;
   const int live = M - m0 < FTM ? (int)(M - m0) : FTM;
   struct Iter {
     f32x4 v[8];
@@ -240,7 +246,7 @@ __device__ __forceinline__ void produce_c1(const FcLevel L, const FcSlab S, uint
     if (j < 7) {
       b16[(row * FLW) * 2 + j] = __builtin_bit_cast(uint16_t, h);
       b16[(FPLANE + row * FLW) * 2 + j] = __builtin_bit_cast(uint16_t, l);
-      if (S.keep && m0 + row < M) feat[(m0 + row) * row_stride + L.col + j] = acc;
+      if (S.keep && m0 + row < M) feat[(m0 + row) * row_stride + L.kcol + j] = acc;
     } else {  // halves 7 .. 15 of the row: zeros
       b16[(row * FLW) * 2 + 7] = 0;
       b16[(FPLANE + row * FLW) * 2 + 7] = 0;
@@ -257,7 +263,11 @@ __device__ __forceinline__ void produce(const FcArgs &A, int s, uint32_t *buf, c
                                         int N, float disp, int ac, float *feat, int row_stride, int pw, int lane, int dbg) {
   const FcSlab S = A.S[s];
   const FcLevel L = A.L[S.level];
+#ifdef SVR_FC0_MEASURE
   if ((dbg >> (8 + S.level)) & 1) return;
+#else
+  (void)dbg;
+#endif
   if (S.lp == 0) {
     produce_c1(L, S, buf, points, m0, M, N, disp, ac, feat, row_stride, pw * 64 + lane);
     return;
@@ -282,16 +292,23 @@ __global__ void args_store_kernel(FcArgs A, FcArgs *__restrict__ dst) {
   for (unsigned i = threadIdx.x; i < sizeof(FcArgs) / 4; i += blockDim.x) reinterpret_cast<uint32_t *>(dst)[i] = src[i];
 }
 
-// `dbg` (environment SVR_FC0_DBG, 0 in production) switches parts of the kernel OFF for measurements -- the results are
-// then wrong by construction: bit 0 producers idle, bit 1 consumers idle, bit 2 no epilogue, bit 3 return at once,
-// bit 8 + l: level l is not gathered (tools/exp/prof_fc0.sh; DESIGN.md section 5b quotes the numbers).
+// `dbg` is a constant 0 unless the file is built with -DSVR_FC0_MEASURE (then: environment SVR_FC0_DBG), which switches
+// parts of the kernel OFF for measurements -- the results are then wrong by construction: bit 0 producers idle, bit 1
+// consumers idle, bit 2 no epilogue, bit 3 return at once, bit 8 + l: level l is not gathered (tools/exp/prof_fc0.sh;
+// DESIGN.md section 5b quotes the numbers).
+#ifdef SVR_FC0_MEASURE
+#define FC_DBG(x) (x)
+#else
+#define FC_DBG(x) 0
+#endif
 __global__ __launch_bounds__(512, FTM == 64 ? 4 : 2) void gather_fc0_kernel(const FcArgs *__restrict__ Ap, const float *__restrict__ points,
                                                             const uint16_t *__restrict__ W0,
                                                             const uint32_t *__restrict__ amax, const float *__restrict__ bias,
                                                             float *__restrict__ Y, int64_t ldy, float *__restrict__ feat,
                                                             int row_stride, int pad_start, int64_t M, int N, float disp, int ac,
-                                                            int relu, int dbg) {
+                                                            int relu, int dbg_arg) {
   extern __shared__ uint32_t lds[];
+  const int dbg = FC_DBG(dbg_arg);
   const FcArgs &A = *Ap;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int64_t m0 = (int64_t)blockIdx.x * FTM;
@@ -409,7 +426,7 @@ __global__ __launch_bounds__(512, FTM == 64 ? 4 : 2) void gather_fc0_kernel(cons
 }
 
 // slab table of a descriptor; false if a level's channel count has no slab shape
-bool build_slabs(const svr_gather_desc *d, uint32_t keep_mask, FcArgs &A) {
+bool build_slabs(const svr_gather_desc *d, uint32_t keep_mask, FcArgs &A, const int32_t *keep_cols = nullptr) {
   int ns = 0, k = 0;
   auto add = [&](int level, int j0, int nj, int lp, int c0, int cols) {
     if (ns >= FC_MAX_SLABS) return false;
@@ -429,7 +446,7 @@ bool build_slabs(const svr_gather_desc *d, uint32_t keep_mask, FcArgs &A) {
   for (int pass = 0; pass < 2; ++pass)
     for (int l = 0; l < d->n_levels; ++l) {
       const svr_level &lv = d->level[l];
-      A.L[l] = FcLevel{lv.vol, lv.C, lv.D, lv.H, lv.W, lv.col};
+      A.L[l] = FcLevel{lv.vol, lv.C, lv.D, lv.H, lv.W, lv.col, keep_cols ? keep_cols[l] : lv.col};
       const int C = lv.C;
       if ((C == 1) != (pass == 0)) continue;
       bool ok = true;
@@ -487,43 +504,116 @@ extern "C" int64_t svr_gather_fc0_workspace(const svr_gather_desc *d, int32_t n_
   return 2 * (int64_t)n_out * A.KF * (int64_t)sizeof(uint16_t) + 1024 + (int64_t)sizeof(FcArgs);
 }
 
-extern "C" int svr_gather_fc0_fwd(const svr_gather_desc *d, const float *points, const float *W, int64_t ldw, const float *bias,
-                                  float *Y, int64_t ldy, int32_t n_out, float *feat, uint32_t keep_levels, int32_t epilogue,
-                                  void *workspace, void *stream) {
-  int rc = check_desc(d, "gather_fc0_fwd");
-  if (rc != SVR_OK) return rc;
+namespace {
+
+struct FcWorkspace {
+  uint32_t *amax;
+  uint16_t *p0;
+  FcArgs *Ad;
+};
+FcWorkspace carve(void *workspace, int32_t n_out, int KF) {
+  FcWorkspace w;
+  w.amax = (uint32_t *)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+  w.p0 = (uint16_t *)(w.amax + 64);
+  uint16_t *p1 = w.p0 + (int64_t)n_out * KF;
+  w.Ad = (FcArgs *)(((uintptr_t)(p1 + (int64_t)n_out * KF) + 255) & ~(uintptr_t)255);
+  return w;
+}
+
+// validates the kept-matrix arguments; kend = end of the last kept level's columns
+int check_keep(const svr_gather_desc *d, const FcArgs &A, const float *feat, int64_t ldf, uint32_t keep_levels, int64_t *kend) {
   const int64_t M = (int64_t)d->B * d->N;
-  if (M == 0) return SVR_OK;
-  SVR_CHECK(points && W && Y && workspace, SVR_E_BADARG, "gather_fc0_fwd: null pointer");
-  SVR_CHECK(n_out == FTN, SVR_E_UNSUPPORTED, "gather_fc0_fwd: %d output columns (the kernel is built for %d)", n_out, FTN);
-  SVR_CHECK(epilogue == SVR_EPI_NONE || ((epilogue == SVR_EPI_BIAS || epilogue == SVR_EPI_BIAS_RELU) && bias), SVR_E_BADARG,
-            "gather_fc0_fwd: epilogue %d", epilogue);
-  SVR_CHECK(keep_levels == 0 || (feat && d->row_stride % 4 == 0 && ((uintptr_t)feat & 15) == 0 && M * d->row_stride < (1LL << 31)),
-            SVR_E_BADARG, "gather_fc0_fwd: keep_levels needs a 16-byte aligned feature matrix with < 2^31 elements");
+  SVR_CHECK(keep_levels == 0 || (feat && ldf % 4 == 0 && ((uintptr_t)feat & 15) == 0 && M * ldf < (1LL << 31)),
+            SVR_E_BADARG, "gather_fc0: keep_levels needs a 16-byte aligned feature matrix with < 2^31 elements");
+  *kend = 0;
+  for (int l = 0; l < d->n_levels; ++l) {
+    if (!((keep_levels >> l) & 1)) continue;
+    const int kc = A.L[l].kcol, w = 7 * d->level[l].C;
+    SVR_CHECK(kc >= 0 && kc + w <= ldf && (d->level[l].C == 1 || kc % 4 == 0), SVR_E_BADSHAPE,
+              "gather_fc0: kept level %d: columns [%d,%d) in a row of %ld", l, kc, kc + w, (long)ldf);
+    for (int m = 0; m < l; ++m)
+      if ((keep_levels >> m) & 1)
+        SVR_CHECK(kc + w <= A.L[m].kcol || A.L[m].kcol + 7 * d->level[m].C <= kc, SVR_E_BADSHAPE,
+                  "gather_fc0: kept levels %d and %d overlap", m, l);
+    *kend = std::max<int64_t>(*kend, kc + w);
+  }
+  return SVR_OK;
+}
+
+}  // namespace
+
+extern "C" int svr_gather_fc0_prepare(const svr_gather_desc *d, const float *W, int64_t ldw, int32_t n_out, float *feat,
+                                      int64_t ldf, const int32_t *keep_cols, uint32_t keep_levels, void *workspace,
+                                      void *stream) {
+  int rc = check_desc(d, "gather_fc0_prepare");
+  if (rc != SVR_OK) return rc;
+  if ((int64_t)d->B * d->N == 0) return SVR_OK;
+  SVR_CHECK(W && workspace, SVR_E_BADARG, "gather_fc0_prepare: null pointer");
+  SVR_CHECK(n_out == FTN, SVR_E_UNSUPPORTED, "gather_fc0_prepare: %d output columns (the kernel is built for %d)", n_out, FTN);
+  if (ldf <= 0) ldf = d->row_stride;
   FcArgs A;
-  SVR_CHECK(build_slabs(d, keep_levels, A), SVR_E_UNSUPPORTED, "gather_fc0_fwd: a level's channel count has no slab shape (1, 16, 32, 64 k)");
-  for (int l = 0; l < d->n_levels; ++l)
-    if (d->level[l].C == 1 && ((keep_levels >> l) & 1))
-      SVR_CHECK(d->level[l].col + 7 <= d->row_stride, SVR_E_BADSHAPE, "gather_fc0_fwd: level %d does not fit the row", l);
+  SVR_CHECK(build_slabs(d, keep_levels, A, keep_cols), SVR_E_UNSUPPORTED,
+            "gather_fc0_prepare: a level's channel count has no slab shape (1, 16, 32, 64 k)");
+  int64_t kend;
+  if ((rc = check_keep(d, A, feat, ldf, keep_levels, &kend)) != SVR_OK) return rc;
   hipStream_t s = (hipStream_t)stream;
-  uint32_t *amax = (uint32_t *)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
-  uint16_t *p0 = (uint16_t *)(amax + 64);
-  uint16_t *p1 = p0 + (int64_t)n_out * A.KF;
-  FcArgs *Ad = (FcArgs *)(((uintptr_t)(p1 + (int64_t)n_out * A.KF) + 255) & ~(uintptr_t)255);
+  const FcWorkspace ws = carve(workspace, n_out, A.KF);
   // W's columns: every column of the layout the slabs cover (the row's padding columns never enter the product)
   int64_t kw = 0;
   for (int l = 0; l < d->n_levels; ++l) kw = std::max<int64_t>(kw, d->level[l].col + 7 * d->level[l].C);
-  (void)hipMemsetAsync(amax, 0, sizeof(uint32_t), s);
+  (void)hipMemsetAsync(ws.amax, 0, sizeof(uint32_t), s);
   hipLaunchKernelGGL(w_amax_kernel, dim3((unsigned)std::min<int64_t>(cdiv(n_out * kw, 1024), 1024)), dim3(256), 0, s, W, ldw,
-                     (int64_t)n_out, kw, amax);
-  hipLaunchKernelGGL(split_w_fused_kernel, dim3((unsigned)cdiv(A.KF, 64), (unsigned)n_out), dim3(64), 0, s, A, W, ldw, amax, p0, (int)n_out);
-  hipLaunchKernelGGL(args_store_kernel, dim3(1), dim3(256), 0, s, A, Ad);
-  hipError_t e = hipFuncSetAttribute((const void *)gather_fc0_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FC_LDS_BYTES);
-  SVR_CHECK(e == hipSuccess, (int)e, "gather_fc0_fwd: cannot reserve %d bytes of LDS: %s", FC_LDS_BYTES, hipGetErrorString(e));
+                     (int64_t)n_out, kw, ws.amax);
+  hipLaunchKernelGGL(split_w_fused_kernel, dim3((unsigned)cdiv(A.KF, 64), (unsigned)n_out), dim3(64), 0, s, A, W, ldw, ws.amax,
+                     ws.p0, (int)n_out);
+  hipLaunchKernelGGL(args_store_kernel, dim3(1), dim3(256), 0, s, A, ws.Ad);
+  return launch_status("gather_fc0_prepare");
+}
+
+extern "C" int svr_gather_fc0_run(const svr_gather_desc *d, const float *points, const float *bias, float *Y, int64_t ldy,
+                                  int32_t n_out, float *feat, int64_t ldf, const int32_t *keep_cols, uint32_t keep_levels,
+                                  int32_t epilogue, void *workspace, void *stream) {
+  int rc = check_desc(d, "gather_fc0_run");
+  if (rc != SVR_OK) return rc;
+  const int64_t M = (int64_t)d->B * d->N;
+  if (M == 0) return SVR_OK;
+  SVR_CHECK(points && Y && workspace, SVR_E_BADARG, "gather_fc0_run: null pointer");
+  SVR_CHECK(n_out == FTN, SVR_E_UNSUPPORTED, "gather_fc0_run: %d output columns (the kernel is built for %d)", n_out, FTN);
+  SVR_CHECK(epilogue == SVR_EPI_NONE || ((epilogue == SVR_EPI_BIAS || epilogue == SVR_EPI_BIAS_RELU) && bias), SVR_E_BADARG,
+            "gather_fc0_run: epilogue %d", epilogue);
+  if (ldf <= 0) ldf = d->row_stride;
+  FcArgs A;  // (the slab table is rebuilt on the host only for its sizes and the argument checks; the kernel reads the
+             // copy svr_gather_fc0_prepare stored in the workspace)
+  SVR_CHECK(build_slabs(d, keep_levels, A, keep_cols), SVR_E_UNSUPPORTED,
+            "gather_fc0_run: a level's channel count has no slab shape (1, 16, 32, 64 k)");
+  int64_t kend;
+  if ((rc = check_keep(d, A, feat, ldf, keep_levels, &kend)) != SVR_OK) return rc;
+  int64_t kw = 0;
+  for (int l = 0; l < d->n_levels; ++l) kw = std::max<int64_t>(kw, d->level[l].col + 7 * d->level[l].C);
+  // kept matrix in the full row layout: the padding starts behind the last LEVEL (kept or not), as svr_gather_trilinear_fwd
+  const int64_t pad_start = keep_cols ? kend : kw;
+  const FcWorkspace ws = carve(workspace, n_out, A.KF);
+  static const hipError_t lds_attr =  // once per process (an immutable kernel attribute, the library's only global state)
+      hipFuncSetAttribute((const void *)gather_fc0_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FC_LDS_BYTES);
+  SVR_CHECK(lds_attr == hipSuccess, (int)lds_attr, "gather_fc0_run: cannot reserve %d bytes of LDS: %s", FC_LDS_BYTES,
+            hipGetErrorString(lds_attr));
   const float *eb = epilogue == SVR_EPI_NONE ? nullptr : bias;
   const int relu = epilogue == SVR_EPI_BIAS_RELU ? 1 : 0;
-  hipLaunchKernelGGL(gather_fc0_kernel, dim3((unsigned)cdiv(M, FTM)), dim3(512), FC_LDS_BYTES, s, Ad, points, p0, amax, eb, Y,
-                     ldy, feat, d->row_stride, keep_levels ? (int)kw : -1, M, d->N, d->displacement, d->align_corners, relu,
-                     getenv("SVR_FC0_DBG") ? atoi(getenv("SVR_FC0_DBG")) : 0);
-  return launch_status("gather_fc0_fwd");
+#ifdef SVR_FC0_MEASURE
+  const int dbg = getenv("SVR_FC0_DBG") ? atoi(getenv("SVR_FC0_DBG")) : 0;
+#else
+  const int dbg = 0;
+#endif
+  hipLaunchKernelGGL(gather_fc0_kernel, dim3((unsigned)cdiv(M, FTM)), dim3(512), FC_LDS_BYTES, (hipStream_t)stream, ws.Ad, points,
+                     ws.p0, ws.amax, eb, Y, ldy, feat, (int)ldf, keep_levels ? (int)pad_start : -1, M, d->N, d->displacement,
+                     d->align_corners, relu, dbg);
+  return launch_status("gather_fc0_run");
+}
+
+extern "C" int svr_gather_fc0_fwd(const svr_gather_desc *d, const float *points, const float *W, int64_t ldw, const float *bias,
+                                  float *Y, int64_t ldy, int32_t n_out, float *feat, int64_t ldf, const int32_t *keep_cols,
+                                  uint32_t keep_levels, int32_t epilogue, void *workspace, void *stream) {
+  int rc = svr_gather_fc0_prepare(d, W, ldw, n_out, feat, ldf, keep_cols, keep_levels, workspace, stream);
+  if (rc != SVR_OK) return rc;
+  return svr_gather_fc0_run(d, points, bias, Y, ldy, n_out, feat, ldf, keep_cols, keep_levels, epilogue, workspace, stream);
 }

@@ -19,6 +19,7 @@ import torch
 import torch.nn as nn
 
 from .. import ops
+from ..arena import StepArena
 
 _ARCH = {
     # stages: ((conv attr names), bn attr name); channels per stage; gather displacement; align_corners
@@ -70,43 +71,48 @@ PULL_MAX_WALK = 64
 _pull_hint = {}       # (device, level, dims, C, B, N) -> {"use": last decision, "slots": [(pinned int32[2], event), ...]}
 
 
+PULL_DECISION_LAG = 3   # steps between a plan's statistic and the decision that uses it
+
+
 def _pull_decision(key, plan, side):
-    """Use the pull form?  Decided from the most recent plan statistic that has ARRIVED on the host (the host runs about a
-    step ahead of the GPU, so that is usually the one of two steps ago); this step's statistic is queued behind the plan
-    on the side stream into a free pinned slot.  No synchronisation, no blocking read."""
-    h = _pull_hint.setdefault(key, {"use": False, "slots": [], "seq": 0, "seen": -1})
+    """Use the pull form?  Decided from the plan statistic of the step PULL_DECISION_LAG steps back -- a FIXED lag, so the
+    form a level takes in step s is a function of the data alone and not of how far the host happens to run ahead of the
+    GPU (round 2 took "the most recent statistic that has arrived": two runs of the same workload could take different
+    forms in the same step).  The statistic travels through a ring of pinned slots (queued behind the plan on the side
+    stream); DataParallelTrainer keeps at most 2 steps in flight, so the slot read here has normally arrived long ago --
+    if it has not (an unthrottled caller), the host waits for it.  The first steps of a shape use the item order."""
+    h = _pull_hint.setdefault(key, {"use": False, "slots": [None] * (PULL_DECISION_LAG + 1), "seq": 0})
     if torch.cuda.is_current_stream_capturing():
-        return h["use"]            # inside a HIP-graph capture: no event queries / pinned allocations; the decision of the
+        return h["use"]            # inside a HIP-graph capture: no event waits / pinned allocations; the decision of the
         #                            eager warm-up steps is baked into the graph
-    free = None
-    for slot in h["slots"]:
-        if slot["event"].query():
-            if slot["seq"] > h["seen"]:
-                h["seen"] = slot["seq"]
-                h["use"] = 0 < int(slot["host"][0]) <= PULL_MAX_WALK
-            free = slot
-    if free is None and len(h["slots"]) < 4:
-        free = {"host": torch.empty(2, dtype=torch.int32, pin_memory=True), "event": torch.cuda.Event(), "seq": -1}
-        h["slots"].append(free)
-    if free is not None:
-        free["host"].copy_(plan.stats, non_blocking=True)
-        free["seq"] = h["seq"]
-        free["event"].record(side)
-        h["seq"] += 1
+    seq, ring = h["seq"], h["slots"]
+    old = ring[(seq - PULL_DECISION_LAG) % len(ring)] if seq >= PULL_DECISION_LAG else None
+    if old is not None:
+        old["event"].synchronize()
+        h["use"] = 0 < int(old["host"][0]) <= PULL_MAX_WALK
+    slot = ring[seq % len(ring)]
+    if slot is None:
+        slot = ring[seq % len(ring)] = {"host": torch.empty(2, dtype=torch.int32, pin_memory=True), "event": torch.cuda.Event()}
+    slot["host"].copy_(plan.stats, non_blocking=True)
+    slot["event"].record(side)
+    h["seq"] = seq + 1
     return h["use"]
 
 
-def _level_orders_async(pts, D, H, W, n_levels, align, layout=None, disp=None, proj_levels=()):
+def _level_orders_async(pts, D, H, W, n_levels, align, layout=None, disp=None, proj_levels=(), arena=None):
     """Backward-scatter preparation that depends only on the points, computed on a side stream beside the encoder;
     returns (orders per level, pull plans per level, ready event).  Level l has the pyramid's resolution
-    (D, H, W) >> (l - 1) for l >= 1 (level 0 is the input grid, one channel: neither).  See SCATTER_FORM."""
+    (D, H, W) >> (l - 1) for l >= 1 (level 0 is the input grid, one channel: neither).  See SCATTER_FORM.
+    layout: the layout of the gradient rows the scatter will read (the full FeatureLayout, or the KeptLayout of the fused
+    step).  arena: the step's StepArena -- the plans' arrays then live there (no allocator traffic on the side stream)."""
     B, N = pts.shape[0], pts.shape[1]
     orders = [None] * n_levels
     plans = [None] * n_levels
     main = torch.cuda.current_stream()
     side = _get_side_stream(pts.device)
     side.wait_stream(main)          # pts may have just been produced on the main stream
-    pts.record_stream(side)         # ... and must not return to the main stream's pool while the side stream reads it
+    if arena is None:
+        pts.record_stream(side)     # ... and must not return to the main stream's pool while the side stream reads it
     launched = False
     form = SCATTER_FORM
     fits32 = layout is not None and N > 0 and 7 * B * N < 2 ** 31 and B * N * layout.row_stride < 2 ** 31
@@ -114,15 +120,18 @@ def _level_orders_async(pts, D, H, W, n_levels, align, layout=None, disp=None, p
         for l in range(1, n_levels):
             dhw = (max(D >> (l - 1), 1), max(H >> (l - 1), 1), max(W >> (l - 1), 1))
             C = layout.channels[l] if layout is not None else 0
+            tag = f"L{l}."
             if l in proj_levels:                     # backward-only projection: items by (cell, displacement)
                 if PROJ_TWO_PASS and min(dhw) >= PROJ_TWO_PASS_MIN_DIM:
                     orders[l] = ops.project_plan(pts, dhw, disp, align)      # two-pass form: no float atomics
+                    orders[l].record_stream(main)
                 else:
-                    orders[l] = ops.item_order(pts, dhw, disp, align, with_j=True)
-                orders[l].record_stream(main)
+                    orders[l] = ops.item_order(pts, dhw, disp, align, with_j=True, arena=arena, tag=tag)
+                    if arena is None:
+                        orders[l].record_stream(main)
                 launched = True
             elif form in ("auto", "pull") and fits32 and ops.pull_plan_supported(B, N, dhw, C, layout.row_stride):
-                plan = ops.pull_plan(pts, dhw, C, layout.col[l], layout.row_stride, disp, align)
+                plan = ops.pull_plan(pts, dhw, C, layout.col[l], layout.row_stride, disp, align, arena=arena, tag=tag)
                 plan.record_stream(main)
                 if form == "pull" or _pull_decision((pts.device.index, l, dhw, C, B, N), plan, side):
                     plans[l] = plan
@@ -130,8 +139,9 @@ def _level_orders_async(pts, D, H, W, n_levels, align, layout=None, disp=None, p
                     orders[l] = plan.items            # the plan's sorted item ids are this level's item order
                 launched = True
             elif form in ("auto", "pull", "items") and fits32:
-                orders[l] = ops.item_order(pts, dhw, disp, align)
-                orders[l].record_stream(main)
+                orders[l] = ops.item_order(pts, dhw, disp, align, arena=arena, tag=tag)
+                if arena is None:
+                    orders[l].record_stream(main)
                 launched = True
             elif N >= 0.15 * dhw[0] * dhw[1] * dhw[2] and N > 64:
                 orders[l] = ops.voxel_order(pts, dhw, align)
@@ -161,6 +171,8 @@ PROJ_TWO_PASS_MIN_DIM = 16
 FUSE_FC0 = os.environ.get("SVR_NO_FUSED_FC0") is None
 # Fused + projected backward: the kept-column branch on the side stream beside the projected branch (SVR_NO_BWD_OVERLAP=1: serial)
 OVERLAP_BACKWARD = os.environ.get("SVR_NO_BWD_OVERLAP") is None
+# The step's large cross-stream buffers live in a per-module StepArena (arena.py); SVR_NO_ARENA=1: ordinary allocations
+USE_ARENA = os.environ.get("SVR_NO_ARENA") is None
 
 
 def _fc0_fusable(channels, B, dims, n_out):
@@ -194,7 +206,15 @@ class _ProjLink:
             start = b
         if start < layout.row_stride:
             keep.append((start, layout.row_stride))
-        self.keep = keep                                # column segments dX0 / dW0 still have to cover
+        # the raw-grid level (C == 1) gets a segment of its own, so that "its gradient is only needed for d(loss)/d(input)"
+        # can never drop the columns of another kept level that happens to share a segment with it
+        raw = [(layout.col[l], layout.col[l] + 7) for l, c in enumerate(layout.channels) if c == 1 and l not in levels]
+        split = []
+        for a, b in keep:
+            cuts = sorted({a, b} | {c for r in raw for c in r if a < c < b})
+            split += list(zip(cuts[:-1], cuts[1:]))
+        self.keep = split                               # column segments dX0 / dW0 still have to cover
+        self.raw = set(raw)                             # ... those of them that hold nothing but the raw-grid level
 
 
 class _EncoderGatherFn(torch.autograd.Function):
@@ -205,7 +225,7 @@ class _EncoderGatherFn(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, ext, grad_mode, link, w0p, b0, x, points, *params):
+    def forward(ctx, ext, grad_mode, link, lease, w0p, b0, x, points, *params):
         """b0 given (with link and w0p): FUSED form -- the output is h0 = relu(fc_0(rows)) straight from the gather
         (gather_fc0.hip), the rows of the levels that are not projected are kept for the backward, and backward()
         takes the gradient wrt fc_0's PRE-activation (what _PointMLPFn's headless form returns for its input)."""
@@ -226,11 +246,24 @@ class _EncoderGatherFn(torch.autograd.Function):
         will_backward = bool(grad_mode) and any(ctx.needs_input_grad)
         ctx.link = link if (will_backward and link is not None) else None
         if ctx.link is not None:
-            ctx.link.need_level0 = bool(ctx.needs_input_grad[5])
+            ctx.link.need_level0 = bool(ctx.needs_input_grad[6])
+        # the step arena (large cross-stream buffers, allocated once): held from here to the end of backward()
+        if lease is not None and not (will_backward and x.is_cuda):
+            lease.release()
+            lease = None
+        ctx.lease = lease
+        arena = lease.arena if lease is not None else None
+        ctx.fused = b0 is not None
+        nlev = nst + 1
+        keep = []
+        if ctx.fused and will_backward:
+            keep = [l for l in range(nlev) if ctx.link is None or l not in ctx.link.levels]
+        # fused step: the backward reads the COMPACT kept-column matrix (800 columns at the 128-architecture)
+        ctx.klay = ext._layout.subset(keep) if keep else None
         if will_backward and x.is_cuda:
             ctx.level_orders, ctx.level_plans, ctx.orders_ready = _level_orders_async(
-                pts, D, H, W, nst + 1, ext._align, ext._layout, ext._disp,
-                proj_levels=ctx.link.levels if ctx.link is not None else ())
+                pts, D, H, W, nlev, ext._align, ctx.klay if ctx.klay is not None else ext._layout, ext._disp,
+                proj_levels=ctx.link.levels if ctx.link is not None else (), arena=arena)
         for si, (convs, bn) in enumerate(ext._stages):
             acts = []
             cur = inp
@@ -250,11 +283,12 @@ class _EncoderGatherFn(torch.autograd.Function):
             levels.append(y)
             saved.append((inp, acts, argmax, ss, mean))
             inp = pooled
-        ctx.fused = b0 is not None
         if ctx.fused:
-            keep = [l for l in range(len(levels)) if ctx.link is None or l not in ctx.link.levels] if will_backward else []
+            rows_out = None
+            if keep and arena is not None:
+                rows_out = arena.get("kept_rows", (B * pts.shape[1], ctx.klay.row_stride), torch.float32, x.device)
             out, feat = ops.gather_fc0_fwd(levels, pts, ext._layout, ext._disp, ext._align, w0p.detach(), b0.detach(), relu=True,
-                                           keep_levels=keep)
+                                           keep_levels=keep, keep_layout=ctx.klay, rows_out=rows_out, arena=arena)
             ctx.feat = feat
         else:
             out = feat = ops.gather_fwd(levels, pts, ext._layout, ext._disp, ext._align)
@@ -266,12 +300,12 @@ class _EncoderGatherFn(torch.autograd.Function):
             with torch.cuda.stream(side):
                 # (levels with a pull plan are written by plain stores: no zero fill)
                 proj = ctx.link.levels if ctx.link is not None else ()
-                ctx.gvols = [None] + [None if l in proj else
-                                      (torch.empty_like(v) if ctx.level_plans[l] is not None else torch.zeros_like(v))
+                ctx.gvols = [None] + [None if l in proj else _gvol(arena, l, v, zero=ctx.level_plans[l] is None)
                                       for l, v in enumerate(levels) if l >= 1]
-                for g in ctx.gvols[1:]:
-                    if g is not None:
-                        g.record_stream(main)
+                if arena is None:
+                    for g in ctx.gvols[1:]:
+                        if g is not None:
+                            g.record_stream(main)
                 ctx.orders_ready = torch.cuda.Event()
                 ctx.orders_ready.record(side)
         ctx.ext, ctx.saved, ctx.levels, ctx.pts = ext, saved, levels, pts
@@ -283,15 +317,19 @@ class _EncoderGatherFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gfeat):
         ext, saved, levels, pts = ctx.ext, ctx.saved, ctx.levels, ctx.pts
-        need_x, need_pts = ctx.needs_input_grad[5], ctx.needs_input_grad[6]
+        need_x, need_pts = ctx.needs_input_grad[6], ctx.needs_input_grad[7]
         gfeat = gfeat.contiguous()
         link = ctx.link
         proj = link.levels if link is not None else ()
+        lease, ctx.lease = ctx.lease, None
+        arena = lease.arena if lease is not None else None
+        klay = ctx.klay if ctx.fused else None
+        scatter_layout = klay if klay is not None else ext._layout
         dw0_keep = db0 = None
         level_orders, level_plans = ctx.level_orders, ctx.level_plans
         if level_orders is None:
             level_orders, level_plans, ready = _level_orders_async(pts, *levels[0].shape[1:4], len(levels), ext._align,
-                                                                   ext._layout, ext._disp, proj_levels=proj)
+                                                                   scatter_layout, ext._disp, proj_levels=proj, arena=arena)
         else:
             ready = ctx.orders_ready
         if ops.GATHER_FLAGS & ops._lib.GATHER_DETERMINISTIC:      # the serial test scatter accumulates into zeros
@@ -302,7 +340,7 @@ class _EncoderGatherFn(torch.autograd.Function):
             ctx.gvols = None
         else:
             gvols = [torch.zeros_like(levels[0]) if need_x else None] + \
-                    [None if l in proj else (torch.empty_like(v) if level_plans[l] is not None else torch.zeros_like(v))
+                    [None if l in proj else _gvol(arena, l, v, zero=level_plans[l] is None)
                      for l, v in enumerate(levels) if l >= 1]
         main = torch.cuda.current_stream() if gfeat.is_cuda else None
         # Fused forward + projection: the backward of the KEPT columns (dW0 / dX0 over 800 columns, then the scatter of
@@ -312,36 +350,36 @@ class _EncoderGatherFn(torch.autograd.Function):
         fork = (ctx.fused and link is not None and main is not None and OVERLAP_BACKWARD
                 and not torch.cuda.is_current_stream_capturing())      # (a captured step keeps the serial order)
         keep_stream = _get_side_stream(gfeat.device) if fork else main
+        skip = ()
         if ctx.fused:
-            # fused forward: fc_0's backward lives here.  gfeat is dz0 (B*N, 256); dW0 / dX0 only over the kept columns
+            # fused forward: fc_0's backward lives here.  gfeat is dz0 (B*N, 256); dW0 / dX0 only over the kept columns,
+            # ONE product each over the compact kept-column matrix
             dh0, feat, w0p = gfeat, ctx.feat, ctx.w0p
             ctx.feat = None
-            keep = link.keep if link is not None else [(0, ext._layout.row_stride)]
+            cols = klay.full_cols_on(w0p.device)
+            w0k = w0p[:, cols]                           # (256, 800): fc_0's weights of the kept columns (zeros behind the padding)
             dw0_keep = torch.zeros_like(w0p)
             if fork:
                 # (no record_stream on what the side streams read: dh0, the kept rows, the gradient volumes ... stay
-                # referenced until main has joined both streams, so the allocator cannot hand them out earlier -- and a
-                # recorded multi-GB block that is freed while the host runs a step ahead cannot be reused in time, which
-                # made the allocator grow and flush its cache: 40-70 ms steps)
+                # referenced until main has joined both streams -- or live in the step arena -- so the allocator cannot
+                # hand them out earlier)
                 keep_stream.wait_stream(main)
-            lvl0 = ext._layout.col[0]
             # dW0 over the kept columns is a leaf (needed at the return only): third stream
             w_stream = _get_side_stream(gfeat.device, 1) if fork else main
             if fork:
                 w_stream.wait_stream(main)
             with torch.cuda.stream(w_stream) if fork else contextlib.nullcontext():
-                for a, b in keep:
-                    dws, dbs = ops.linear_bwd_weight(dh0, feat[:, a:b], want_bias=db0 is None)
-                    dw0_keep[:, a:b] = dws
-                    db0 = dbs if db0 is None else db0
+                dwk, db0 = ops.linear_bwd_weight(dh0, feat, want_bias=True)
+                dw0_keep[:, cols[:klay.width]] = dwk[:, :klay.width]
                 if fork:
                     db0.record_stream(main)
             with torch.cuda.stream(keep_stream) if fork else contextlib.nullcontext():
-                gfeat = torch.empty_like(feat)           # the projected levels' columns are never read
-                for a, b in keep:
-                    if a == lvl0 and not need_x and link is not None:
-                        continue                         # raw-grid columns: their gradient is only needed for d(loss)/d(input)
-                    ops.linear_bwd_data(dh0, w0p[:, a:b], out=gfeat[:, a:b])
+                if arena is not None:
+                    gfeat = arena.get("kept_grad", tuple(feat.shape), torch.float32, feat.device)
+                else:
+                    gfeat = torch.empty_like(feat)
+                ops.linear_bwd_data(dh0, w0k, out=gfeat)
+            skip = tuple(l for l in range(len(levels)) if klay.col[l] < 0)
             if link is not None:
                 link.dh0 = dh0
         if link is not None and link.dh0 is None:
@@ -349,9 +387,9 @@ class _EncoderGatherFn(torch.autograd.Function):
         with torch.cuda.stream(keep_stream) if fork else contextlib.nullcontext():
             if ready is not None:
                 torch.cuda.current_stream().wait_event(ready)
-            gpts = ops.gather_bwd(levels, gvols, pts, gfeat, ext._layout, ext._disp, ext._align, want_gpoints=need_pts,
+            gpts = ops.gather_bwd(levels, gvols, pts, gfeat, scatter_layout, ext._disp, ext._align, want_gpoints=need_pts,
                                   level_orders=[None if l in proj else o for l, o in enumerate(level_orders)],
-                                  level_plans=level_plans)
+                                  level_plans=level_plans, skip_levels=skip)
             if fork:
                 keep_done = torch.cuda.Event()
                 keep_done.record(keep_stream)
@@ -404,10 +442,20 @@ class _EncoderGatherFn(torch.autograd.Function):
             gx = (gx + gvols[0]).view(ctx.x_shape)
         if dw0p is None:
             dw0p = dw0_keep
-        out = [None, None, None, dw0p, db0, gx, gpts]
+        if lease is not None:
+            lease.release()     # every kernel that touches the arena is enqueued; the next step orders itself behind them
+        out = [None, None, None, None, dw0p, db0, gx, gpts]
         for p in ext._param_list:
             out.append(grads.get(p))
         return tuple(out)
+
+
+def _gvol(arena, level, like, zero):
+    """Gradient volume of a level for the backward scatter: from the step arena when there is one."""
+    if arena is None:
+        return torch.zeros_like(like) if zero else torch.empty_like(like)
+    g = arena.get(f"gvol{level}", tuple(like.shape), like.dtype, like.device)
+    return g.zero_() if zero else g
 
 
 class _PointMLPFn(torch.autograd.Function):
@@ -465,12 +513,11 @@ class _PointMLPFn(torch.autograd.Function):
         dw0 = torch.zeros_like(w0p)
         dfeat = torch.empty_like(feat)            # the projected levels' columns are never read
         db0 = None
-        lvl0 = link.layout.col[0]
         for a, b in link.keep:
             dws, dbs = ops.linear_bwd_weight(dh0, feat[:, a:b], want_bias=db0 is None)
             dw0[:, a:b] = dws
             db0 = dbs if db0 is None else db0
-            if a <= lvl0 < b and not link.need_level0 and a == lvl0:
+            if (a, b) in link.raw and not link.need_level0:
                 continue                          # raw-grid columns: their gradient is only needed for d(loss)/d(input)
             ops.linear_bwd_data(dh0, w0p[:, a:b], out=dfeat[:, a:b])
         return dfeat, None, dw0, db0, dw1, db1, dw2, db2, dwo, dbo, None
@@ -487,6 +534,7 @@ class _ExtractorBase(nn.Module):
         self.displacments = _displacements(a["disp"])            # plain attribute, like the reference
         chans = [1] + [convs[-1].out_channels for convs, _ in self._stages]
         self._layout = ops.FeatureLayout(chans)
+        self._arena = StepArena()      # the step's large cross-stream buffers, allocated once (arena.py)
         self._param_list = []
         for convs, bn in self._stages:
             for c in convs:
@@ -519,13 +567,13 @@ class _ExtractorBase(nn.Module):
     def feature_rows_from_levels(self, levels, points, order=None):
         return ops.gather_fwd(levels, points.float().contiguous(), self._layout, self._disp, self._align, order=order)
 
-    def feature_rows(self, x, points, link=None, w0p=None, b0=None):
+    def feature_rows(self, x, points, link=None, w0p=None, b0=None, lease=None):
         """(B*N, FS) rows in the internal column layout (what the point MLP consumes).  link / w0p: the backward-only
         projection of the wide levels (IFNet.forward wires it; the encoder's backward then also returns its share of
         fc_0's weight gradient)."""
         if not x.is_cuda:
             raise RuntimeError("IF-Net HIP path needs GPU tensors (no CPU fallback)")
-        return _EncoderGatherFn.apply(self, torch.is_grad_enabled(), link, w0p, b0, x.float(), points.float(), *self._param_list)
+        return _EncoderGatherFn.apply(self, torch.is_grad_enabled(), link, lease, w0p, b0, x.float(), points.float(), *self._param_list)
 
     def forward(self, x, points):
         """Reference layout (B, sumC, 1, 7, N) -- model/ifnet.py:197; used by API-compat callers."""
@@ -632,10 +680,24 @@ class IFNet(nn.Module):
         return ops.fc_out_fwd_bf16(h, self.fc_out.weight.reshape(-1).contiguous(), self.fc_out.bias, row_map).view(B, N)
 
     @torch.no_grad()
-    def query(self, levels, points, spatial_sort=False):
+    def prepare_query(self, levels, max_points):
+        """Per-pyramid preparation of the f32 query path (fc_0's weights split for the fused kernel, slab table): pass the
+        result to query(..., prepared=) when one pyramid is queried chunk by chunk (dense-grid inference); None when the
+        fused kernel does not cover the shapes."""
+        ext = self.ifnet_feature_extractor
+        if levels[0].dtype != torch.float32 or not FUSE_FC0 or self.fc_0.out_channels != 256:
+            return None
+        B = levels[0].shape[0]
+        probe = torch.empty(B, 1, 3, device=levels[0].device)
+        if not ops.gather_fc0_supported(levels, probe, ext._layout, ext._disp, ext._align, self.fc_0.out_channels):
+            return None
+        return ops.gather_fc0_prepare(levels, ext._layout, ext._disp, ext._align, self._fc0_internal(), B, int(max_points))
+
+    @torch.no_grad()
+    def query(self, levels, points, spatial_sort=False, prepared=None):
         """Logits (B,N) for `points` against a pyramid from encode() (f32, or bf16 storage).  spatial_sort: visit the
         points of every sample in Morton order (pays off for scattered points: the gather's corner reads become cache
-        hits; a dense lattice is ordered already); results do not depend on it."""
+        hits; a dense lattice is ordered already); results do not depend on it.  prepared: prepare_query(levels, ...)."""
         B, N = points.shape[0], points.shape[1]
         points = points.float().contiguous()
         row_map = None
@@ -644,7 +706,9 @@ class IFNet(nn.Module):
         if levels[0].dtype == torch.bfloat16:
             return self._query_bf16(levels, points, row_map)
         ext = self.ifnet_feature_extractor
-        if FUSE_FC0 and ops.gather_fc0_supported(levels, points, ext._layout, ext._disp, ext._align, self.fc_0.out_channels):
+        if prepared is not None:
+            h, _ = ops.gather_fc0_run(prepared, points, self.fc_0.bias)
+        elif FUSE_FC0 and ops.gather_fc0_supported(levels, points, ext._layout, ext._disp, ext._align, self.fc_0.out_channels):
             h, _ = ops.gather_fc0_fwd(levels, points, ext._layout, ext._disp, ext._align, self._fc0_internal(), self.fc_0.bias)
         else:
             rows = ext.feature_rows_from_levels(levels, points)
@@ -662,14 +726,19 @@ class IFNet(nn.Module):
         if not x.is_cuda:
             raise RuntimeError("IF-Net HIP path needs GPU tensors (no CPU fallback)")
         row_map = None
+        ext = self.ifnet_feature_extractor
+        # training step: the large buffers that cross streams come from the extractor's step arena (held until the
+        # encoder's backward has been enqueued; a second forward in between gets ordinary allocations)
+        lease = ext._arena.lease() if (USE_ARENA and torch.is_grad_enabled() and not points.requires_grad
+                                       and not torch.cuda.is_current_stream_capturing()) else None
+        arena = lease.arena if lease is not None else None
         if spatial_sort and N > 1:
             pts = points.detach().float().contiguous()
-            row_map, sorted_pts = ops.morton_order(pts, want_sorted=True)     # samples stay contiguous
+            row_map, sorted_pts = ops.morton_order(pts, want_sorted=True, arena=arena)     # samples stay contiguous
             if points.requires_grad:       # rare (subsample_points > 0): keep the permutation differentiable
                 points = points.reshape(B * N, 3)[row_map.long()].view(B, N, 3)
             else:
                 points = sorted_pts
-        ext = self.ifnet_feature_extractor
         w0p = self._fc0_internal()
         link = None
         if (PROJECT_WIDE_LEVELS and torch.is_grad_enabled() and w0p.requires_grad and not points.requires_grad
@@ -682,13 +751,13 @@ class IFNet(nn.Module):
                 link = _ProjLink(wide, ext._layout)
         if (FUSE_FC0 and not points.requires_grad and B * N * ext._layout.row_stride < 2 ** 31
                 and _fc0_fusable(ext._layout.channels, B, x.shape[2:], self.fc_0.out_channels)):
-            h0 = ext.feature_rows(x, points, link, w0p, self.fc_0.bias)
+            h0 = ext.feature_rows(x, points, link, w0p, self.fc_0.bias, lease=lease)
             logits = _PointMLPFn.apply(h0, row_map, None, None,
                                        self.fc_1.weight.squeeze(2), self.fc_1.bias,
                                        self.fc_2.weight.squeeze(2), self.fc_2.bias,
                                        self.fc_out.weight.reshape(-1), self.fc_out.bias, None)
             return logits.view(B, N)
-        rows = ext.feature_rows(x, points, link, w0p if link is not None else None)
+        rows = ext.feature_rows(x, points, link, w0p if link is not None else None, lease=lease)
         logits = _PointMLPFn.apply(rows, row_map, w0p, self.fc_0.bias,
                                    self.fc_1.weight.squeeze(2), self.fc_1.bias,
                                    self.fc_2.weight.squeeze(2), self.fc_2.bias,
@@ -718,9 +787,11 @@ def evaluate_network_on_grid(network, x, resolution, res_increase=1, points_batc
     values = []
     with torch.no_grad():
         levels = (network.encode(x, storage) if storage != "f32" else network.encode(x)) if hasattr(network, "encode") else None
+        prep = network.prepare_query(levels, points_batch_size) if (levels is not None and hasattr(network, "prepare_query")) else None
         for pi in torch.split(pointsf, points_batch_size):
             pi = pi.unsqueeze(0)
-            z = network.query(levels, pi) if levels is not None else network(x, pi)
+            z = (network.query(levels, pi, prepared=prep) if prep is not None else network.query(levels, pi)) \
+                if levels is not None else network(x, pi)
             values.append(torch.sigmoid(z).squeeze(0))
     value = torch.cat(values, dim=0).cpu().numpy()
     r = [int(s) * res_increase for s in resolution]

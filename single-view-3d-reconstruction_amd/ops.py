@@ -5,6 +5,7 @@ import ctypes as C
 import torch
 
 from . import _lib
+from .arena import alloc as _alloc
 from ._lib import EPI_BIAS, EPI_BIAS_RELU, EPI_MASK, EPI_NONE, GatherDesc, check  # noqa: F401
 
 
@@ -46,6 +47,12 @@ class FeatureLayout:
         self.width = off
         self.row_stride = (off + 31) // 32 * 32
 
+    def subset(self, levels):
+        """Compact layout of a SUBSET of the levels (same relative order, no gaps, row stride padded to 32): the
+        kept-column matrix of the training step -- the levels whose backward is not projected keep their gathered
+        columns in (B*N, 800) instead of a 2592-wide row (128-architecture)."""
+        return KeptLayout(self, levels)
+
     def reference_permutation(self):
         """perm[k_internal] = reference feature row k = c_global*7 + j (model/ifnet.py:43-45,197);
         -1 for padding columns."""
@@ -59,15 +66,46 @@ class FeatureLayout:
         return perm
 
 
-def morton_order(points, want_sorted=False):
+class KeptLayout:
+    """Column layout of the kept-column matrix: `col[l]` for the kept levels (-1 for the others), `row_stride`, and
+    `full_cols` (row_stride,) long: the column of the FULL feature row behind every kept column (a padding column of
+    the full row -- zero weight, zero feature -- behind the kept matrix's own padding)."""
+
+    def __init__(self, full, levels):
+        self.full = full
+        self.levels = tuple(sorted(levels, key=lambda l: full.col[l]))
+        self.channels = list(full.channels)
+        self.col = [-1] * len(full.channels)
+        off, src = 0, []
+        for l in self.levels:
+            self.col[l] = off
+            w = 7 * full.channels[l]
+            src += list(range(full.col[l], full.col[l] + w))
+            off += w
+        self.width = off
+        self.row_stride = (off + 31) // 32 * 32
+        if self.row_stride > off and full.row_stride <= full.width:
+            raise RuntimeError("KeptLayout: the full row has no padding column to stand behind the kept padding")
+        src += [full.width] * (self.row_stride - off)            # a zero column of the full row
+        self.full_cols = torch.tensor(src, dtype=torch.long)
+        self._dev = {}
+
+    def full_cols_on(self, device):
+        t = self._dev.get(device)
+        if t is None:
+            t = self._dev[device] = self.full_cols.to(device)
+        return t
+
+
+def morton_order(points, want_sorted=False, arena=None):
     """(B*N,) int32 processing order: points of one sample sorted by a 64^3 Morton code
     (and, optionally, the points gathered into that order)."""
     _f32(points)
     B, N, _ = points.shape
     l = _lib.lib()
-    order = torch.empty(B * N, device=points.device, dtype=torch.int32)
-    spts = torch.empty_like(points) if want_sorted else None
-    ws = torch.empty(l.svr_points_morton_order_workspace(B, N), device=points.device, dtype=torch.uint8)
+    order = _alloc(arena, "morton_order", (B * N,), torch.int32, points.device)
+    spts = _alloc(arena, "morton_points", tuple(points.shape), torch.float32, points.device) if want_sorted else None
+    ws = _alloc(arena, "morton_ws", (l.svr_points_morton_order_workspace(B, N),), torch.uint8, points.device)
     check(l.svr_points_morton_order(_p(points), _p(order), _p(spts), B, N, _p(ws), _stream()), "morton_order")
     return (order, spts) if want_sorted else order
 
@@ -93,9 +131,13 @@ class PullPlan:
         self.c = _lib.PullPlan(_p(keys), _p(recs), _p(heads), n_items)
 
     def record_stream(self, stream):
+        if self.persistent:      # arena-owned buffers never return to the allocator
+            return
         for t in (self.keys, self.recs, self.heads, self.items, self.stats):
             if t is not None:
                 t.record_stream(stream)
+
+    persistent = False
 
 
 def pull_plan_supported(B, N, dims, C, row_stride):
@@ -103,35 +145,39 @@ def pull_plan_supported(B, N, dims, C, row_stride):
     return C in (16, 32, 64) and N > 0 and cells < 2 ** 31 - 1 and 7 * B * N < 2 ** 31 and B * N * row_stride < 2 ** 31
 
 
-def pull_plan(points, dims, C, col, row_stride, displacement, align_corners=False):
-    """Sort the 7*B*N (point, displacement) items of one level by base cell and build the records / cell heads."""
+def pull_plan(points, dims, C, col, row_stride, displacement, align_corners=False, arena=None, tag=""):
+    """Sort the 7*B*N (point, displacement) items of one level by base cell and build the records / cell heads.
+    arena / tag: take the plan's arrays from a StepArena (names prefixed with `tag`) instead of the allocator."""
     _f32(points)
     B, N, _ = points.shape
     l = _lib.lib()
     T = 7 * B * N
     cells = B * (dims[0] + 1) * (dims[1] + 1) * (dims[2] + 1)
     dev = points.device
-    keys = torch.empty(max(T, 1), device=dev, dtype=torch.int32)
-    recs = torch.empty(max(T, 1), 4, device=dev, dtype=torch.int32)
-    heads = torch.empty(cells + 1, device=dev, dtype=torch.int32)
-    items = torch.empty(max(T, 1), device=dev, dtype=torch.int32)       # sorted item ids: also this level's item order
-    stats = torch.zeros(2, device=dev, dtype=torch.int32)
-    ws = torch.empty(l.svr_gather_pull_plan_workspace(B, N) + l.svr_gather_pull_plan_workspace_cells(B, *dims), device=dev,
-                     dtype=torch.uint8)
+    keys = _alloc(arena, tag + "keys", (max(T, 1),), torch.int32, dev)
+    recs = _alloc(arena, tag + "recs", (max(T, 1), 4), torch.int32, dev)
+    heads = _alloc(arena, tag + "heads", (cells + 1,), torch.int32, dev)
+    items = _alloc(arena, tag + "items", (max(T, 1),), torch.int32, dev)   # sorted item ids: also this level's item order
+    stats = _alloc(arena, tag + "stats", (2,), torch.int32, dev).zero_()
+    # (the sort workspace is shared by all plans of a step: they are built one after the other on one stream)
+    ws = _alloc(arena, "plan_ws", (l.svr_gather_pull_plan_workspace(B, N) + l.svr_gather_pull_plan_workspace_cells(B, *dims),),
+                torch.uint8, dev)
     check(l.svr_gather_pull_plan(_p(points), B, N, dims[0], dims[1], dims[2], C, col, row_stride, int(align_corners),
                                  displacement, _p(keys), _p(recs), _p(heads), _p(items), _p(stats), _p(ws), _stream()),
           "gather_pull_plan")
-    return PullPlan(keys, recs, heads, T, items, stats)
+    plan = PullPlan(keys, recs, heads, T, items, stats)
+    plan.persistent = arena is not None
+    return plan
 
 
-def item_order(points, dims, displacement, align_corners=False, with_j=False):
+def item_order(points, dims, displacement, align_corners=False, with_j=False, arena=None, tag=""):
     """(7*B*N,) int32 item ids pn*7+j sorted by (sample, base cell of the displaced sample[, displacement j]) in a
     volume of `dims`."""
     _f32(points)
     B, N, _ = points.shape
     l = _lib.lib()
-    items = torch.empty(max(7 * B * N, 1), device=points.device, dtype=torch.int32)
-    ws = torch.empty(l.svr_gather_pull_plan_workspace(B, N), device=points.device, dtype=torch.uint8)
+    items = _alloc(arena, tag + "items", (max(7 * B * N, 1),), torch.int32, points.device)
+    ws = _alloc(arena, "plan_ws", (l.svr_gather_pull_plan_workspace(B, N),), torch.uint8, points.device)
     check(l.svr_gather_item_order(_p(points), B, N, dims[0], dims[1], dims[2], int(align_corners), displacement, int(with_j),
                                   _p(items), _p(ws), _stream()), "gather_item_order")
     return items
@@ -202,7 +248,9 @@ def gather_project_bwd(points, dh, dims, items, displacement, align_corners=Fals
 
 
 def make_gather_desc(vols, gvols, layout, B, N, displacement, align_corners, order=None, level_orders=None, flags=0,
-                     level_plans=None):
+                     level_plans=None, skip_levels=()):
+    """layout: a FeatureLayout, or a KeptLayout (compact kept-column matrix; the levels it does not hold must be in
+    skip_levels).  skip_levels: these levels get NULL volume pointers (a backward skips them)."""
     d = GatherDesc()
     d.flags = int(flags)
     d.order = _p(order)
@@ -218,8 +266,13 @@ def make_gather_desc(vols, gvols, layout, B, N, displacement, align_corners, ord
         if ref.dim() != 5 or ref.shape[0] != B or ref.shape[4] != layout.channels[l]:
             raise RuntimeError(f"level {l}: expected (B,D,H,W,{layout.channels[l]}) channels-last, got {tuple(ref.shape)}")
         L = d.level[l]
-        L.vol, L.gvol = _p(v), _p(g)
         L.C, L.D, L.H, L.W = ref.shape[4], ref.shape[1], ref.shape[2], ref.shape[3]
+        if l in skip_levels:
+            L.vol, L.gvol, L.col = C.c_void_p(0), C.c_void_p(0), 0
+            continue
+        if layout.col[l] < 0:
+            raise RuntimeError(f"level {l} has no columns in this layout (list it in skip_levels)")
+        L.vol, L.gvol = _p(v), _p(g)
         L.col = layout.col[l]
         o = level_orders[l] if level_orders is not None else None
         # a (7*B*N) order is an ITEM order (svr_gather_item_order), a (B*N) one a point order (svr_points_voxel_order)
@@ -256,38 +309,91 @@ def gather_fc0_supported(vols, points, layout, displacement, align_corners, n_ou
     return bool(_lib.lib().svr_gather_fc0_supported(C.byref(d)))
 
 
-def gather_fc0_fwd(vols, points, layout, displacement, align_corners, w, bias, relu=True, keep_levels=()):
-    """h0 (B*N, 256) = [relu](feature_rows(vols, points) @ w.T + bias) without materialising the feature rows (gather_fc0.hip).
-    keep_levels: levels whose gathered columns are also stored -> (h0, rows) with rows (B*N, row_stride) valid ONLY in
-    those levels' columns and the padding columns (the rest is uninitialised memory); () -> (h0, None)."""
-    B, N, _ = points.shape
-    _f32(points, w, bias)
+class Fc0Prepared:
+    """fc_0's weights split into the fused kernel's f16 planes + the slab table of one pyramid (svr_gather_fc0_prepare):
+    reusable for any number of gather_fc0_run calls on the same volumes / layout / weights."""
+
+    def __init__(self, vols, layout, displacement, align_corners, n_out, ws, keep_levels, keep_layout):
+        self.vols, self.layout, self.displacement, self.align_corners = list(vols), layout, displacement, align_corners
+        self.n_out, self.ws, self.keep_levels, self.keep_layout = n_out, ws, tuple(keep_levels), keep_layout
+        self.mask = 0
+        for lv in self.keep_levels:
+            self.mask |= 1 << lv
+        self.kc = None
+        self.stride = layout.row_stride
+        if self.mask and keep_layout is not None:
+            if set(keep_layout.levels) != set(self.keep_levels):
+                raise RuntimeError("gather_fc0: keep_layout does not hold exactly keep_levels")
+            self.stride = keep_layout.row_stride
+            self.kc = (C.c_int32 * len(self.vols))(*[int(c) for c in keep_layout.col])
+
+
+def gather_fc0_prepare(vols, layout, displacement, align_corners, w, B, N, keep_levels=(), keep_layout=None, arena=None):
+    """Split w (n_out, >= layout.width) for the fused gather -> fc_0 kernel and store the slab table (three small
+    launches); -> Fc0Prepared for gather_fc0_run.  B, N: the largest point set that will be queried."""
+    _f32(w)
     d = make_gather_desc(vols, None, layout, B, N, displacement, align_corners)
     l = _lib.lib()
     n_out = w.shape[0]
     assert w.stride(1) == 1 and w.shape[1] >= layout.width
     ws_bytes = l.svr_gather_fc0_workspace(C.byref(d), n_out)
     if ws_bytes <= 0:
-        raise RuntimeError("gather_fc0_fwd: unsupported level shapes (see svr_gather_fc0_supported)")
-    ws = torch.empty(ws_bytes, device=points.device, dtype=torch.uint8)
-    out = torch.empty(B * N, n_out, device=points.device, dtype=torch.float32)
-    mask = 0
-    for lv in keep_levels:
-        mask |= 1 << lv
-    rows = torch.empty(B * N, layout.row_stride, device=points.device, dtype=torch.float32) if mask else None
+        raise RuntimeError("gather_fc0: unsupported level shapes (see svr_gather_fc0_supported)")
+    ws = _alloc(arena, "fc0_ws", (ws_bytes,), torch.uint8, w.device)
+    prep = Fc0Prepared(vols, layout, displacement, align_corners, n_out, ws, keep_levels, keep_layout)
+    # (the kept matrix itself is only needed by run; prepare validates its geometry against a dummy aligned address)
+    check(l.svr_gather_fc0_prepare(C.byref(d), C.c_void_p(w.data_ptr()), w.stride(0), n_out, C.c_void_p(256) if prep.mask else None,
+                                   prep.stride if prep.mask else 0, prep.kc, prep.mask, _p(ws), _stream()), "gather_fc0_prepare")
+    return prep
+
+
+def gather_fc0_run(prep, points, bias, relu=True, rows_out=None):
+    """The fused gather -> fc_0 kernel alone, on a prepared pyramid: -> (h0 (B*N, n_out), kept rows or None)."""
+    B, N, _ = points.shape
+    _f32(points, bias)
+    d = make_gather_desc(prep.vols, None, prep.layout, B, N, prep.displacement, prep.align_corners)
+    out = torch.empty(B * N, prep.n_out, device=points.device, dtype=torch.float32)
+    rows, ldf = None, 0
+    if prep.mask:
+        if rows_out is not None:
+            if tuple(rows_out.shape) != (B * N, prep.stride) or not rows_out.is_contiguous():
+                raise RuntimeError(f"gather_fc0: rows_out must be contiguous ({B * N}, {prep.stride})")
+            _f32(rows_out)
+            rows = rows_out
+        else:
+            rows = torch.empty(B * N, prep.stride, device=points.device, dtype=torch.float32)
+        ldf = prep.stride
     epi = EPI_NONE if bias is None else (EPI_BIAS_RELU if relu else EPI_BIAS)
-    check(l.svr_gather_fc0_fwd(C.byref(d), _p(points), C.c_void_p(w.data_ptr()), w.stride(0), _p(bias), _p(out), out.stride(0),
-                               n_out, _p(rows), mask, epi, _p(ws), _stream()), "gather_fc0_fwd")
+    check(_lib.lib().svr_gather_fc0_run(C.byref(d), _p(points), _p(bias), _p(out), out.stride(0), prep.n_out, _p(rows), ldf,
+                                        prep.kc, prep.mask, epi, _p(prep.ws), _stream()), "gather_fc0_run")
     return out, rows
 
 
-def gather_bwd(vols, gvols, points, gfeat, layout, displacement, align_corners, want_gpoints=False, order=None,
-               level_orders=None, flags=0, level_plans=None):
-    """level_plans[l] (PullPlan or None): that level is scattered atomic-free in pull form and its gvol OVERWRITTEN
-    (it may be uninitialised); the other levels accumulate into their (zeroed) gvol with float atomics."""
+def gather_fc0_fwd(vols, points, layout, displacement, align_corners, w, bias, relu=True, keep_levels=(), keep_layout=None,
+                   rows_out=None, arena=None):
+    """h0 (B*N, 256) = [relu](feature_rows(vols, points) @ w.T + bias) without materialising the feature rows (gather_fc0.hip).
+    keep_levels: levels whose gathered columns are also stored -> (h0, rows); () -> (h0, None).
+      keep_layout None: rows (B*N, layout.row_stride) in the full row layout, valid ONLY in those levels' columns and the
+        padding columns (the rest is uninitialised memory);
+      keep_layout = layout.subset(keep_levels): rows (B*N, keep_layout.row_stride), the compact kept-column matrix (every
+        column valid, padding zero).
+    rows_out: write the kept rows there instead of allocating; arena: a StepArena for the per-call workspace.
+    = gather_fc0_prepare + gather_fc0_run."""
     B, N, _ = points.shape
+    prep = gather_fc0_prepare(vols, layout, displacement, align_corners, w, B, N, keep_levels, keep_layout, arena)
+    return gather_fc0_run(prep, points, bias, relu, rows_out)
+
+
+def gather_bwd(vols, gvols, points, gfeat, layout, displacement, align_corners, want_gpoints=False, order=None,
+               level_orders=None, flags=0, level_plans=None, skip_levels=()):
+    """level_plans[l] (PullPlan or None): that level is scattered atomic-free in pull form and its gvol OVERWRITTEN
+    (it may be uninitialised); the other levels accumulate into their (zeroed) gvol with float atomics.
+    layout may be a KeptLayout (gfeat = gradient of the compact kept-column matrix; skip_levels = the levels it lacks)."""
+    B, N, _ = points.shape
+    if gfeat.numel() != B * N * layout.row_stride:
+        raise RuntimeError(f"gather_bwd: gfeat {tuple(gfeat.shape)} does not match the layout's ({B * N}, {layout.row_stride})")
     d = make_gather_desc(vols, gvols, layout, B, N, displacement, align_corners, order, level_orders,
-                         flags=flags | GATHER_FLAGS, level_plans=level_plans)
+                         flags=flags | GATHER_FLAGS, level_plans=level_plans, skip_levels=skip_levels)
     gp = torch.empty_like(points) if want_gpoints else None
     check(_lib.lib().svr_gather_trilinear_bwd(C.byref(d), _p(points), _p(gfeat), _p(gp), _stream()), "gather_bwd")
     return gp

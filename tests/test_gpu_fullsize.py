@@ -250,4 +250,13 @@ def test_config3_fused_gather_fc0_equals_the_two_kernels(clustered):
                 assert torch.equal(kept[:, a:b], rows[:, a:b]), f"level {l}"
             assert torch.all(kept[:, ext._layout.width:] == 0)
             assert float((h0 - want).abs().max()) <= 2e-6 * scale
-            del h0, kept
+            del kept
+            # the training step's form: compact kept-column matrix (B*N, 800)
+            klay = ext._layout.subset(keep)
+            assert klay.row_stride == 800
+            h0c, keptc = ops.gather_fc0_fwd(levels, pts, ext._layout, ext._disp, ext._align, w0p, b0, relu=True, keep_levels=keep,
+                                            keep_layout=klay)
+            assert torch.equal(h0c, h0)
+            assert torch.equal(keptc[:, :klay.width], rows[:, klay.full_cols[:klay.width].cuda()])
+            assert torch.all(keptc[:, klay.width:] == 0)
+            del h0, h0c, keptc

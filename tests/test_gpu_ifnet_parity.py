@@ -257,7 +257,9 @@ def test_no_grad_forward_does_not_prepare_the_backward():
 
 def test_adaptive_scatter_form_follows_the_point_distribution():
     """SCATTER_FORM "auto": the pull form for spread-out points, the item-order atomics for clustered ones, decided from
-    the previous step's `longest walk` statistic (no synchronisation: the first step of a shape uses the item order)."""
+    the `longest walk` statistic of the step PULL_DECISION_LAG steps back -- a fixed lag, so the sequence of forms is a
+    function of the data and never of host timing: the same with the host far ahead of the GPU (no synchronisation
+    between the steps) and with a device synchronisation after every step."""
     import svr_amd  # noqa: F401
     from svr_amd import ops
     from svr_amd.model import ifnet as ifn
@@ -266,21 +268,38 @@ def test_adaptive_scatter_form_follows_the_point_distribution():
     disp = float(np.float32(0.0722))
     g = torch.Generator().manual_seed(3)
     B, N, D = 2, 1500, 32
+    lag = ifn.PULL_DECISION_LAG
     uniform = (torch.rand(B, N, 3, generator=g) - 0.5).cuda()
     clustered = (torch.randn(B, N, 3, generator=g) * 0.002).clamp(-0.5, 0.5).cuda()     # everything inside a few voxels
-    ifn._pull_hint.clear()
     for pts, expect_pull in ((uniform, True), (clustered, False)):
-        forms = []
-        for step in range(3):
-            orders, plans, ready = ifn._level_orders_async(pts, D, D, D, 6, False, layout, disp)
+        seqs = []
+        for sync in (True, False):
+            ifn._pull_hint.clear()
+            forms = []
+            for step in range(lag + 2):
+                orders, plans, ready = ifn._level_orders_async(pts, D, D, D, 6, False, layout, disp)
+                if sync:
+                    torch.cuda.synchronize()
+                forms.append([p is not None for p in plans[1:4]])
+                assert all(o is not None and o.numel() == 7 * B * N for o in orders[4:])
+                assert all((plans[l] is None) != (orders[l] is None) for l in (1, 2, 3))
             torch.cuda.synchronize()
-            forms.append([p is not None for p in plans[1:4]])
-            assert all(o is not None and o.numel() == 7 * B * N for o in orders[4:])
-            assert all((plans[l] is None) != (orders[l] is None) for l in (1, 2, 3))
-        if expect_pull:
-            assert forms[0] == [False, False, False] and forms[-1][0] and forms[-1][1], forms   # level 1/2: short walks
-        else:
-            assert forms[-1] == [False, False, False], forms
+            seqs.append(forms)
+            assert all(f == [False, False, False] for f in forms[:lag]), forms       # no statistic yet: item order
+            if expect_pull:
+                assert forms[lag][0] and forms[lag][1] and forms[-1] == forms[lag], forms   # level 1/2: short walks
+            else:
+                assert forms[-1] == [False, False, False], forms
+        assert seqs[0] == seqs[1], seqs
+    # a change of distribution arrives exactly `lag` steps later
+    ifn._pull_hint.clear()
+    got = []
+    for step in range(2 * lag + 2):
+        pts = uniform if step <= lag else clustered
+        _, plans, _ = ifn._level_orders_async(pts, D, D, D, 6, False, layout, disp)
+        got.append(plans[1] is not None)
+    torch.cuda.synchronize()
+    assert got == [False] * lag + [True] * (lag + 1) + [False], got
     ifn._pull_hint.clear()
 
 

@@ -543,6 +543,21 @@ def test_fused_gather_fc0_equals_gather_then_linear(B, dims, N, spread, chans, a
         a, b = layout.col[l], layout.col[l] + 7 * chans[l]
         assert torch.equal(kept[:, a:b], rows[:, a:b]), f"level {l}"
     assert torch.all(kept[:, layout.width:] == 0)
+    # compact kept-column matrix (what the training step keeps): the same bits at the KeptLayout's columns, zero padding,
+    # written into a caller-provided buffer that starts as NaN (every column must be written), same h0
+    klay = layout.subset(keep)
+    assert klay.width == 7 * sum(chans[l] for l in keep) and klay.row_stride % 32 == 0 and klay.row_stride - klay.width < 32
+    assert all((klay.col[l] >= 0) == (l in keep) for l in range(len(chans)))
+    buf = torch.full((B * N, klay.row_stride), float("nan"), device="cuda")
+    h0c, keptc = ops.gather_fc0_fwd(vols_g, pts, layout, disp, ac, w, bias, relu=True, keep_levels=keep, keep_layout=klay,
+                                    rows_out=buf)
+    assert keptc.data_ptr() == buf.data_ptr() and torch.equal(h0c, h0)
+    for l in keep:
+        a, b = layout.col[l], layout.col[l] + 7 * chans[l]
+        assert torch.equal(keptc[:, klay.col[l]: klay.col[l] + 7 * chans[l]], rows[:, a:b]), f"compact level {l}"
+    assert torch.all(keptc[:, klay.width:] == 0)
+    fc = klay.full_cols
+    assert torch.equal(keptc[:, :klay.width], rows[:, fc[:klay.width].cuda()]) and bool((fc[klay.width:] == layout.width).all())
     scale = float(want.abs().max())
     assert float((h0 - want).abs().max()) <= 1e-6 * scale
     ref = torch.relu(rows.double().cpu() @ w.double().cpu().t() + bias.double().cpu())
