@@ -32,7 +32,10 @@ SOURCES = {
     "sample_io.hip": [],
     "conv2d.hip": [],
 }
-COMMON = ["-O3", "-fPIC", "--offload-arch=gfx950", "-munsafe-fp-atomics", "-std=c++17", "-I" + INCLUDE, "-I" + CSRC]
+COMMON = ["-O3", "-fPIC", "--offload-arch=gfx950", "-munsafe-fp-atomics", "-std=c++17", "-I" + INCLUDE, "-I" + CSRC,
+          # per-kernel register / scratch report into build/<file>.log (resource_usage() parses it: a kernel that starts to
+          # spill is caught on the CPU, tests/test_capi_cpu.py -- round 3 lost 4.5x on the fused gather to 260 B/lane of scratch)
+          "-Rpass-analysis=kernel-resource-usage"]
 
 
 def _hipcc():
@@ -66,17 +69,44 @@ def build(force=False, verbose=False):
             cmd = [_hipcc()] + COMMON + extra + (["-x", "hip"] if src.endswith(".cpp") else []) + ["-c", path, "-o", obj]
             if verbose:
                 print(" ".join(cmd), file=sys.stderr)
-            procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
-    for src, p in procs:
+            procs.append((src, obj, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    for src, obj, p in procs:
         out, _ = p.communicate()
         if p.returncode != 0:
             raise RuntimeError(f"hipcc failed on {src}:\n{out.decode(errors='replace')}")
+        with open(obj[:-2] + ".log", "wb") as f:
+            f.write(out)
     if force or procs or _stale(LIB, objs):
         cmd = [_hipcc(), "-shared", "-fPIC", "--offload-arch=gfx950", "-o", LIB] + objs + ["-lz"]
         r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
         if r.returncode != 0:
             raise RuntimeError("link failed:\n" + r.stdout.decode(errors="replace"))
     return LIB
+
+
+def resource_usage():
+    """{kernel name (mangled): {"vgprs", "agprs", "scratch", "occupancy", "file"}} from the compile logs of the last build."""
+    import re
+    objdir = os.path.join(HERE, "build")
+    out = {}
+    for src in SOURCES:
+        log = os.path.join(objdir, src.rsplit(".", 1)[0] + ".log")
+        if not os.path.exists(log):
+            continue
+        cur = None
+        for line in open(log, errors="replace"):
+            m = re.search(r"remark: Function Name: (\S+)", line)
+            if m:
+                cur = out.setdefault(m.group(1), {"file": src})
+                continue
+            if cur is None:
+                continue
+            for key, pat in (("vgprs", r"remark:\s+VGPRs: (\d+)"), ("agprs", r"remark:\s+AGPRs: (\d+)"),
+                             ("scratch", r"ScratchSize \[bytes/lane\]: (\d+)"), ("occupancy", r"Occupancy \[waves/SIMD\]: (\d+)")):
+                m = re.search(pat, line)
+                if m:
+                    cur[key] = int(m.group(1))
+    return out
 
 
 if __name__ == "__main__":

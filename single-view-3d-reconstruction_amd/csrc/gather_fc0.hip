@@ -319,9 +319,9 @@ __global__ __launch_bounds__(512, FTM == 64 ? 4 : 2) void gather_fc0_kernel(cons
     const int pw = wave - 4;
     if (pad_start >= 0 && t - 256 < FTM && m0 + (t - 256) < M)  // kept rows: the padding columns behind the last level are zeros
       for (int cc = pad_start; cc < row_stride; ++cc) feat[(m0 + (t - 256)) * row_stride + cc] = 0.f;
-    if (!(dbg & 1)) produce(A, 0, lds, points, m0, M, N, disp, ac, feat, row_stride, pw, lane, dbg);
-    slab_barrier();
-    for (int s = 0; s < S; ++s) {
+    // slab s + 1 is produced into the buffer the consumers are not reading, then the barrier hands both over (ONE call site:
+    // with a second, peeled call for slab 0 the compiler inlined all five slab shapes twice and spilled 268 B / lane)
+    for (int s = -1; s < S; ++s) {
       if (s + 1 < S && !(dbg & 1)) produce(A, s + 1, lds + ((s + 1) & 1) * FSLAB, points, m0, M, N, disp, ac, feat, row_stride, pw, lane, dbg);
       slab_barrier();
     }
@@ -356,9 +356,15 @@ __global__ __launch_bounds__(512, FTM == 64 ? 4 : 2) void gather_fc0_kernel(cons
   }
   slab_barrier();  // slab 0 is in LDS
   int s = 0, kin = 0, ksl = A.S[0].nk, kidx = 0;
+  // `mma_on`: an always-true scalar the compiler cannot see through.  With the k-step body unconditional the register
+  // allocator spills 260 B / lane of the accumulators (one basic block for the whole unrolled loop: the launch takes 11.7
+  // instead of 2.6 ms); behind a uniform branch -- which is how the kernel was developed, the branch used to be a
+  // measurement switch -- it keeps 128 VGPRs without scratch.  One s_cbranch per k-step.
+  int mma_on = !(dbg & 2);
+  asm volatile("" : "+s"(mma_on));
   // k-step kidx on the fragments `cur`; `fre` (used one step ago) is refilled with step kidx + 3
   auto step = [&](const uint4 (&cur)[2][2], uint4 (&fre)[2][2]) {
-    if (!(dbg & 2)) {
+    if (mma_on) {
       loadb(fre, kidx + BDIST);
       const uint32_t *pa = lds + (s & 1) * FSLAB + kin * FKSTEP;
       f16x8 b[3][2];
