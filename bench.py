@@ -316,7 +316,9 @@ def main():
             "all_reduce_ms": _stats(kt.times("all_reduce_mean")),
             "gather_fc0_ms": _stats(kt.times("gather_fc0_run") or kt.times("gather_fwd")),
             "hipMalloc_calls_in_timed_region": mem1.get("num_device_alloc", 0) - mem0.get("num_device_alloc", 0),
-            "hipFree_calls_in_timed_region": mem1.get("num_device_free", 0) - mem0.get("num_device_free", 0)}
+            "hipFree_calls_in_timed_region": mem1.get("num_device_free", 0) - mem0.get("num_device_free", 0),
+            "reserved_bytes_grown_in_timed_region": mem1.get("reserved_bytes.all.current", 0) - mem0.get("reserved_bytes.all.current", 0),
+            "reserved_bytes": mem1.get("reserved_bytes.all.current", 0)}
     ranks = [mine]
     if launched and world > 1:
         ranks = [None] * world
@@ -492,6 +494,8 @@ def report(a, world, dt, loss, step_ms, host_ms, kt, kd, ranks, forms, fwd_ms, q
         "host_enqueue_ms": _stats(host_ms),
         "allocator": {"hipMalloc_calls_in_timed_region": ranks[0]["hipMalloc_calls_in_timed_region"],
                       "hipFree_calls_in_timed_region": ranks[0]["hipFree_calls_in_timed_region"],
+                      "reserved_bytes_grown_in_timed_region": ranks[0]["reserved_bytes_grown_in_timed_region"],
+                      "reserved_bytes": ranks[0]["reserved_bytes"],
                       "arena_bytes": arena.nbytes(), "arena_buffers_grown_in_timed_region": arena.grown - grown0,
                       "note": "the step's large cross-stream buffers (kept columns 1.28 GB, their gradient, gradient volumes, "
                               "scatter plans) live in a per-module arena allocated in the set-up steps"},

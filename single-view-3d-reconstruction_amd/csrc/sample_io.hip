@@ -17,6 +17,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
 #include <string>
 #include <vector>
 
@@ -59,6 +60,8 @@ int zip_find(FILE *f, const std::string &name, ZipEntry &e) {
     cd_size = rd64(r + 40);
     cd_off = rd64(r + 48);
   }
+  // a truncated or garbage file must not size an allocation or a seek: the directory lies inside the file
+  if (cd_off > (uint64_t)size || cd_size > (uint64_t)size - cd_off) return -1;
   std::vector<unsigned char> cd((size_t)cd_size);
   if (fseek(f, (long)cd_off, SEEK_SET) || fread(cd.data(), 1, cd.size(), f) != cd.size()) return -1;
   size_t p = 0;
@@ -67,6 +70,7 @@ int zip_find(FILE *f, const std::string &name, ZipEntry &e) {
     const int method = rd16(&cd[p + 10]);
     uint64_t comp = rd32(&cd[p + 20]), uncomp = rd32(&cd[p + 24]), local = rd32(&cd[p + 42]);
     const size_t nl = rd16(&cd[p + 28]), xl = rd16(&cd[p + 30]), cl = rd16(&cd[p + 32]);
+    if (p + 46 + nl + xl + cl > cd.size()) return -1;  // entry runs past the directory
     const std::string fn((const char *)&cd[p + 46], nl);
     size_t x = p + 46 + nl;
     const size_t xend = x + xl;
@@ -74,9 +78,10 @@ int zip_find(FILE *f, const std::string &name, ZipEntry &e) {
       const int id = rd16(&cd[x]), sz = rd16(&cd[x + 2]);
       if (id == 1) {
         size_t q = x + 4;
-        if (uncomp == 0xFFFFFFFFu) { uncomp = rd64(&cd[q]); q += 8; }
-        if (comp == 0xFFFFFFFFu) { comp = rd64(&cd[q]); q += 8; }
-        if (local == 0xFFFFFFFFu) { local = rd64(&cd[q]); q += 8; }
+        const size_t fend = x + 4 + (size_t)sz < xend ? x + 4 + (size_t)sz : xend;
+        if (uncomp == 0xFFFFFFFFu) { if (q + 8 > fend) return -1; uncomp = rd64(&cd[q]); q += 8; }
+        if (comp == 0xFFFFFFFFu) { if (q + 8 > fend) return -1; comp = rd64(&cd[q]); q += 8; }
+        if (local == 0xFFFFFFFFu) { if (q + 8 > fend) return -1; local = rd64(&cd[q]); q += 8; }
       }
       x += 4 + (size_t)sz;
     }
@@ -171,7 +176,7 @@ int npy_parse(FILE *f, const ZipEntry &e, NpyInfo &info) {
   if (memcmp(h, "\x93NUMPY", 6) != 0) return -1;
   uint64_t hlen, pre;
   if (h[6] == 1) { hlen = rd16(h + 8); pre = 10; } else { if (first < 12) return -1; hlen = rd32(h + 8); pre = 12; }
-  if (pre + hlen > e.uncomp) return -1;
+  if (pre + hlen > e.uncomp || hlen > (1u << 20)) return -1;  // (numpy headers are a few hundred bytes)
   std::string d((size_t)hlen, '\0');
   if (zip_read(f, e, pre, &d[0], hlen)) return -1;
   info.header_bytes = pre + hlen;
@@ -188,7 +193,9 @@ int npy_parse(FILE *f, const ZipEntry &e, NpyInfo &info) {
   info.dtype = dtype_code(d.substr(q0 + 1, q1 - q0 - 1));
   p = value_after("'fortran_order'");
   if (p == std::string::npos) return -1;
-  info.fortran = d.compare(d.find_first_not_of(' ', p), 4, "True") == 0;
+  const size_t fo = d.find_first_not_of(' ', p);
+  if (fo == std::string::npos) return -1;
+  info.fortran = d.compare(fo, 4, "True") == 0;
   p = value_after("'shape'");
   if (p == std::string::npos) return -1;
   size_t a = d.find('(', p), b = d.find(')', a);
@@ -282,8 +289,11 @@ extern "C" int svr_df_read(const char *path, float *payload, int64_t n) {
   return SVR_OK;
 }
 
-extern "C" int svr_npz_member_info(const char *path, const char *member, int32_t *dtype, int32_t *ndim, int64_t *shape,
-                                   int32_t *fortran_order) {
+// The host readers never throw across the ABI: std::bad_alloc / std::length_error / std::out_of_range from a malformed file
+// come back as SVR_E_IO (a half-written occupancy_*.npz must not abort the training process).
+namespace {
+
+int npz_member_info_impl(const char *path, const char *member, int32_t *dtype, int32_t *ndim, int64_t *shape, int32_t *fortran_order) {
   File fh(path);
   ZipEntry e;
   NpyInfo info;
@@ -296,19 +306,46 @@ extern "C" int svr_npz_member_info(const char *path, const char *member, int32_t
   return SVR_OK;
 }
 
-extern "C" int svr_npz_member_read(const char *path, const char *member, void *out, int64_t nbytes) {
+int npz_member_read_impl(const char *path, const char *member, void *out, int64_t nbytes) {
   File fh(path);
   ZipEntry e;
   NpyInfo info;
   if (int rc = open_member(path, member, fh, e, info, "npz_member_read")) return rc;
   int64_t count = 1;
-  for (int i = 0; i < info.ndim; ++i) count *= info.shape[i];
+  for (int i = 0; i < info.ndim; ++i) {
+    SVR_CHECK(info.shape[i] >= 0 && (info.shape[i] == 0 || count <= (int64_t)(1LL << 56) / info.shape[i]), SVR_E_IO,
+              "npz_member_read: %s[%s]: implausible shape", path, member);
+    count *= info.shape[i];
+  }
   SVR_CHECK(out && nbytes == count * dtype_size(info.dtype), SVR_E_BADSHAPE, "npz_member_read: %s[%s] holds %ld bytes, caller sized for %ld",
             path, member, (long)(count * dtype_size(info.dtype)), (long)nbytes);
   int rc = zip_read(fh.f, e, info.header_bytes, out, (uint64_t)nbytes);
   SVR_CHECK(rc == 0, rc == -2 ? SVR_E_UNSUPPORTED : SVR_E_IO, "npz_member_read: %s[%s]: %s", path, member,
             rc == -2 ? "unsupported zip compression method" : "read / inflate failed");
   return SVR_OK;
+}
+
+template <typename F>
+int io_guard(const char *what, F &&body) {
+  try {
+    return body();
+  } catch (const std::exception &ex) {
+    SVR_CHECK(false, SVR_E_IO, "%s: malformed file (%s)", what, ex.what());
+  } catch (...) {
+    SVR_CHECK(false, SVR_E_IO, "%s: malformed file", what);
+  }
+  return SVR_E_IO;
+}
+
+}  // namespace
+
+extern "C" int svr_npz_member_info(const char *path, const char *member, int32_t *dtype, int32_t *ndim, int64_t *shape,
+                                   int32_t *fortran_order) {
+  return io_guard("npz_member_info", [&] { return npz_member_info_impl(path, member, dtype, ndim, shape, fortran_order); });
+}
+
+extern "C" int svr_npz_member_read(const char *path, const char *member, void *out, int64_t nbytes) {
+  return io_guard("npz_member_read", [&] { return npz_member_read_impl(path, member, out, nbytes); });
 }
 
 extern "C" int svr_df_to_grid(const float *payload, float *out, int32_t X, int32_t Y, int32_t Z, void *stream) {

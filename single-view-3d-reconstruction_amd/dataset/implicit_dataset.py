@@ -84,10 +84,18 @@ class DeviceSampleLoader:
     def _pinned(self, shape, dtype):
         return torch.empty(shape, dtype=dtype, pin_memory=True)
 
+    @staticmethod
+    def _c_order(fortran, path, key):
+        # the device path reinterprets the flat payload as C order (process_sample.py writes C-order arrays); a
+        # Fortran-order member would be silently transposed: refuse it (ImplicitDataset / npz_load honour the flag)
+        if fortran:
+            raise ValueError(f"{path}[{key}]: fortran_order arrays are not supported by DeviceSampleLoader")
+
     def _decode(self, folder):
         s = {}
         with torch.cuda.stream(self.copy_stream):
-            dtype, shape, _ = sample_io.npz_member_info(folder / "depth_grid.npz", "grid")
+            dtype, shape, fortran = sample_io.npz_member_info(folder / "depth_grid.npz", "grid")
+            self._c_order(fortran, folder / "depth_grid.npz", "grid")
             stage = self._pinned(int(np.prod(shape)), torch.from_numpy(np.empty(0, dtype)).dtype)
             sample_io.npz_load(folder / "depth_grid.npz", "grid", out=stage.numpy())
             s["input"] = sample_io.cast_to_f32(stage.to(self.device, non_blocking=True).view(shape))
@@ -99,7 +107,8 @@ class DeviceSampleLoader:
             for sigma in SIGMAS:
                 f = folder / f"occupancy_{sigma}.npz"
                 for key in ("points", "grid_coords", "occupancies"):
-                    dtype, shape, _ = sample_io.npz_member_info(f, key)
+                    dtype, shape, fortran = sample_io.npz_member_info(f, key)
+                    self._c_order(fortran, f, key)
                     st = self._pinned(int(np.prod(shape)), torch.from_numpy(np.empty(0, dtype)).dtype)
                     sample_io.npz_load(f, key, out=st.numpy())
                     s[(sigma, key)] = st.to(self.device, non_blocking=True).view(shape)
@@ -117,7 +126,15 @@ class DeviceSampleLoader:
             s = self._decode(folder)
             if self.cache is not None:
                 self.cache[item] = s
-        torch.cuda.current_stream().wait_event(s["_ready"])
+        cur = torch.cuda.current_stream()
+        cur.wait_event(s["_ready"])
+        # The decoded tensors were allocated under copy_stream but are read by kernels on the CALLER's stream (the subset
+        # kernels below; `input` / `target` by whatever consumes the sample).  Without record_stream a cache=False sample
+        # dropped at return hands its blocks back to copy_stream's pool while those kernels are still queued, and the next
+        # _decode overwrites them with H2D copies that never wait for the consumer.
+        for t in s.values():
+            if torch.is_tensor(t) and t.is_cuda:
+                t.record_stream(cur)
         if s.get("_staging") is not None and s["_ready"].query():
             s["_staging"] = None                       # the copies have landed: give the pinned staging buffers back
         pts, occ, grid = [], [], []

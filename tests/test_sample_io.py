@@ -85,3 +85,48 @@ def test_implicit_dataset_matches_reference_getitem(tmp_path):
         for k in ("grid", "points", "input", "occupancies", "target"):
             assert got[k].dtype == ref[k].dtype and got[k].shape == ref[k].shape and torch.equal(got[k], ref[k]), k
     assert tuple(ds[0]["input"].shape) == (1, 139, 104, 112) and tuple(ds[0]["points"].shape) == (600, 3)
+
+
+def test_malformed_npz_returns_an_error_instead_of_crashing(tmp_path):
+    """A half-written / corrupted .npz must come back as a RuntimeError through the C ABI (SVR_E_IO), never as an
+    uncaught C++ exception or an out-of-bounds read: truncations at every region of the file, a central directory whose
+    size / offset fields point past the file, an entry whose name length runs past the directory, and an .npy header
+    without a value after 'fortran_order'."""
+    io = _io()
+    rng = np.random.default_rng(5)
+    good = tmp_path / "good.npz"
+    np.savez_compressed(good, points=rng.uniform(-0.5, 0.5, size=(2000, 3)), occupancies=rng.random(2000) < 0.3)
+    raw = good.read_bytes()
+    assert np.array_equal(io.npz_load(good, "points"), np.load(good)["points"])
+    bad = tmp_path / "bad.npz"
+    for cut in (0, 10, 30, len(raw) // 3, len(raw) // 2, len(raw) - 40, len(raw) - 22, len(raw) - 1):
+        bad.write_bytes(raw[:cut])
+        with pytest.raises(RuntimeError):
+            io.npz_load(bad, "points")
+    eocd = raw.rfind(b"PK\x05\x06")
+    assert eocd > 0
+    for off, val in ((12, 0x7FFFFFF0), (16, 0x7FFFFFF0), (12, 0xFFFFFFFE)):      # cd_size / cd_offset far past the file
+        b = bytearray(raw)
+        b[eocd + off: eocd + off + 4] = int(val).to_bytes(4, "little")
+        bad.write_bytes(bytes(b))
+        with pytest.raises(RuntimeError):
+            io.npz_load(bad, "points")
+    cd = raw.find(b"PK\x01\x02")
+    b = bytearray(raw)
+    b[cd + 28: cd + 30] = (0xFFFF).to_bytes(2, "little")                          # file-name length past the directory
+    bad.write_bytes(bytes(b))
+    with pytest.raises(RuntimeError):
+        io.npz_load(bad, "points")
+    # stored member with a damaged .npy header: nothing but spaces behind 'fortran_order':
+    plain = tmp_path / "plain.npz"
+    np.savez(plain, a=np.arange(6.0).reshape(2, 3))
+    r = plain.read_bytes()
+    k = r.find(b"'fortran_order': False")
+    assert k > 0
+    hdr_end = r.find(b"\n", k)
+    b = bytearray(r)
+    b[k + len(b"'fortran_order':"): hdr_end] = b" " * (hdr_end - k - len(b"'fortran_order':"))
+    bad.write_bytes(bytes(b))
+    with pytest.raises(RuntimeError):
+        io.npz_load(bad, "a")
+    assert np.array_equal(io.npz_load(plain, "a"), np.arange(6.0).reshape(2, 3))  # the library is still usable afterwards
