@@ -130,6 +130,25 @@ def _relaunch_under_torchrun(a):
     return subprocess.call(cmd, env=env)
 
 
+def _malloc_sites(snap):
+    """--alloc-trace: every segment_alloc (= hipMalloc) of the recorded history with the frames of this repository on the
+    Python stack of the request that caused it."""
+    out = []
+    for trace in snap.get("device_traces", []):
+        for i, ev in enumerate(trace):
+            if ev.get("action") != "segment_alloc":
+                continue
+            frames = ev.get("frames") or []
+            if not frames:
+                for ev2 in trace[i + 1:i + 4]:
+                    if ev2.get("action") == "alloc":
+                        frames = ev2.get("frames") or []
+                        break
+            mine = [f"{os.path.relpath(f['filename'], ROOT)}:{f['line']} {f['name']}" for f in frames if ROOT in f.get("filename", "")]
+            out.append({"bytes": ev.get("size"), "stream": ev.get("stream"), "frames": mine[:5]})
+    return out
+
+
 def _stats(v):
     """min / median / p90 / max / mean of a list of milliseconds."""
     if not v:
@@ -191,6 +210,8 @@ def main():
     ap.add_argument("--no-fwd-only", action="store_true")
     ap.add_argument("--no-query", action="store_true", help="skip the query-path (f32 / bf16 storage / lattice) measurement")
     ap.add_argument("--no-diag", action="store_true", help="skip the untimed single-stream steps behind the timed region")
+    ap.add_argument("--alloc-trace", action="store_true",
+                    help="record the caching allocator's history over the timed region and report the call sites of every hipMalloc")
     ap.add_argument("--dist", choices=["uniform", "surface"], default="uniform",
                     help="query-point distribution; uniform (default) is the reported worst case")
     a = ap.parse_args()
@@ -252,17 +273,24 @@ def main():
     grown0 = arena.grown
     sync()
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]
-    host_ms = []
+    host_ms, malloc_at = [], []
+    if a.alloc_trace:
+        torch.cuda.memory._record_memory_history(max_entries=1000000, stacks="python")
     t0 = time.perf_counter()
     marks[0].record()
     for i in range(a.steps):
         h0 = time.perf_counter()
-        out = dp.step(batch)
+        loss_t = dp.step(batch)["loss"].detach()     # (not the graph: a kept loss tensor keeps its step's activations alive)
         marks[i + 1].record()
         host_ms.append((time.perf_counter() - h0) * 1e3)
+        malloc_at.append(torch.cuda.memory_stats(dev).get("num_device_alloc", 0))      # host-side counter, no device call
     sync()
     dt = time.perf_counter() - t0
     mem1 = torch.cuda.memory_stats(dev)
+    malloc_sites = None
+    if a.alloc_trace:
+        malloc_sites = _malloc_sites(torch.cuda.memory._snapshot())
+        torch.cuda.memory._record_memory_history(enabled=None)
     for mod, name, orig in restore:
         setattr(mod, name, orig)
     step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(a.steps)]
@@ -304,7 +332,7 @@ def main():
                 os.environ["SVR_NO_SIDE_STREAM"] = prev_env
             for mod, name, orig in diag:
                 setattr(mod, name, orig)
-    loss = float(out["loss"].detach())
+    loss = float(loss_t)
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
     if launched:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -316,6 +344,8 @@ def main():
             "all_reduce_ms": _stats(kt.times("all_reduce_mean")),
             "gather_fc0_ms": _stats(kt.times("gather_fc0_run") or kt.times("gather_fwd")),
             "hipMalloc_calls_in_timed_region": mem1.get("num_device_alloc", 0) - mem0.get("num_device_alloc", 0),
+            "hipMalloc_calls_per_step": [b - a_ for a_, b in zip([mem0.get("num_device_alloc", 0)] + malloc_at[:-1], malloc_at)],
+            "hipMalloc_sites": malloc_sites,
             "hipFree_calls_in_timed_region": mem1.get("num_device_free", 0) - mem0.get("num_device_free", 0),
             "reserved_bytes_grown_in_timed_region": mem1.get("reserved_bytes.all.current", 0) - mem0.get("reserved_bytes.all.current", 0),
             "reserved_bytes": mem1.get("reserved_bytes.all.current", 0)}
@@ -493,6 +523,8 @@ def report(a, world, dt, loss, step_ms, host_ms, kt, kd, ranks, forms, fwd_ms, q
         "step_max_over_median": (st["max"] / st["median"]) if st else None,
         "host_enqueue_ms": _stats(host_ms),
         "allocator": {"hipMalloc_calls_in_timed_region": ranks[0]["hipMalloc_calls_in_timed_region"],
+                      "hipMalloc_calls_per_step": ranks[0]["hipMalloc_calls_per_step"],
+                      "hipMalloc_sites": ranks[0]["hipMalloc_sites"],
                       "hipFree_calls_in_timed_region": ranks[0]["hipFree_calls_in_timed_region"],
                       "reserved_bytes_grown_in_timed_region": ranks[0]["reserved_bytes_grown_in_timed_region"],
                       "reserved_bytes": ranks[0]["reserved_bytes"],

@@ -316,7 +316,13 @@ class _EncoderGatherFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gfeat):
+        if ctx.saved is None:
+            raise RuntimeError("IF-Net HIP path: second backward through the same forward pass (the saved pyramid and "
+                               "activations are released by the first one; retain_graph is not supported)")
         ext, saved, levels, pts = ctx.ext, ctx.saved, ctx.levels, ctx.pts
+        # plain attributes are not freed with the graph's saved tensors: a caller that keeps the loss tensor (and with it
+        # this node) alive into the next step would otherwise hold ~9 GB of activations twice
+        ctx.saved = ctx.levels = ctx.pts = None
         need_x, need_pts = ctx.needs_input_grad[6], ctx.needs_input_grad[7]
         gfeat = gfeat.contiguous()
         link = ctx.link

@@ -46,12 +46,17 @@ class FeatureLayout:
             off += 7 * self.channels[l]
         self.width = off
         self.row_stride = (off + 31) // 32 * 32
+        self._subsets = {}
 
     def subset(self, levels):
         """Compact layout of a SUBSET of the levels (same relative order, no gaps, row stride padded to 32): the
         kept-column matrix of the training step -- the levels whose backward is not projected keep their gathered
         columns in (B*N, 800) instead of a 2592-wide row (128-architecture)."""
-        return KeptLayout(self, levels)
+        key = tuple(sorted(levels))
+        k = self._subsets.get(key)
+        if k is None:          # cached: the layout's device-side column index is uploaded once, not once per step
+            k = self._subsets[key] = KeptLayout(self, levels)
+        return k
 
     def reference_permutation(self):
         """perm[k_internal] = reference feature row k = c_global*7 + j (model/ifnet.py:43-45,197);

@@ -193,10 +193,10 @@ def test_dense_lattice_inference_at_139x104x112():
     assert got.shape == DIMS and np.isfinite(got).all()
     lat = make_3d_grid((-0.5,) * 3, (0.5,) * 3, DIMS).view(*DIMS, 3)
     assert float(lat[0, 0, 0, 0]) == -0.5 and float(lat[-1, -1, -1, 2]) == 0.5
-    sel = lat[3::17, 5::13, 2::11].reshape(-1, 3)                       # interior subset
-    gsel = got[3::17, 5::13, 2::11].reshape(-1)
-    faces = [lat[0, ::7, ::7], lat[-1, ::7, ::7], lat[::9, 0, ::7], lat[::9, -1, ::7], lat[::9, ::7, 0], lat[::9, ::7, -1]]
-    gfaces = [got[0, ::7, ::7], got[-1, ::7, ::7], got[::9, 0, ::7], got[::9, -1, ::7], got[::9, ::7, 0], got[::9, ::7, -1]]
+    sel = lat[3::7, 5::7, 2::7].reshape(-1, 3)                       # interior subset
+    gsel = got[3::7, 5::7, 2::7].reshape(-1)
+    faces = [lat[0, ::5, ::5], lat[-1, ::5, ::5], lat[::5, 0, ::5], lat[::5, -1, ::5], lat[::5, ::5, 0], lat[::5, ::5, -1]]
+    gfaces = [got[0, ::5, ::5], got[-1, ::5, ::5], got[::5, 0, ::5], got[::5, -1, ::5], got[::5, ::5, 0], got[::5, ::5, -1]]
     psel = torch.cat([sel] + [f.reshape(-1, 3) for f in faces]).unsqueeze(0)
     gall = np.concatenate([gsel] + [f.reshape(-1) for f in gfaces])
     with torch.no_grad():
