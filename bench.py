@@ -315,6 +315,8 @@ def main():
                 (ops, "conv3d_c1_fwd_stats", w(ops, "conv3d_c1_fwd_stats", lambda x, wt, *r, **k: _conv_key("conv_in_fwd", x, wt.shape[0], 1))),
                 (ops, "conv3d_k3_bwd_data", w(ops, "conv3d_k3_bwd_data", lambda dy, wt, *r, **k: _conv_key("conv_bwd_data", dy, wt.shape[0], wt.shape[1]))),
                 (ops, "conv3d_k3_bwd_weight", w(ops, "conv3d_k3_bwd_weight", lambda x, dy, *r, **k: _conv_key("conv_bwd_weight", x, dy.shape[4], x.shape[4]))),
+                (ops, "stage1_fwd", w(ops, "stage1_fwd", lambda x, wt, *r, **k: "stage1_fwd:" + "x".join(str(v) for v in x.shape[:4]) + f"x{wt.shape[0]}")),
+                (ops, "stage1_bwd", w(ops, "stage1_bwd", lambda x, wp, *r, **k: "stage1_bwd:" + "x".join(str(v) for v in x.shape[:4]) + f"x{wp.shape[2]}")),
                 (ops, "bn_forward", w(ops, "bn_forward", lambda x, *r, **k: "bn_fwd:" + "x".join(str(v) for v in x.shape))),
                 (ops, "bn_backward", w(ops, "bn_backward", lambda x, *r, **k: "bn_bwd:" + "x".join(str(v) for v in x.shape)))]
         prev_overlap, _ifn.OVERLAP_BACKWARD = _ifn.OVERLAP_BACKWARD, False
@@ -588,7 +590,8 @@ def report(a, world, dt, loss, step_ms, host_ms, kt, kd, ranks, forms, fwd_ms, q
     # every GEMM of the step, keyed by the shape it was CALLED with: point-MLP layers have M = points, the two
     # projected levels add voxel-row GEMMs (M = B*S^3); fc_0's backward runs over the kept columns only
     what = {"linear_fwd": "forward (f16x3)", "linear_bwd_data": "dX", "linear_bwd_weight": "dW + bias gradient"}
-    mlp_ms, enc_ms = 0.0, {"conv_fwd": 0.0, "conv_in_fwd": 0.0, "conv_bwd_data": 0.0, "conv_bwd_weight": 0.0, "bn_fwd": 0.0, "bn_bwd": 0.0}
+    mlp_ms, enc_ms = 0.0, {"stage1_fwd": 0.0, "stage1_bwd": 0.0, "conv_fwd": 0.0, "conv_in_fwd": 0.0, "conv_bwd_data": 0.0,
+                           "conv_bwd_weight": 0.0, "bn_fwd": 0.0, "bn_bwd": 0.0}
     for key in sorted(kd.ev):
         op, _, shape = key.partition(":")
         calls = len(kd.ev[key]) / DIAG_STEPS
@@ -625,6 +628,22 @@ def report(a, world, dt, loss, step_ms, host_ms, kt, kd, ranks, forms, fwd_ms, q
                             "peak": MFMA_F16_PEAK_TFLOPS if split > 1 else 157.3, "achieved": tf,
                             "frac": tf / (MFMA_F16_PEAK_TFLOPS if split > 1 else 157.3), "ms_per_step": ms, "calls_per_step": calls,
                             "f32_equivalent_TFLOPs": tf / split})
+        elif op in ("stage1_fwd", "stage1_bwd"):
+            # recomputed first stage (stage1.hip): HBM bound by construction.  Algorithmic bytes per voxel of the 16-channel
+            # volume: forward = x twice (4 B each) + y written (64 B) + pooled and argmax (64 / 8 + 16 / 8 B); backward = x twice
+            # + dy twice (64 B each) + dpooled and argmax twice ((64 + 16) / 8 B each)
+            dims = [int(v) for v in shape.split("x")]
+            vox = dims[0] * dims[1] * dims[2] * dims[3]
+            enc_ms[op] += ms
+            per_vox = (8 + 64 + 8 + 2) if op == "stage1_fwd" else (8 + 128 + 20)
+            byts = vox * per_vox * calls
+            rate = byts / (ms * 1e-3) / 1e9
+            what1 = ("forward: conv_in -> ReLU -> BatchNorm statistics, then again -> y, pooled, argmax" if op == "stage1_fwd" else
+                     "backward: BatchNorm reduce, then BatchNorm apply -> conv_in weight / bias gradient (no dconv tensor)")
+            kernels.append({"kernel": f"encoder stage 1 recomputed ({what1}) {shape}", "bound": "hbm", "unit": "GB/s",
+                            "peak": HBM_PEAK_GBPS, "achieved": rate, "frac": rate / HBM_PEAK_GBPS, "ms_per_step": ms,
+                            "calls_per_step": calls, "algorithmic_bytes_per_step": byts,
+                            "mfma_f32_TFLOPs": (vox * (2 if op == "stage1_fwd" else 2 + 2 * 32 / 27.0) * 2 * 27 * 16 * calls) / (ms * 1e-3) / 1e12})
         elif op in ("bn_fwd", "bn_bwd"):
             # BatchNorm + pool passes: HBM bound.  Algorithmic bytes per element of the (B,D,H,W,C) volume: forward =
             # statistics read (skipped where the producing conv delivers them) + apply read + write (+ pooled write / 8 and

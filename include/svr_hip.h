@@ -381,6 +381,31 @@ int svr_bn_bwd_apply(const float *x, const float *dy, const float *dpooled, cons
                      int32_t D, int32_t H, int32_t W, int32_t C, int relu_mask, void *stream);
 
 /* ---------------------------------------------------------------------------------------
+ * First encoder stage of the 128-architecture as one recomputed unit (stage1.hip):
+ *   a = relu(conv_in(x) + bias), y = BatchNorm3d(a), pooled = MaxPool3d(2)(y)
+ * (replaces model/ifnet.py:126,138,136 as called at :165-166,169, and their autograd).  `a` -- one input channel, 27 taps,
+ * 16 outputs -- is recomputed from x in every pass instead of being stored: the forward reads x and writes y / pooled /
+ * argmax only, the backward reads x, dy, dpooled and writes the parameter gradients only.
+ *   svr_stage1_supported: Co == 16 and 32-bit offsets inside one sample.
+ *   svr_stage1_fwd:  training != 0: batch statistics (stats[0:16] mean, [16:32] biased variance, float64; running
+ *                    statistics updated like torch), else the running statistics; outputs as svr_bn_finalize +
+ *                    svr_bn_apply_pool (scale_shift 3 x 16, mean_f32 16, y, pooled / argmax may be NULL).
+ *   svr_stage1_bwd:  dy_total = dy (may be NULL) + unpool(dpooled via argmax) (may be NULL); sums (float64, 2 x 16) =
+ *                    sum dy_total, sum dy_total*xhat; dgamma, dbeta; dWp[27][16] and db[16] of conv_in; dout (may be NULL)
+ *                    = d(loss)/d(conv_in output) for a caller that needs d(loss)/d(x).  relu_mask as svr_bn_bwd_apply.
+ *   workspace: svr_stage1_workspace(B, D, H, W) bytes.  Wp = svr_conv3d_pack_weight's Wp_fwd ([27][1][16]).          */
+int32_t svr_stage1_supported(int32_t B, int32_t D, int32_t H, int32_t W, int32_t Co);
+int64_t svr_stage1_workspace(int32_t B, int32_t D, int32_t H, int32_t W);
+int svr_stage1_fwd(const float *x, const float *Wp, const float *bias, const float *gamma, const float *beta,
+                   float *running_mean, float *running_var, float *y, float *pooled, uint8_t *argmax,
+                   float *scale_shift, float *mean_f32, double *stats, int32_t B, int32_t D, int32_t H, int32_t W,
+                   int32_t Co, float eps, float momentum, int training, void *workspace, void *stream);
+int svr_stage1_bwd(const float *x, const float *Wp, const float *bias, const float *dy, const float *dpooled,
+                   const uint8_t *argmax, const float *mean_f32, const float *scale_shift, double *sums,
+                   float *dgamma, float *dbeta, float *dWp, float *db, float *dout, int32_t B, int32_t D,
+                   int32_t H, int32_t W, int32_t Co, int relu_mask, void *workspace, void *stream);
+
+/* ---------------------------------------------------------------------------------------
  * Depth -> point cloud -> voxel grid  (model/projection.py).
  * ------------------------------------------------------------------------------------- */
 /* pc[b][v*Wi+u] = (c2f * [X,Y,Z,1]) then optionally (p - dims/2)/dims  (projection.py:150-163,

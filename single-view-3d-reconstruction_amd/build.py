@@ -26,6 +26,7 @@ SOURCES = {
     "conv3d_bf16.hip": [],
     "conv3d_bwdw_bf16.hip": [],
     "bn_pool.hip": [],
+    "stage1.hip": [f"-DS1_EXP={os.environ['SVR_S1_EXP']}"] if os.environ.get("SVR_S1_EXP") else [],   # measurement builds
     "projection.hip": ["-ffp-contract=off"],
     "bf16_path.hip": ["-ffp-contract=off"],
     "mesh_occupancy.hip": ["-ffp-contract=off"],

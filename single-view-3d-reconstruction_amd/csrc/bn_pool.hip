@@ -346,6 +346,10 @@ namespace svr {
 void bn_stats_final_launch(const double *part, double *stats, int64_t rows, int C, int blocks, hipStream_t s) {
   hipLaunchKernelGGL(bn_stats_final_kernel, dim3(C), dim3(256), 0, s, part, stats, rows, C, blocks);
 }
+// out[c] = ordered f64 sum over `blocks` partial rows [blocks][cols]: shared with stage1.hip's backward reduction
+void bn_sum_parts_launch(const double *part, double *out, int cols, int blocks, hipStream_t s) {
+  hipLaunchKernelGGL(sum_parts_kernel, dim3(cols), dim3(256), 0, s, part, out, cols, blocks);
+}
 }  // namespace svr
 
 extern "C" int64_t svr_bn_stats_workspace(int64_t rows, int32_t C) {

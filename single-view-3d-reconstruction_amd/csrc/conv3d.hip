@@ -720,6 +720,13 @@ void conv3d_bwd_weight_reduce_launch(const float *slab, float *dWp, int Ci, int 
   const int per = 27 * cit * cot * 1024;
   hipLaunchKernelGGL(conv3d_bwd_weight_reduce_kernel, dim3(cdiv(per, 64)), dim3(256), 0, s, slab, dWp, Ci, Co, cit, cot, parts);
 }
+// shared with stage1.hip: conv_in's dWp[tap][co] / db[co] = ordered f64 sums of per-workgroup slabs [part][32 taps][32] / [part][Co]
+void conv3d_c1_wgrad_reduce_launch(const float *slab, float *dWp, int Co, int parts, hipStream_t s) {
+  hipLaunchKernelGGL(conv3d_c1_bwd_weight_reduce_kernel, dim3(27 * Co), dim3(256), 0, s, slab, dWp, Co, parts);
+}
+void conv3d_db_reduce_launch(const float *dbpart, float *db, int Co, int parts, hipStream_t s) {
+  hipLaunchKernelGGL(conv3d_db_reduce_kernel, dim3(Co), dim3(256), 0, s, dbpart, db, Co, parts);
+}
 }  // namespace svr
 
 extern "C" int svr_conv3d_pack_weight(const float *W, float *Wp_fwd, float *Wp_bwd, int32_t Ci, int32_t Co, void *stream) {

@@ -171,6 +171,10 @@ PROJ_TWO_PASS_MIN_DIM = 16
 FUSE_FC0 = os.environ.get("SVR_NO_FUSED_FC0") is None
 # Fused + projected backward: the kept-column branch on the side stream beside the projected branch (SVR_NO_BWD_OVERLAP=1: serial)
 OVERLAP_BACKWARD = os.environ.get("SVR_NO_BWD_OVERLAP") is None
+# First stage of the 128-architecture (conv_in -> ReLU -> BatchNorm -> pool) with conv_in's activation recomputed instead
+# of stored (stage1.hip): 3 of 5 forward and 5 of 7 backward passes over 1 GB tensors less.  SVR_NO_STAGE1=1: the separate
+# conv / BatchNorm / weight-gradient kernels.
+STAGE1_RECOMPUTE = os.environ.get("SVR_NO_STAGE1") is None
 # The step's large cross-stream buffers live in a per-module StepArena (arena.py); SVR_NO_ARENA=1: ordinary allocations
 USE_ARENA = os.environ.get("SVR_NO_ARENA") is None
 
@@ -188,6 +192,12 @@ def _fc0_fusable(channels, B, dims, n_out):
         if B * max(D >> s, 1) * max(H >> s, 1) * max(W >> s, 1) * c >= 2 ** 30:
             return False
     return True
+
+
+def _stage1_applies(si, convs, inp):
+    """First stage, one convolution from one input channel to 16 (the 128-architecture's conv_in), shapes stage1.hip covers."""
+    return (STAGE1_RECOMPUTE and si == 0 and len(convs) == 1 and inp.is_cuda and tuple(convs[0].weight.shape[:2]) == (16, 1)
+            and min(inp.shape[1:4]) >= 1 and ops.stage1_supported(inp, 16))
 
 
 class _ProjLink:
@@ -265,6 +275,17 @@ class _EncoderGatherFn(torch.autograd.Function):
                 pts, D, H, W, nlev, ext._align, ctx.klay if ctx.klay is not None else ext._layout, ext._disp,
                 proj_levels=ctx.link.levels if ctx.link is not None else (), arena=arena)
         for si, (convs, bn) in enumerate(ext._stages):
+            if _stage1_applies(si, convs, inp):
+                conv = convs[0]
+                y, pooled, argmax, ss, mean, wp = ops.stage1_fwd(
+                    inp, conv.weight.detach(), conv.bias.detach(), bn.weight.detach(), bn.bias.detach(), bn.running_mean,
+                    bn.running_var, training, eps=bn.eps, momentum=bn.momentum, want_pool=(si + 1 < nst))
+                if training:
+                    bn.num_batches_tracked += 1
+                levels.append(y)
+                saved.append((inp, ("stage1", wp), argmax, ss, mean))      # conv_in's activation is never stored
+                inp = pooled
+                continue
             acts = []
             cur = inp
             stats = None
@@ -428,6 +449,17 @@ class _EncoderGatherFn(torch.autograd.Function):
         for si in range(len(ext._stages) - 1, -1, -1):
             convs, bn = ext._stages[si]
             inp, acts, argmax, ss, mean = saved[si]
+            if isinstance(acts, tuple):       # ("stage1", wp): BatchNorm backward + conv_in's weight gradient in two passes
+                conv = convs[0]
+                dgamma, dbeta, dwp, db, dout = ops.stage1_bwd(
+                    inp, acts[1], conv.bias.detach(), gvols[si + 1], dpooled, argmax if dpooled is not None else None, mean, ss,
+                    relu_mask=True, training=ctx.training, want_dout=need_x)
+                grads[bn.weight], grads[bn.bias] = dgamma, dbeta
+                grads[conv.weight] = ops.conv3d_unpack_wgrad(dwp, 1, conv.weight.shape[0])
+                grads[conv.bias] = db
+                if need_x:
+                    gx = ops.conv3d_k3_bwd_data(dout, conv.weight.detach())
+                continue
             dout, dgamma, dbeta = ops.bn_backward(acts[-1], gvols[si + 1], dpooled, argmax if dpooled is not None else None,
                                                   mean, ss, relu_mask=True, training=ctx.training)
             grads[bn.weight], grads[bn.bias] = dgamma, dbeta
@@ -560,6 +592,14 @@ class _ExtractorBase(nn.Module):
         levels = [inp]
         nst = len(self._stages)
         for si, (convs, bn) in enumerate(self._stages):
+            if _stage1_applies(si, convs, inp):
+                conv = convs[0]
+                y, pooled = ops.stage1_fwd(inp, conv.weight.detach(), conv.bias.detach(), bn.weight.detach(), bn.bias.detach(),
+                                           bn.running_mean, bn.running_var, self.training, eps=bn.eps, momentum=bn.momentum,
+                                           want_pool=(si + 1 < nst))[:2]
+                levels.append(y)
+                inp = pooled
+                continue
             cur = inp
             for conv in convs:
                 cur = ops.conv3d_k3_fwd(cur, conv.weight.detach(), conv.bias.detach(), relu=True)

@@ -765,6 +765,58 @@ def bn_backward(x, dy, dpooled, argmax, mean, ss, relu_mask=True, training=True)
     return dx, dgamma, dbeta
 
 
+def stage1_supported(x, Co):
+    """The recomputed first stage (stage1.hip) covers this input grid?  x (B,D,H,W,1)."""
+    B, D, H, W, Ci = x.shape
+    return Ci == 1 and bool(_lib.lib().svr_stage1_supported(B, D, H, W, Co))
+
+
+def stage1_fwd(x, w, bias, gamma, beta, running_mean, running_var, training, eps=1e-5, momentum=0.1, want_pool=True):
+    """x (B,D,H,W,1) -> y = BN(relu(conv_in(x))), pooled, argmax, scale_shift (3*16), mean (16), wp: conv_in's activation
+    is recomputed wherever it is needed and never stored (stage1.hip)."""
+    _f32(x, w, bias, gamma, beta, running_mean, running_var)
+    B, D, H, W, _ = x.shape
+    Co = w.shape[0]
+    if training and B * D * H * W <= 1:
+        raise ValueError(f"Expected more than 1 value per channel when training, got input size torch.Size([{B}, {Co}, {D}, {H}, {W}])")
+    l = _lib.lib()
+    dev = x.device
+    wp, _ = conv3d_pack_weight(w, want_bwd=False)
+    y = torch.empty(B, D, H, W, Co, device=dev, dtype=torch.float32)
+    pooled = argmax = None
+    if want_pool:
+        pooled = torch.empty(B, D // 2, H // 2, W // 2, Co, device=dev, dtype=torch.float32)
+        argmax = torch.empty(B, D // 2, H // 2, W // 2, Co, device=dev, dtype=torch.uint8)
+    ss = torch.empty(3 * Co, device=dev, dtype=torch.float32)
+    mean = torch.empty(Co, device=dev, dtype=torch.float32)
+    stats = torch.empty(2 * Co, device=dev, dtype=torch.float64) if training else None
+    ws = torch.empty(l.svr_stage1_workspace(B, D, H, W), device=dev, dtype=torch.uint8)
+    check(l.svr_stage1_fwd(_p(x), _p(wp), _p(bias), _p(gamma), _p(beta), _p(running_mean), _p(running_var), _p(y), _p(pooled),
+                           _p(argmax), _p(ss), _p(mean), _p(stats), B, D, H, W, Co, eps, momentum, int(training), _p(ws),
+                           _stream()), "stage1_fwd")
+    return y, pooled, argmax, ss, mean, wp
+
+
+def stage1_bwd(x, wp, bias, dy, dpooled, argmax, mean, ss, relu_mask=True, training=True, want_dout=False):
+    """Backward of stage1_fwd -> dgamma, dbeta, dWp [27][1][16], db, dout (None unless want_dout)."""
+    _f32(x, wp, bias, dy, dpooled, mean, ss)
+    B, D, H, W, _ = x.shape
+    Co = wp.shape[2]
+    l = _lib.lib()
+    dev = x.device
+    sums = torch.empty(2 * Co, device=dev, dtype=torch.float64)
+    dgamma = torch.empty(Co, device=dev, dtype=torch.float32)
+    dbeta = torch.empty(Co, device=dev, dtype=torch.float32)
+    dwp = torch.empty(27, 1, Co, device=dev, dtype=torch.float32)
+    db = torch.empty(Co, device=dev, dtype=torch.float32)
+    dout = torch.empty(B, D, H, W, Co, device=dev, dtype=torch.float32) if want_dout else None
+    ws = torch.empty(l.svr_stage1_workspace(B, D, H, W), device=dev, dtype=torch.uint8)
+    check(l.svr_stage1_bwd(_p(x), _p(wp), _p(bias), _p(dy), _p(dpooled), _p(argmax), _p(mean), _p(ss), _p(sums), _p(dgamma),
+                           _p(dbeta), _p(dwp), _p(db), _p(dout), B, D, H, W, Co, int(relu_mask) | (0 if training else 2),
+                           _p(ws), _stream()), "stage1_bwd")
+    return dgamma, dbeta, dwp, db, dout
+
+
 # ------------------------------------------------------------------------------------------
 # projection: unproject / splat / clamp / blur
 # ------------------------------------------------------------------------------------------

@@ -429,6 +429,63 @@ def test_bn_pool_fwd_bwd(B, dims, C, pool):
     assert G.rel_err(dge.cpu().numpy(), gge.numpy()) < 1e-5 and G.rel_err(dbe.cpu().numpy(), gbe.numpy()) < 1e-5
 
 
+@pytest.mark.parametrize("B,dims,training", [(2, (9, 7, 11), True), (1, (16, 16, 16), True), (2, (19, 10, 21), True),
+                                             (1, (8, 8, 8), False), (3, (3, 2, 5), True)])
+def test_stage1_recomputed_conv_in_bn_pool(B, dims, training):
+    """stage1.hip: y = BN(relu(conv_in(x))), pooled, and the backward (dgamma, dbeta, conv_in's dW / db, optional dconv)
+    against float64 torch autograd of the same three modules (model/ifnet.py:126,138,136 as called at :165-169) -- odd,
+    non-cubic volumes (cut pool cells, partial bricks), batch > 1, eval mode."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(B * 100 + dims[0])
+    x = (torch.rand(B, 1, *dims, generator=g) < 0.3).float() * torch.rand(B, 1, *dims, generator=g)
+    w = (torch.randn(16, 1, 3, 3, 3, generator=g) / 27 ** 0.5).requires_grad_(True)
+    b = (torch.randn(16, generator=g) * 0.3).requires_grad_(True)
+    gamma = (torch.rand(16, generator=g) + 0.5).requires_grad_(True)
+    beta = (torch.rand(16, generator=g) - 0.5).requires_grad_(True)
+    rm, rv = torch.rand(16, generator=g) * 0.2, torch.rand(16, generator=g) + 0.5
+    xd = x.double().requires_grad_(True)
+    a_ref = F.relu(F.conv3d(xd, w.double(), b.double(), padding=1))
+    rm_r, rv_r = rm.double().clone(), rv.double().clone()
+    y_ref = F.batch_norm(a_ref, rm_r, rv_r, gamma.double(), beta.double(), training, 0.1, 1e-5)
+    pool = min(dims) >= 2
+    rm_g, rv_g = rm.clone().cuda(), rv.clone().cuda()
+    assert ops.stage1_supported(_cl(x), 16)
+    y, pooled, argmax, ss, mean, wp = ops.stage1_fwd(_cl(x), w.detach().cuda(), b.detach().cuda(), gamma.detach().cuda(),
+                                                     beta.detach().cuda(), rm_g, rv_g, training, want_pool=pool)
+    assert G.rel_err(_ncdhw(y).numpy(), y_ref.detach().numpy()) < 3e-6
+    if training:
+        assert G.rel_err(rm_g.cpu().numpy(), rm_r.numpy()) < 2e-6 and G.rel_err(rv_g.cpu().numpy(), rv_r.numpy()) < 2e-6
+    dy = torch.randn(y_ref.shape, generator=g)
+    obj = (y_ref * dy.double()).sum()
+    dp = None
+    if pool:
+        p_ref = F.max_pool3d(y_ref, 2)
+        assert G.rel_err(_ncdhw(pooled).numpy(), p_ref.detach().numpy()) < 3e-6
+        # the argmax routes the pooled gradient: same voxel as torch's (checked through the gradient below)
+        dp = torch.randn(p_ref.shape, generator=g)
+        obj = obj + (p_ref * dp.double()).sum()
+    gx, gw, gb, gg, gbeta = torch.autograd.grad(obj, (xd, w, b, gamma, beta))
+    for want_dout in (False, True):
+        dgamma, dbeta, dwp, db, dout = ops.stage1_bwd(_cl(x), wp, b.detach().cuda(), _cl(dy), _cl(dp) if pool else None,
+                                                      argmax if pool else None, mean, ss, relu_mask=True, training=training,
+                                                      want_dout=want_dout)
+        dw = ops.conv3d_unpack_wgrad(dwp, 1, 16)
+        assert G.rel_err(dw.cpu().numpy(), gw.numpy()) < 1e-5
+        assert G.rel_err(db.cpu().numpy(), gb.numpy()) < 1e-5
+        assert G.rel_err(dgamma.cpu().numpy(), gg.numpy()) < 1e-5 and G.rel_err(dbeta.cpu().numpy(), gbeta.numpy()) < 1e-5
+        if want_dout:       # d(loss)/d(x) through the separate backward-data kernel, as the encoder's backward does
+            dx = ops.conv3d_k3_bwd_data(dout, w.detach().cuda(), mode="f32")
+            assert G.rel_err(_ncdhw(dx).numpy(), gx.numpy()) < 1e-5
+    # the same results as the separate kernels it replaces (conv_in + statistics, BatchNorm + pool) on the same input
+    if training:
+        rm2, rv2 = rm.clone().cuda(), rv.clone().cuda()
+        a2, st2 = ops.conv3d_c1_fwd_stats(_cl(x), w.detach().cuda(), b.detach().cuda(), relu=True)
+        y2, p2, am2, _, _ = ops.bn_forward(a2, gamma.detach().cuda(), beta.detach().cuda(), rm2, rv2, True, want_pool=pool, stats=st2)
+        assert G.rel_err(y.cpu().numpy(), y2.cpu().numpy()) < 3e-6
+        if pool:
+            assert G.rel_err(pooled.cpu().numpy(), p2.cpu().numpy()) < 3e-6
+
+
 def test_morton_order_is_a_permutation_and_gather_is_order_independent():
     ops = _ops()
     chans = [1, 16, 32, 64, 128, 128]
