@@ -175,6 +175,8 @@ OVERLAP_BACKWARD = os.environ.get("SVR_NO_BWD_OVERLAP") is None
 # of stored (stage1.hip): 3 of 5 forward and 5 of 7 backward passes over 1 GB tensors less.  SVR_NO_STAGE1=1: the separate
 # conv / BatchNorm / weight-gradient kernels.
 STAGE1_RECOMPUTE = os.environ.get("SVR_NO_STAGE1") is None
+# Training step: the Morton sort of the points runs on the side stream beside the encoder (SVR_SORT_ON_MAIN=1: in front of it)
+SORT_ON_SIDE_STREAM = os.environ.get("SVR_SORT_ON_MAIN") is None
 # The step's large cross-stream buffers live in a per-module StepArena (arena.py); SVR_NO_ARENA=1: ordinary allocations
 USE_ARENA = os.environ.get("SVR_NO_ARENA") is None
 
@@ -280,8 +282,6 @@ class _EncoderGatherFn(torch.autograd.Function):
                 y, pooled, argmax, ss, mean, wp = ops.stage1_fwd(
                     inp, conv.weight.detach(), conv.bias.detach(), bn.weight.detach(), bn.bias.detach(), bn.running_mean,
                     bn.running_var, training, eps=bn.eps, momentum=bn.momentum, want_pool=(si + 1 < nst))
-                if training:
-                    bn.num_batches_tracked += 1
                 levels.append(y)
                 saved.append((inp, ("stage1", wp), argmax, ss, mean))      # conv_in's activation is never stored
                 inp = pooled
@@ -299,11 +299,14 @@ class _EncoderGatherFn(torch.autograd.Function):
             y, pooled, argmax, ss, mean = ops.bn_forward(
                 cur, bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var, training,
                 eps=bn.eps, momentum=bn.momentum, want_pool=(si + 1 < nst), stats=stats)
-            if training:
-                bn.num_batches_tracked += 1
             levels.append(y)
             saved.append((inp, acts, argmax, ss, mean))
             inp = pooled
+        if training:      # one multi-tensor launch for the counters of all stages
+            torch._foreach_add_([bn.num_batches_tracked for _, bn in ext._stages], 1)
+        ready, ext._points_ready = getattr(ext, "_points_ready", None), None
+        if ready is not None:
+            torch.cuda.current_stream().wait_event(ready)      # the sorted points (IFNet.forward sorts them on the side stream)
         if ctx.fused:
             rows_out = None
             if keep and arena is not None:
@@ -561,6 +564,22 @@ class _PointMLPFn(torch.autograd.Function):
         return dfeat, None, dw0, db0, dw1, db1, dw2, db2, dwo, dbo, None
 
 
+class _PermuteColumnsFn(torch.autograd.Function):
+    """w (H, F) -> w[:, src] with zeros where mask (H, FS): a column permutation with zero padding columns.  Backward is the inverse
+    permutation (one index_select) -- autograd's own backward of advanced indexing is an index_put with a sort (a dozen
+    launches at the end of every step)."""
+
+    @staticmethod
+    def forward(ctx, w, src, mask, inv):
+        ctx.save_for_backward(inv)
+        return w.index_select(1, src).masked_fill_(mask, 0.0)
+
+    @staticmethod
+    def backward(ctx, g):
+        (inv,) = ctx.saved_tensors
+        return g.index_select(1, inv), None, None, None
+
+
 class _ExtractorBase(nn.Module):
     """Shared host logic of the two extractor variants."""
 
@@ -693,15 +712,19 @@ class IFNet(nn.Module):
             raise NotImplementedError(f"net_res={net_res}")
         self.fc_out = nn.Conv1d(hidden_dim, 1, 1)
         self.actvn = nn.ReLU()
-        self.register_buffer("_fc0_perm", self.ifnet_feature_extractor._layout.reference_permutation(), persistent=False)
+        perm = self.ifnet_feature_extractor._layout.reference_permutation()
+        self.register_buffer("_fc0_perm", perm, persistent=False)
+        # gather index / 0-1 mask of the internal columns, and the inverse (reference feature k -> internal column)
+        self.register_buffer("_fc0_src", perm.clamp(min=0), persistent=False)
+        self.register_buffer("_fc0_mask", perm < 0, persistent=False)          # True on the padding columns
+        inv = torch.empty(int((perm >= 0).sum()), dtype=torch.long)
+        inv[perm[perm >= 0]] = torch.nonzero(perm >= 0).squeeze(1)
+        self.register_buffer("_fc0_inv", inv, persistent=False)
 
     def _fc0_internal(self):
         """fc_0.weight (H, F, 1) with reference column order k = c*7+j -> (H, FS) in the internal
         column order (zero weight on padding columns).  The checkpoint layout never changes."""
-        w = self.fc_0.weight.squeeze(2)
-        perm = self._fc0_perm
-        wz = torch.cat([w, w.new_zeros(w.shape[0], 1)], dim=1)
-        return wz[:, torch.where(perm >= 0, perm, torch.full_like(perm, w.shape[1]))].contiguous()
+        return _PermuteColumnsFn.apply(self.fc_0.weight.squeeze(2), self._fc0_src, self._fc0_mask, self._fc0_inv)
 
     @torch.no_grad()
     def encode(self, x, storage="f32"):
@@ -778,9 +801,22 @@ class IFNet(nn.Module):
         lease = ext._arena.lease() if (USE_ARENA and torch.is_grad_enabled() and not points.requires_grad
                                        and not torch.cuda.is_current_stream_capturing()) else None
         arena = lease.arena if lease is not None else None
+        ext._points_ready = None
         if spatial_sort and N > 1:
             pts = points.detach().float().contiguous()
-            row_map, sorted_pts = ops.morton_order(pts, want_sorted=True, arena=arena)     # samples stay contiguous
+            if arena is not None and SORT_ON_SIDE_STREAM and not os.environ.get("SVR_NO_SIDE_STREAM"):
+                # the Morton sort (a chain of ~25 launch-bound radix-sort kernels, 0.2 ms) is only needed by the gather and
+                # by the scatter plans: it runs on the side stream, in front of the plans, while the encoder starts on the
+                # main stream at once; the main stream waits for it in front of the gather (_EncoderGatherFn.forward).
+                # (Arena buffers only: they never return to an allocator pool, so no record_stream bookkeeping.)
+                main, side = torch.cuda.current_stream(), _get_side_stream(x.device)
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    row_map, sorted_pts = ops.morton_order(pts, want_sorted=True, arena=arena)
+                    ext._points_ready = torch.cuda.Event()
+                    ext._points_ready.record(side)
+            else:
+                row_map, sorted_pts = ops.morton_order(pts, want_sorted=True, arena=arena)     # samples stay contiguous
             if points.requires_grad:       # rare (subsample_points > 0): keep the permutation differentiable
                 points = points.reshape(B * N, 3)[row_map.long()].view(B, N, 3)
             else:

@@ -623,3 +623,54 @@ def test_fused_gather_fc0_equals_gather_then_linear(B, dims, N, spread, chans, a
     h0n, none = ops.gather_fc0_fwd(vols_g, pts, layout, disp, ac, w, bias, relu=False)
     assert none is None
     assert torch.equal(torch.relu(h0n), h0)
+
+
+def test_fused_gather_fc0_with_non_finite_volume_values():
+    """Documented difference (gather_fc0.hip, produce_slab): ATen's grid_sample SKIPS a corner outside the volume; the fused
+    kernel reads the CLAMPED (existing) voxel and multiplies by a weight of exactly 0 -- identical for finite volumes, but
+    0 * inf = NaN.  A clamped corner is always the same voxel as an in-range corner of the same sample UNLESS the whole
+    sample lies outside the volume, so the two differ exactly there: ATen returns 0, the fused kernel NaN when the nearest
+    border voxel is non-finite.  The unfused gather (svr_gather_trilinear_fwd, what API-compat callers get) follows ATen.
+    Pinned: (a) a non-finite voxel no sample reaches changes nothing; (b) with an inf border plane the unfused rows equal
+    F.grid_sample bit for bit, the fused h0 is non-finite wherever ATen's features are AND in the rows whose samples lie
+    entirely beyond that plane (finite zeros in ATen), and every other row keeps its bits."""
+    import torch.nn.functional as F
+    ops = _ops()
+    chans = [1, 16, 32, 64, 128, 128]
+    B, dims, N = 1, (16, 16, 16), 600
+    vols = _rand_levels(B, dims, chans, 41)
+    g = torch.Generator().manual_seed(42)
+    pts = (torch.rand(B, N, 3, generator=g) - 0.5) * 0.6          # interior: nobody comes near the border voxels
+    jit = (torch.rand(60, 3, generator=g) - 0.5) * torch.tensor([0.0, 0.2, 0.2])
+    pts[0, :40] = torch.tensor([0.499, 0.0, 0.0]) + jit[:40]       # straddle the last plane of the first spatial axis
+    pts[0, 40:60] = torch.tensor([0.62, 0.0, 0.0]) + jit[40:]      # all 7 samples entirely beyond it (source index > 16)
+    layout = ops.FeatureLayout(chans)
+    disp = float(np.float32(0.0722))
+    w = (torch.randn(256, layout.row_stride, generator=g) / 30).cuda()
+    w[:, layout.width:] = 0
+    bias = torch.randn(256, generator=g).cuda()
+    base = ops.gather_fc0_fwd([_cl(v) for v in vols], pts.cuda(), layout, disp, False, w, bias, relu=False)[0]
+    assert bool(torch.isfinite(base).all())
+    # (a) a corner voxel of the level-1 volume far away from every sample
+    va = [v.clone() for v in vols]
+    va[1][0, :, 0, 0, 0] = float("inf")
+    ha = ops.gather_fc0_fwd([_cl(v) for v in va], pts.cuda(), layout, disp, False, w, bias, relu=False)[0]
+    assert torch.equal(ha, base)
+    # (b) the whole last plane of the first spatial axis of level 1
+    vb = [v.clone() for v in vols]
+    vb[1][0, :, -1] = float("inf")
+    vols_b = [_cl(v) for v in vb]
+    rows = ops.gather_fwd(vols_b, pts.cuda(), layout, disp, False)
+    grid = torch.stack([2 * pts[..., 2], 2 * pts[..., 1], 2 * pts[..., 0]], -1).view(B, 1, 1, N, 3)
+    want1 = F.grid_sample(vb[1], grid, mode="bilinear", padding_mode="zeros", align_corners=False)[0, :, 0, 0].t()   # (N, 16), j = 0
+    got1 = rows[:, layout.col[1]: layout.col[1] + 16].cpu()
+    assert bool(((got1 == want1) | (torch.isnan(got1) & torch.isnan(want1))).all())   # the unfused gather IS ATen, inf / nan included
+    aten_bad = ~torch.isfinite(rows[:, layout.col[1]: layout.col[1] + 7 * 16]).all(dim=1).cpu()
+    assert bool(aten_bad[:40].any()) and not bool(aten_bad[40:].any())  # beyond the plane ATen returns finite zeros
+    assert bool((rows[40:60, layout.col[1]: layout.col[1] + 7 * 16] == 0).all())
+    hb = ops.gather_fc0_fwd(vols_b, pts.cuda(), layout, disp, False, w, bias, relu=False)[0]
+    bad = ~torch.isfinite(hb).all(dim=1).cpu()
+    beyond = torch.zeros(N, dtype=torch.bool)
+    beyond[40:60] = True
+    assert torch.equal(bad, aten_bad | beyond)                       # the documented difference, and nothing else
+    assert torch.equal(hb[~bad.cuda()], base[~bad.cuda()])
