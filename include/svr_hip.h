@@ -252,7 +252,12 @@ int svr_linear_fwd_bf16x6(const float *X, int64_t ldx, const float *W, int64_t l
 /* Same result with the 3-product f16 split (x = hi + lo in f16: 22 mantissa bits; W normalised by a power of two,
  * lo terms kept normal by exact 2^11 scaling, see gemm_f16x3.hip): as accurate as an f32 GEMM (~3e-7 of f64) at
  * half the matrix-core work of bf16x6.  Domain: |X| < 65504 (f16 range).
- * workspace: svr_linear_fwd_f16x3_workspace(N, K) bytes.                                                  */
+ * workspace: svr_linear_fwd_f16x3_workspace(N, K) bytes.
+ * PREPARE / RUN (the four split-precision entry points svr_linear_fwd_f16x3, svr_linear_bwd_data_bf16x3,
+ * svr_conv3d_k3_fwd_f16x3, svr_conv3d_k3_bwd_data_bf16x3): with the data operand (X / dY / in / dout) NULL the call only
+ * prepares the workspace from W (scale + split planes: the launches that depend on the parameters alone); with W NULL it
+ * runs on a workspace an earlier call prepared.  A training step prepares every layer once, on a side stream, while the
+ * first kernels of the step run (model/ifnet.py), instead of 2-4 launch-bound kernels in front of every layer.         */
 int64_t svr_linear_fwd_f16x3_workspace(int64_t N, int64_t K);
 int svr_linear_fwd_f16x3(const float *X, int64_t ldx, const float *W, int64_t ldw, const float *bias,
                           float *Y, int64_t ldy, int64_t M, int64_t N, int64_t K, int epilogue,

@@ -334,15 +334,17 @@ extern "C" int64_t svr_conv3d_bwd_data_bf16x3_workspace(int32_t Ci, int32_t Co) 
 extern "C" int svr_conv3d_k3_bwd_data_bf16x3(const float *dout, const float *W, float *din, int32_t B, int32_t D, int32_t H,
                                              int32_t Wd, int32_t Ci, int32_t Co, int epilogue, const float *mask,
                                              void *workspace, void *stream) {
-  SVR_CHECK(dout && W && din && workspace, SVR_E_BADARG, "conv3d_bwd_data_bf16x3: null pointer");
-  SVR_CHECK(B > 0 && D > 0 && H > 0 && Wd > 0, SVR_E_BADSHAPE, "conv3d_bwd_data_bf16x3: empty volume");
+  // dout == NULL: PREPARE only (W -> split planes in the workspace);  W == NULL: RUN on a workspace prepared earlier
+  SVR_CHECK((dout || W) && (!dout || din) && workspace, SVR_E_BADARG, "conv3d_bwd_data_bf16x3: null pointer");
   SVR_CHECK(Co % 16 == 0 && Ci % 2 == 0 && Ci >= 2, SVR_E_UNSUPPORTED, "conv3d_bwd_data_bf16x3: need Co %% 16 == 0, Ci even (Ci=%d Co=%d)", Ci, Co);
-  SVR_CHECK(epilogue == SVR_EPI_NONE || (epilogue == SVR_EPI_MASK && mask), SVR_E_BADARG, "conv3d_bwd_data_bf16x3: epilogue %d", epilogue);
   hipStream_t s = (hipStream_t)stream;
   uint16_t *hi = (uint16_t *)(((uintptr_t)workspace + 15) & ~(uintptr_t)15);
   uint16_t *mid = hi + (size_t)27 * Ci * Co;
   // the transposed conv reads dOut (Co channels = its K) and writes Ci channels: planes [27][Ci][Co]
-  hipLaunchKernelGGL(pack_bwd_planes_kernel, dim3(cdiv(27 * Ci * (Co / 2), 256)), dim3(256), 0, s, W, hi, mid, Ci, Co);
+  if (W) hipLaunchKernelGGL(pack_bwd_planes_kernel, dim3(cdiv(27 * Ci * (Co / 2), 256)), dim3(256), 0, s, W, hi, mid, Ci, Co);
+  if (!dout) return launch_status("conv3d_bwd_data_bf16x3 (prepare)");
+  SVR_CHECK(B > 0 && D > 0 && H > 0 && Wd > 0, SVR_E_BADSHAPE, "conv3d_bwd_data_bf16x3: empty volume");
+  SVR_CHECK(epilogue == SVR_EPI_NONE || (epilogue == SVR_EPI_MASK && mask), SVR_E_BADARG, "conv3d_bwd_data_bf16x3: epilogue %d", epilogue);
   ConvShape sh{B, D, H, Wd, /*K=*/Co, /*NOUT=*/Ci};
   const int nbz = (int)cdiv(D, BRZ), nby = (int)cdiv(H, BRY), nbx = (int)cdiv(Wd, BRX);
   const unsigned bricks = (unsigned)((int64_t)B * nbz * nby * nbx);
@@ -400,18 +402,22 @@ extern "C" int64_t svr_conv3d_fwd_f16x3_workspace(int32_t Ci, int32_t Co) { retu
 extern "C" int svr_conv3d_k3_fwd_f16x3(const float *in, const float *W, const float *bias, float *out, int32_t B, int32_t D,
                                        int32_t H, int32_t Wd, int32_t Ci, int32_t Co, int epilogue, void *workspace,
                                        void *stream) {
-  SVR_CHECK(in && W && out && workspace, SVR_E_BADARG, "conv3d_fwd_f16x3: null pointer");
-  SVR_CHECK(B > 0 && D > 0 && H > 0 && Wd > 0, SVR_E_BADSHAPE, "conv3d_fwd_f16x3: empty volume");
+  // in == NULL: PREPARE only (W -> scale + split planes in the workspace);  W == NULL: RUN on a workspace prepared earlier
+  SVR_CHECK((in || W) && (!in || out) && workspace, SVR_E_BADARG, "conv3d_fwd_f16x3: null pointer");
   SVR_CHECK(Ci % 16 == 0 && Co >= 1, SVR_E_UNSUPPORTED, "conv3d_fwd_f16x3: need Ci %% 16 == 0 (Ci=%d Co=%d)", Ci, Co);
-  SVR_CHECK(epilogue == SVR_EPI_NONE || ((epilogue == SVR_EPI_BIAS || epilogue == SVR_EPI_BIAS_RELU) && bias), SVR_E_BADARG,
-            "conv3d_fwd_f16x3: epilogue %d", epilogue);
   hipStream_t s = (hipStream_t)stream;
   uint32_t *amax = (uint32_t *)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
   uint16_t *p0 = (uint16_t *)(amax + 64);
   const int64_t ps = (int64_t)27 * Ci * Co;
-  (void)hipMemsetAsync(amax, 0, sizeof(uint32_t), s);
-  hipLaunchKernelGGL(w_amax_kernel, dim3((unsigned)cdiv(ps, 1024)), dim3(256), 0, s, W, ps, (int64_t)1, ps, amax);
-  hipLaunchKernelGGL(pack_fwd_planes_f16_kernel, dim3(cdiv(27 * Co * (Ci / 2), 256)), dim3(256), 0, s, W, amax, p0, p0 + ps, Ci, Co);
+  if (W) {
+    (void)hipMemsetAsync(amax, 0, sizeof(uint32_t), s);
+    hipLaunchKernelGGL(w_amax_kernel, dim3((unsigned)cdiv(ps, 1024)), dim3(256), 0, s, W, ps, (int64_t)1, ps, amax);
+    hipLaunchKernelGGL(pack_fwd_planes_f16_kernel, dim3(cdiv(27 * Co * (Ci / 2), 256)), dim3(256), 0, s, W, amax, p0, p0 + ps, Ci, Co);
+  }
+  if (!in) return launch_status("conv3d_fwd_f16x3 (prepare)");
+  SVR_CHECK(B > 0 && D > 0 && H > 0 && Wd > 0, SVR_E_BADSHAPE, "conv3d_fwd_f16x3: empty volume");
+  SVR_CHECK(epilogue == SVR_EPI_NONE || ((epilogue == SVR_EPI_BIAS || epilogue == SVR_EPI_BIAS_RELU) && bias), SVR_E_BADARG,
+            "conv3d_fwd_f16x3: epilogue %d", epilogue);
   ConvShape sh{B, D, H, Wd, Ci, Co};
   const int nbz = (int)cdiv(D, BRZ), nby = (int)cdiv(H, BRY), nbx = (int)cdiv(Wd, BRX);
   const unsigned bricks = (unsigned)((int64_t)B * nbz * nby * nbx);

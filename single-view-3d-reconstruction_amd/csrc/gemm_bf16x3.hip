@@ -636,17 +636,19 @@ extern "C" int64_t svr_linear_bwd_data_bf16x3_workspace(int64_t N, int64_t K) { 
 extern "C" int svr_linear_bwd_data_bf16x3(const float *dY, int64_t lddy, const float *W, int64_t ldw, float *dX, int64_t lddx,
                                           int64_t M, int64_t N, int64_t K, int epilogue, const float *mask, int64_t ldmask,
                                           void *workspace, void *stream) {
-  if (M == 0) return SVR_OK;
-  SVR_CHECK(dY && W && dX && workspace, SVR_E_BADARG, "linear_bwd_data_bf16x3: null pointer");
-  SVR_CHECK(M >= 0 && N > 0 && K > 0 && N % XK == 0 && K % 4 == 0 && lddx % 4 == 0 && ldmask % 4 == 0, SVR_E_BADSHAPE,
-            "linear_bwd_data_bf16x3: M=%ld N=%ld K=%ld (need N %% 32 == 0, K and leading dims %% 4 == 0)", (long)M, (long)N, (long)K);
-  SVR_CHECK(lddy % 4 == 0 && ((uintptr_t)dY & 15) == 0, SVR_E_ALIGN, "linear_bwd_data_bf16x3: dY must be 16-byte aligned");
-  SVR_CHECK(epilogue == SVR_EPI_NONE || (epilogue == SVR_EPI_MASK && mask), SVR_E_BADARG, "linear_bwd_data_bf16x3: epilogue %d", epilogue);
-  if (M == 0) return SVR_OK;
+  // dY == NULL: PREPARE only (W -> split planes in the workspace);  W == NULL: RUN on a workspace prepared earlier
+  if (M == 0 && dY) return SVR_OK;
+  SVR_CHECK((dY || W) && (!dY || dX) && workspace, SVR_E_BADARG, "linear_bwd_data_bf16x3: null pointer");
+  SVR_CHECK(M >= 0 && N > 0 && K > 0 && N % XK == 0 && K % 4 == 0, SVR_E_BADSHAPE,
+            "linear_bwd_data_bf16x3: M=%ld N=%ld K=%ld (need N %% 32 == 0, K %% 4 == 0)", (long)M, (long)N, (long)K);
   hipStream_t s = (hipStream_t)stream;
   uint16_t *hi = (uint16_t *)(((uintptr_t)workspace + 15) & ~(uintptr_t)15);
   uint16_t *mid = hi + N * K;
-  hipLaunchKernelGGL(pack_planes_kernel, dim3((unsigned)cdiv(K * (N / 2), 256)), dim3(256), 0, s, W, ldw, hi, mid, N, K);
+  if (W) hipLaunchKernelGGL(pack_planes_kernel, dim3((unsigned)cdiv(K * (N / 2), 256)), dim3(256), 0, s, W, ldw, hi, mid, N, K);
+  if (!dY) return launch_status("linear_bwd_data_bf16x3 (prepare)");
+  SVR_CHECK(lddx % 4 == 0 && ldmask % 4 == 0, SVR_E_BADSHAPE, "linear_bwd_data_bf16x3: leading dimensions must be multiples of 4");
+  SVR_CHECK(lddy % 4 == 0 && ((uintptr_t)dY & 15) == 0, SVR_E_ALIGN, "linear_bwd_data_bf16x3: dY must be 16-byte aligned");
+  SVR_CHECK(epilogue == SVR_EPI_NONE || (epilogue == SVR_EPI_MASK && mask), SVR_E_BADARG, "linear_bwd_data_bf16x3: epilogue %d", epilogue);
   dim3 grid(xcd_grid(cdiv(K, NN_TN) * cdiv(M, NN_TM)));
   hipLaunchKernelGGL(linear_nn_x3_kernel, grid, dim3(256), 0, s, dY, lddy, hi, mid, dX, lddx,
                      epilogue == SVR_EPI_MASK ? mask : nullptr, ldmask, M, N, K);

@@ -220,18 +220,22 @@ extern "C" int64_t svr_linear_fwd_f16x3_workspace(int64_t N, int64_t K) { return
 extern "C" int svr_linear_fwd_f16x3(const float *X, int64_t ldx, const float *W, int64_t ldw, const float *bias, float *Y,
                                     int64_t ldy, int64_t M, int64_t N, int64_t K, int epilogue, void *workspace,
                                     void *stream) {
-  if (M == 0) return SVR_OK;  // empty point set
-  SVR_CHECK(X && W && Y && workspace, SVR_E_BADARG, "linear_fwd_f16x3: null pointer");
+  // X == NULL: PREPARE only (W -> scale + split planes in the workspace);  W == NULL: RUN on a workspace prepared earlier
+  if (M == 0 && X) return SVR_OK;  // empty point set
+  SVR_CHECK((X || W) && (!X || Y) && workspace, SVR_E_BADARG, "linear_fwd_f16x3: null pointer");
   SVR_CHECK(M >= 0 && N > 0 && K > 0 && K % YK == 0, SVR_E_BADSHAPE, "linear_fwd_f16x3: M=%ld N=%ld K=%ld (K %% 16)", (long)M, (long)N, (long)K);
-  SVR_CHECK(ldx % 4 == 0 && ((uintptr_t)X & 15) == 0, SVR_E_ALIGN, "linear_fwd_f16x3: X must be 16-byte aligned");
-  SVR_CHECK(epilogue == SVR_EPI_NONE || ((epilogue == SVR_EPI_BIAS || epilogue == SVR_EPI_BIAS_RELU) && bias), SVR_E_BADARG,
-            "linear_fwd_f16x3: epilogue %d", epilogue);
   hipStream_t s = (hipStream_t)stream;
   uint32_t *amax = (uint32_t *)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
   uint16_t *p0 = (uint16_t *)(amax + 64);
-  (void)hipMemsetAsync(amax, 0, sizeof(uint32_t), s);
-  hipLaunchKernelGGL(w_amax_kernel, dim3((unsigned)std::min<int64_t>(cdiv(N * K, 1024), 1024)), dim3(256), 0, s, W, ldw, N, K, amax);
-  hipLaunchKernelGGL(split_w_kernel, dim3((unsigned)cdiv(N * (K / 2), 256)), dim3(256), 0, s, W, ldw, amax, p0, N, K);
+  if (W) {
+    (void)hipMemsetAsync(amax, 0, sizeof(uint32_t), s);
+    hipLaunchKernelGGL(w_amax_kernel, dim3((unsigned)std::min<int64_t>(cdiv(N * K, 1024), 1024)), dim3(256), 0, s, W, ldw, N, K, amax);
+    hipLaunchKernelGGL(split_w_kernel, dim3((unsigned)cdiv(N * (K / 2), 256)), dim3(256), 0, s, W, ldw, amax, p0, N, K);
+  }
+  if (!X) return launch_status("linear_fwd_f16x3 (prepare)");
+  SVR_CHECK(ldx % 4 == 0 && ((uintptr_t)X & 15) == 0, SVR_E_ALIGN, "linear_fwd_f16x3: X must be 16-byte aligned");
+  SVR_CHECK(epilogue == SVR_EPI_NONE || ((epilogue == SVR_EPI_BIAS || epilogue == SVR_EPI_BIAS_RELU) && bias), SVR_E_BADARG,
+            "linear_fwd_f16x3: epilogue %d", epilogue);
   const float *eb = epilogue == SVR_EPI_NONE ? nullptr : bias;
   const int relu = epilogue == SVR_EPI_BIAS_RELU ? 1 : 0;
   // SCHED = 2 (one MFMA, a slice of the split, one LDS store, ...): 2.39 ms at 400 000 x 2592 x 256 against 2.49 for

@@ -177,6 +177,8 @@ OVERLAP_BACKWARD = os.environ.get("SVR_NO_BWD_OVERLAP") is None
 STAGE1_RECOMPUTE = os.environ.get("SVR_NO_STAGE1") is None
 # Training step: the Morton sort of the points runs on the side stream beside the encoder (SVR_SORT_ON_MAIN=1: in front of it)
 SORT_ON_SIDE_STREAM = os.environ.get("SVR_SORT_ON_MAIN") is None
+# ... and so do the parameter-only preparations of the split-precision layers (SVR_NO_WEIGHT_PREP=1: in front of every layer)
+PREPARE_WEIGHTS_AHEAD = os.environ.get("SVR_NO_WEIGHT_PREP") is None
 # The step's large cross-stream buffers live in a per-module StepArena (arena.py); SVR_NO_ARENA=1: ordinary allocations
 USE_ARENA = os.environ.get("SVR_NO_ARENA") is None
 
@@ -483,6 +485,8 @@ class _EncoderGatherFn(torch.autograd.Function):
             gx = (gx + gvols[0]).view(ctx.x_shape)
         if dw0p is None:
             dw0p = dw0_keep
+        ext._prepared.invalidate()      # the optimizer is about to change the parameters the planes were made from
+        ops.set_prepared(None)
         if lease is not None:
             lease.release()     # every kernel that touches the arena is enqueued; the next step orders itself behind them
         out = [None, None, None, None, dw0p, db0, gx, gpts]
@@ -592,6 +596,7 @@ class _ExtractorBase(nn.Module):
         chans = [1] + [convs[-1].out_channels for convs, _ in self._stages]
         self._layout = ops.FeatureLayout(chans)
         self._arena = StepArena()      # the step's large cross-stream buffers, allocated once (arena.py)
+        self._prepared = ops.PreparedWeights()   # split-precision weight planes of a step, prepared on the side stream
         self._param_list = []
         for convs, bn in self._stages:
             for c in convs:
@@ -727,6 +732,29 @@ class IFNet(nn.Module):
         return _PermuteColumnsFn.apply(self.fc_0.weight.squeeze(2), self._fc0_src, self._fc0_mask, self._fc0_inv)
 
     @torch.no_grad()
+    def _prepare_weights_async(self):
+        """Training step: the weight planes of every split-precision layer (encoder convolutions behind conv_in, fc_1,
+        fc_2; forward and backward-data forms) are made on the side stream, in front of the Morton sort, instead of in
+        2-4 launch-bound kernels in front of each layer call on the main stream (~40 launches per step).  Valid until
+        the encoder's backward has been enqueued; ops find them by the parameter's address (ops.PreparedWeights)."""
+        if not PREPARE_WEIGHTS_AHEAD:
+            return
+        ext = self.ifnet_feature_extractor
+        prep = ext._prepared
+        main, side = torch.cuda.current_stream(), _get_side_stream(self.fc_out.weight.device)
+        side.wait_stream(main)          # the optimizer step that produced these parameters
+        with torch.cuda.stream(side):
+            prep.begin()
+            for convs, _ in ext._stages:
+                for conv in convs:
+                    if conv.weight.shape[1] > 1:
+                        prep.add_conv(conv.weight.detach())
+            prep.add_linear(self.fc_1.weight.detach().squeeze(2))
+            prep.add_linear(self.fc_2.weight.detach().squeeze(2))
+            prep.finish(side)
+        ops.set_prepared(prep)
+
+    @torch.no_grad()
     def encode(self, x, storage="f32"):
         """Cache the feature pyramid of a grid for repeated queries (dense-grid inference).  storage="bf16": the
         throughput mode -- the pyramid (computed in f32) is stored in bf16 and query() runs the bf16-storage gather +
@@ -805,6 +833,7 @@ class IFNet(nn.Module):
         if spatial_sort and N > 1:
             pts = points.detach().float().contiguous()
             if arena is not None and SORT_ON_SIDE_STREAM and not os.environ.get("SVR_NO_SIDE_STREAM"):
+                self._prepare_weights_async()
                 # the Morton sort (a chain of ~25 launch-bound radix-sort kernels, 0.2 ms) is only needed by the gather and
                 # by the scatter plans: it runs on the side stream, in front of the plans, while the encoder starts on the
                 # main stream at once; the main stream waits for it in front of the gather (_EncoderGatherFn.forward).

@@ -481,6 +481,97 @@ def fc_out_fwd_bf16(h, w, b, row_map=None):
 FORWARD_GEMM = "f16x3"
 
 
+class PreparedWeights:
+    """Workspaces of the split-precision kernels, prepared AHEAD of the layer calls (include/svr_hip.h, PREPARE / RUN): the
+    launches that only depend on the parameters (amax, split planes: 2-4 launch-bound kernels per layer and pass) run once
+    per training step on a side stream instead of in front of every layer on the main stream.  Keyed by the parameter's
+    storage address; valid from finish() until invalidate() -- i.e. for one forward + backward; every lookup outside that
+    window, for a tensor that was not prepared, or for one that was modified in place since (its version counter moved), misses
+    and the op prepares its own workspace as before."""
+
+    def __init__(self):
+        self._ws = {}
+        self._valid = {}          # key -> the parameter's version counter when its planes were made
+        self.ready = None
+        self._waited = True
+
+    def _buf(self, key, nbytes, device):
+        t = self._ws.get(key)
+        if t is None or t.numel() < nbytes or t.device != device:
+            t = self._ws[key] = torch.empty(nbytes, device=device, dtype=torch.uint8)
+        return t
+
+    def begin(self):
+        self._valid.clear()
+
+    def add_conv(self, w):
+        """w (Co,Ci,3,3,3): forward (f16x3) and backward-data (bf16x3) planes, where those modes apply."""
+        _f32(w)
+        Co, Ci = w.shape[0], w.shape[1]
+        l = _lib.lib()
+        z = C.c_void_p(0)
+        if FORWARD_CONV == "f16x3" and Ci % 16 == 0:
+            ws = self._buf(("cf", w.data_ptr()), l.svr_conv3d_fwd_f16x3_workspace(Ci, Co), w.device)
+            check(l.svr_conv3d_k3_fwd_f16x3(z, _p(w), z, z, 0, 0, 0, 0, Ci, Co, EPI_NONE, _p(ws), _stream()), "conv3d_fwd_f16x3 prepare")
+            self._valid[("cf", w.data_ptr())] = w._version
+        if BACKWARD_CONV == "bf16x3" and Ci % 2 == 0 and Co % 16 == 0:
+            ws = self._buf(("cb", w.data_ptr()), l.svr_conv3d_bwd_data_bf16x3_workspace(Ci, Co), w.device)
+            check(l.svr_conv3d_k3_bwd_data_bf16x3(z, _p(w), z, 0, 0, 0, 0, Ci, Co, EPI_NONE, z, _p(ws), _stream()),
+                  "conv3d_bwd_data_bf16x3 prepare")
+            self._valid[("cb", w.data_ptr())] = w._version
+
+    def add_linear(self, w):
+        """w (N,K) row-major: forward (f16x3) and backward-data (bf16x3) planes, where those modes apply."""
+        _f32(w)
+        N, K = w.shape
+        assert w.stride(1) == 1
+        l = _lib.lib()
+        z = C.c_void_p(0)
+        if FORWARD_GEMM == "f16x3" and K % 16 == 0:
+            ws = self._buf(("lf", w.data_ptr()), l.svr_linear_fwd_f16x3_workspace(N, K), w.device)
+            check(l.svr_linear_fwd_f16x3(z, 0, C.c_void_p(w.data_ptr()), w.stride(0), z, z, 0, 0, N, K, EPI_NONE, _p(ws), _stream()),
+                  "linear_fwd_f16x3 prepare")
+            self._valid[("lf", w.data_ptr())] = w._version
+        if BACKWARD_GEMM == "bf16x3" and N % 32 == 0 and K % 4 == 0:
+            ws = self._buf(("lb", w.data_ptr()), l.svr_linear_bwd_data_bf16x3_workspace(N, K), w.device)
+            check(l.svr_linear_bwd_data_bf16x3(z, 0, C.c_void_p(w.data_ptr()), w.stride(0), z, 0, 0, N, K, EPI_NONE, z, 0, _p(ws),
+                                               _stream()), "linear_bwd_data_bf16x3 prepare")
+            self._valid[("lb", w.data_ptr())] = w._version
+
+    def finish(self, stream):
+        self.ready = torch.cuda.Event()
+        self.ready.record(stream)
+        self._waited = False
+
+    def invalidate(self):
+        self._valid.clear()
+
+    def lookup(self, kind, w):
+        """The prepared workspace of `w` for `kind` ("cf" / "cb" / "lf" / "lb"), or None.  The first hit of a step makes
+        the calling stream wait for the preparation (the step's later work on other streams is ordered behind it)."""
+        key = (kind, w.data_ptr())
+        if self._valid.get(key, -1) != w._version:      # not prepared, or modified in place since (an optimizer step)
+            return None
+        if not self._waited:
+            torch.cuda.current_stream().wait_event(self.ready)
+            self._waited = True
+        return self._ws[key]
+
+
+_prepared = None     # the PreparedWeights of the training step in flight (model/ifnet.py), or None
+
+
+def set_prepared(p):
+    global _prepared
+    _prepared = p
+
+
+def _lookup(kind, w, mode, default):
+    if _prepared is None or (mode is not None and mode != default):
+        return None
+    return _prepared.lookup(kind, w)
+
+
 def linear_fwd(x, w, bias, relu=True, out=None, mode=None):
     """y = [relu](x @ w.T + bias); x (M,K) row stride may exceed K (padded feature rows)."""
     _f32(x, w, bias)
@@ -492,8 +583,11 @@ def linear_fwd(x, w, bias, relu=True, out=None, mode=None):
     epi = EPI_NONE if bias is None else (EPI_BIAS_RELU if relu else EPI_BIAS)
     if (mode or FORWARD_GEMM) == "f16x3" and K % 16 == 0:
         l = _lib.lib()
-        ws = torch.empty(l.svr_linear_fwd_f16x3_workspace(N, K), device=x.device, dtype=torch.uint8)
-        check(l.svr_linear_fwd_f16x3(C.c_void_p(x.data_ptr()), x.stride(0), C.c_void_p(w.data_ptr()), w.stride(0), _p(bias),
+        ws = _lookup("lf", w, mode, "f16x3") if w.stride(0) == K else None
+        wptr = C.c_void_p(0) if ws is not None else C.c_void_p(w.data_ptr())      # W NULL: the workspace is prepared
+        if ws is None:
+            ws = torch.empty(l.svr_linear_fwd_f16x3_workspace(N, K), device=x.device, dtype=torch.uint8)
+        check(l.svr_linear_fwd_f16x3(C.c_void_p(x.data_ptr()), x.stride(0), wptr, w.stride(0), _p(bias),
                                      _p(out), out.stride(0), M, N, K, epi, _p(ws), _stream()), "linear_fwd_f16x3")
         return out
     if (mode or FORWARD_GEMM) == "bf16x6" and K % 16 == 0:
@@ -523,8 +617,11 @@ def linear_bwd_data(dy, w, mask=None, out=None, mode=None):
     epi = EPI_MASK if mask is not None else EPI_NONE
     if (mode or BACKWARD_GEMM) == "bf16x3" and N % 32 == 0:
         l = _lib.lib()
-        ws = torch.empty(l.svr_linear_bwd_data_bf16x3_workspace(N, K), device=dy.device, dtype=torch.uint8)
-        check(l.svr_linear_bwd_data_bf16x3(C.c_void_p(dy.data_ptr()), dy.stride(0), C.c_void_p(w.data_ptr()), w.stride(0),
+        ws = _lookup("lb", w, mode, "bf16x3") if (w.stride(0) == K and w.stride(1) == 1) else None
+        wptr = C.c_void_p(0) if ws is not None else C.c_void_p(w.data_ptr())      # W NULL: the workspace is prepared
+        if ws is None:
+            ws = torch.empty(l.svr_linear_bwd_data_bf16x3_workspace(N, K), device=dy.device, dtype=torch.uint8)
+        check(l.svr_linear_bwd_data_bf16x3(C.c_void_p(dy.data_ptr()), dy.stride(0), wptr, w.stride(0),
                                            C.c_void_p(out.data_ptr()), out.stride(0), M, N, K, epi,
                                            C.c_void_p(mask.data_ptr()) if mask is not None else C.c_void_p(0),
                                            mask.stride(0) if mask is not None else 0, _p(ws), _stream()),
@@ -641,8 +738,11 @@ def conv3d_k3_fwd(x, w, bias, relu=True, mode=None):
     if (mode or FORWARD_CONV) == "f16x3" and Ci % 16 == 0:
         l = _lib.lib()
         out = torch.empty(B, D, H, W, Co, device=x.device, dtype=torch.float32)
-        ws = torch.empty(l.svr_conv3d_fwd_f16x3_workspace(Ci, Co), device=x.device, dtype=torch.uint8)
-        check(l.svr_conv3d_k3_fwd_f16x3(_p(x), _p(w), _p(bias), _p(out), B, D, H, W, Ci, Co,
+        ws = _lookup("cf", w, mode, "f16x3")
+        wptr = C.c_void_p(0) if ws is not None else _p(w)                          # W NULL: the workspace is prepared
+        if ws is None:
+            ws = torch.empty(l.svr_conv3d_fwd_f16x3_workspace(Ci, Co), device=x.device, dtype=torch.uint8)
+        check(l.svr_conv3d_k3_fwd_f16x3(_p(x), wptr, _p(bias), _p(out), B, D, H, W, Ci, Co,
                                         EPI_BIAS_RELU if relu else EPI_BIAS, _p(ws), _stream()), "conv3d_fwd_f16x3")
         return out
     if (mode or FORWARD_CONV) == "bf16x6" and Ci % 16 == 0:
@@ -681,8 +781,11 @@ def conv3d_k3_bwd_data(dout, w, mask=None, mode=None):
     if (mode or BACKWARD_CONV) == "bf16x3" and Ci % 2 == 0 and Co % 16 == 0:
         l = _lib.lib()
         din = torch.empty(B, D, H, W, Ci, device=dout.device, dtype=torch.float32)
-        ws = torch.empty(l.svr_conv3d_bwd_data_bf16x3_workspace(Ci, Co), device=dout.device, dtype=torch.uint8)
-        check(l.svr_conv3d_k3_bwd_data_bf16x3(_p(dout), _p(w), _p(din), B, D, H, W, Ci, Co,
+        ws = _lookup("cb", w, mode, "bf16x3")
+        wptr = C.c_void_p(0) if ws is not None else _p(w)                          # W NULL: the workspace is prepared
+        if ws is None:
+            ws = torch.empty(l.svr_conv3d_bwd_data_bf16x3_workspace(Ci, Co), device=dout.device, dtype=torch.uint8)
+        check(l.svr_conv3d_k3_bwd_data_bf16x3(_p(dout), wptr, _p(din), B, D, H, W, Ci, Co,
                                               EPI_MASK if mask is not None else EPI_NONE, _p(mask), _p(ws), _stream()),
               "conv3d_bwd_data_bf16x3")
         return din
