@@ -349,6 +349,11 @@ int64_t svr_conv3d_k3_bwd_weight_bf16x3_workspace(int32_t B, int32_t D, int32_t 
 int svr_conv3d_k3_bwd_weight_bf16x3(const float *in, const float *dout, float *dWp, float *db, int32_t B,
                                     int32_t D, int32_t H, int32_t W, int32_t Ci, int32_t Co,
                                     void *workspace, void *stream);
+/* The same, written straight in the parameter's layout dW(Co,Ci,3,3,3) (autograd's layout of nn.Conv3d.weight.grad):
+ * the slab reduction, the layout change and the bias-gradient reduction are one launch.                          */
+int svr_conv3d_k3_bwd_weight_bf16x3_param(const float *in, const float *dout, float *dW, float *db, int32_t B,
+                                          int32_t D, int32_t H, int32_t W, int32_t Ci, int32_t Co,
+                                          void *workspace, void *stream);
 
 /* ---------------------------------------------------------------------------------------
  * BatchNorm3d (training or eval) + MaxPool3d(2), channels-last
@@ -359,6 +364,10 @@ int svr_conv3d_k3_bwd_weight_bf16x3(const float *in, const float *dout, float *d
 int64_t svr_bn_stats_workspace(int64_t rows, int32_t C);
 int svr_bn_stats(const float *x, double *stats, int64_t rows /*B*D*H*W*/, int32_t C,
                  void *workspace, void *stream);
+/* svr_bn_stats followed by svr_bn_finalize(training = 1) in two launches instead of three (stats may be NULL).      */
+int svr_bn_stats_finalize(const float *x, double *stats, const float *gamma, const float *beta, float *running_mean,
+                          float *running_var, float *scale_shift, float *mean_f32, int64_t rows, int32_t C,
+                          float eps, float momentum, void *workspace, void *stream);
 /* scale_shift[0:C] = gamma*invstd, [C:2C] = beta - mean*gamma*invstd, [2C:3C] = invstd (f32);
  * training != 0 also updates running_mean/var (momentum, unbiased var) like torch.          */
 int svr_bn_finalize(const double *stats, const float *gamma, const float *beta, float *running_mean,
@@ -396,7 +405,8 @@ int svr_bn_bwd_apply(const float *x, const float *dy, const float *dpooled, cons
  *                    statistics updated like torch), else the running statistics; outputs as svr_bn_finalize +
  *                    svr_bn_apply_pool (scale_shift 3 x 16, mean_f32 16, y, pooled / argmax may be NULL).
  *   svr_stage1_bwd:  dy_total = dy (may be NULL) + unpool(dpooled via argmax) (may be NULL); sums (float64, 2 x 16) =
- *                    sum dy_total, sum dy_total*xhat; dgamma, dbeta; dWp[27][16] and db[16] of conv_in; dout (may be NULL)
+ *                    sum dy_total, sum dy_total*xhat; dgamma, dbeta; dW(16,1,3,3,3) (the PARAMETER's layout) and db[16]
+ *                    (may be NULL) of conv_in; dout (may be NULL)
  *                    = d(loss)/d(conv_in output) for a caller that needs d(loss)/d(x).  relu_mask as svr_bn_bwd_apply.
  *   workspace: svr_stage1_workspace(B, D, H, W) bytes.  Wp = svr_conv3d_pack_weight's Wp_fwd ([27][1][16]).          */
 int32_t svr_stage1_supported(int32_t B, int32_t D, int32_t H, int32_t W, int32_t Co);
@@ -407,7 +417,7 @@ int svr_stage1_fwd(const float *x, const float *Wp, const float *bias, const flo
                    int32_t Co, float eps, float momentum, int training, void *workspace, void *stream);
 int svr_stage1_bwd(const float *x, const float *Wp, const float *bias, const float *dy, const float *dpooled,
                    const uint8_t *argmax, const float *mean_f32, const float *scale_shift, double *sums,
-                   float *dgamma, float *dbeta, float *dWp, float *db, float *dout, int32_t B, int32_t D,
+                   float *dgamma, float *dbeta, float *dW, float *db, float *dout, int32_t B, int32_t D,
                    int32_t H, int32_t W, int32_t Co, int relu_mask, void *workspace, void *stream);
 
 /* ---------------------------------------------------------------------------------------

@@ -99,8 +99,10 @@ SIGNATURES = {
     "svr_conv3d_k3_bwd_weight": (C.c_int, [P, P, P, P, I32, I32, I32, I32, I32, I32, P, P]),
     "svr_conv3d_k3_bwd_weight_bf16x3_workspace": (I64, [I32, I32, I32, I32, I32, I32]),
     "svr_conv3d_k3_bwd_weight_bf16x3": (C.c_int, [P, P, P, P, I32, I32, I32, I32, I32, I32, P, P]),
+    "svr_conv3d_k3_bwd_weight_bf16x3_param": (C.c_int, [P, P, P, P, I32, I32, I32, I32, I32, I32, P, P]),
     "svr_bn_stats_workspace": (I64, [I64, I32]),
     "svr_bn_stats": (C.c_int, [P, P, I64, I32, P, P]),
+    "svr_bn_stats_finalize": (C.c_int, [P, P, P, P, P, P, P, P, I64, I32, F32, F32, P, P]),
     "svr_bn_finalize": (C.c_int, [P, P, P, P, P, P, P, I64, I32, F32, F32, C.c_int, P]),
     "svr_bn_apply_pool": (C.c_int, [P, P, P, P, P, I32, I32, I32, I32, I32, P]),
     "svr_bn_bwd_reduce": (C.c_int, [P, P, P, P, P, P, P, I32, I32, I32, I32, I32, P, P]),

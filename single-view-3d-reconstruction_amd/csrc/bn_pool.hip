@@ -66,9 +66,35 @@ __global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float *__re
   }
 }
 
-// one workgroup per channel: f64 tree over the block partials (fixed order)
+// what svr_bn_finalize computes for one channel from (mean, biased variance): running statistics (training), scale / shift /
+// invstd, the f32 mean
+struct BnFinalize {
+  const float *gamma, *beta;
+  float *rmean, *rvar, *ss, *mean_f32;   // ss == nullptr: nothing to finalize
+  float eps, momentum;
+};
+__device__ __forceinline__ void bn_finalize_channel(const BnFinalize &f, int c, int C, double mean, double var, int64_t rows,
+                                                    int training) {
+  if (training) {
+    if (f.rmean) f.rmean[c] = (float)((1.0 - (double)f.momentum) * (double)f.rmean[c] + (double)f.momentum * mean);
+    if (f.rvar) {
+      double unb = rows > 1 ? var * (double)rows / (double)(rows - 1) : var;
+      f.rvar[c] = (float)((1.0 - (double)f.momentum) * (double)f.rvar[c] + (double)f.momentum * unb);
+    }
+  }
+  double invstd = 1.0 / sqrt(var + (double)f.eps);
+  float g = f.gamma ? f.gamma[c] : 1.f, b = f.beta ? f.beta[c] : 0.f;
+  float scale = (float)invstd * g;
+  f.ss[c] = scale;
+  f.ss[C + c] = b - (float)mean * scale;
+  f.ss[2 * C + c] = (float)invstd;
+  f.mean_f32[c] = (float)mean;
+}
+
+// one workgroup per channel: f64 tree over the block partials (fixed order); with fin.ss the same thread also does
+// svr_bn_finalize's work for its channel (training mode), one launch instead of two
 __global__ __launch_bounds__(256) void bn_stats_final_kernel(const double *__restrict__ part, double *__restrict__ stats,
-                                                             int64_t rows, int C, int blocks) {
+                                                             int64_t rows, int C, int blocks, BnFinalize fin) {
   const int c = blockIdx.x;
   double s = 0, ss = 0;
   for (int b = threadIdx.x; b < blocks; b += 256) { s += part[(int64_t)b * 2 * C + c]; ss += part[(int64_t)b * 2 * C + C + c]; }
@@ -82,37 +108,24 @@ __global__ __launch_bounds__(256) void bn_stats_final_kernel(const double *__res
   if (threadIdx.x == 0) {
     double mean = r1[0] / (double)rows;
     double var = r2[0] / (double)rows - mean * mean;
-    stats[c] = mean;
-    stats[C + c] = var > 0 ? var : 0;
+    var = var > 0 ? var : 0;
+    if (stats) { stats[c] = mean; stats[C + c] = var; }
+    if (fin.ss) bn_finalize_channel(fin, c, C, mean, var, rows, 1);
   }
 }
 
-__global__ void bn_finalize_kernel(const double *__restrict__ stats, const float *__restrict__ gamma,
-                                   const float *__restrict__ beta, float *__restrict__ rmean, float *__restrict__ rvar,
-                                   float *__restrict__ ss, float *__restrict__ mean_f32, int64_t rows, int C, float eps,
-                                   float momentum, int training) {
+__global__ void bn_finalize_kernel(const double *__restrict__ stats, BnFinalize fin, int64_t rows, int C, int training) {
   int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   double mean, var;
   if (training) {
     mean = stats[c];
     var = stats[C + c];
-    if (rmean) rmean[c] = (float)((1.0 - (double)momentum) * (double)rmean[c] + (double)momentum * mean);
-    if (rvar) {
-      double unb = rows > 1 ? var * (double)rows / (double)(rows - 1) : var;
-      rvar[c] = (float)((1.0 - (double)momentum) * (double)rvar[c] + (double)momentum * unb);
-    }
   } else {
-    mean = (double)rmean[c];
-    var = (double)rvar[c];
+    mean = (double)fin.rmean[c];
+    var = (double)fin.rvar[c];
   }
-  double invstd = 1.0 / sqrt(var + (double)eps);
-  float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
-  float scale = (float)invstd * g;
-  ss[c] = scale;
-  ss[C + c] = b - (float)mean * scale;
-  ss[2 * C + c] = (float)invstd;
-  mean_f32[c] = (float)mean;
+  bn_finalize_channel(fin, c, C, mean, var, rows, training);
 }
 
 // ---------------------------------------------------------------- apply + pool
@@ -192,7 +205,12 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(const float *__restrict__ x
                                                      const uint8_t *__restrict__ argmax,
                                                      const float *__restrict__ mean, const float *__restrict__ ss,
                                                      const double *__restrict__ sums, double *__restrict__ part,
-                                                     float *__restrict__ dx, Vol v, int64_t cells, int relu_mask) {
+                                                     float *__restrict__ dx, Vol v, int64_t cells, int relu_mask,
+                                                     float *__restrict__ dgamma, float *__restrict__ dbeta) {
+  if (APPLY && blockIdx.x == 0 && (int)threadIdx.x < v.C) {   // dgamma = sum dy*xhat, dbeta = sum dy (no extra launch)
+    if (dbeta) dbeta[threadIdx.x] = (float)sums[threadIdx.x];
+    if (dgamma) dgamma[threadIdx.x] = (float)sums[v.C + threadIdx.x];
+  }
   const int Q = v.C / 4;
   const int q = threadIdx.x % Q, cl = threadIdx.x / Q, CL = 256 / Q;
   const int Dc = (v.D + 1) / 2, Hc = (v.H + 1) / 2, Wc = (v.W + 1) / 2;
@@ -311,14 +329,6 @@ __global__ __launch_bounds__(256) void sum_parts_kernel(const double *__restrict
   if (threadIdx.x == 0) out[c] = red[0];
 }
 
-__global__ void bn_param_grads_kernel(const double *__restrict__ sums, float *__restrict__ dgamma,
-                                      float *__restrict__ dbeta, int C) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  if (dbeta) dbeta[c] = (float)sums[c];
-  if (dgamma) dgamma[c] = (float)sums[C + c];
-}
-
 int check_c(int C) {
   SVR_CHECK(C >= 4 && C <= 256 && C % 4 == 0 && 256 % (C / 4) == 0, SVR_E_UNSUPPORTED, "bn: C=%d (need 4 | C, C/4 | 256)", C);
   return SVR_OK;
@@ -344,7 +354,14 @@ int bwd_blocks(int64_t cells, int C) {
 namespace svr {
 // mean / biased variance from per-block partial sums [blocks][2C] (f64): shared with conv3d.hip's fused conv_in forward
 void bn_stats_final_launch(const double *part, double *stats, int64_t rows, int C, int blocks, hipStream_t s) {
-  hipLaunchKernelGGL(bn_stats_final_kernel, dim3(C), dim3(256), 0, s, part, stats, rows, C, blocks);
+  hipLaunchKernelGGL(bn_stats_final_kernel, dim3(C), dim3(256), 0, s, part, stats, rows, C, blocks, BnFinalize{});
+}
+// ... the same + svr_bn_finalize(training = 1) in ONE launch (stats may be null): shared with stage1.hip
+void bn_stats_finalize_launch(const double *part, double *stats, int64_t rows, int C, int blocks, const float *gamma,
+                              const float *beta, float *rmean, float *rvar, float *ss, float *mean_f32, float eps, float momentum,
+                              hipStream_t s) {
+  hipLaunchKernelGGL(bn_stats_final_kernel, dim3(C), dim3(256), 0, s, part, stats, rows, C, blocks,
+                     BnFinalize{gamma, beta, rmean, rvar, ss, mean_f32, eps, momentum});
 }
 // out[c] = ordered f64 sum over `blocks` partial rows [blocks][cols]: shared with stage1.hip's backward reduction
 void bn_sum_parts_launch(const double *part, double *out, int cols, int blocks, hipStream_t s) {
@@ -364,16 +381,31 @@ extern "C" int svr_bn_stats(const float *x, double *stats, int64_t rows, int32_t
   int64_t rpb;
   int blocks = stats_blocks(rows, &rpb);
   hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(blocks), dim3(256), 0, s, x, (double *)workspace, rows, C, rpb);
-  hipLaunchKernelGGL(bn_stats_final_kernel, dim3(C), dim3(256), 0, s, (const double *)workspace, stats, rows, C, blocks);
+  hipLaunchKernelGGL(bn_stats_final_kernel, dim3(C), dim3(256), 0, s, (const double *)workspace, stats, rows, C, blocks, BnFinalize{});
   return launch_status("bn_stats");
+}
+
+// svr_bn_stats + svr_bn_finalize(training = 1) as two launches instead of three (the per-channel tree also finalizes)
+extern "C" int svr_bn_stats_finalize(const float *x, double *stats, const float *gamma, const float *beta, float *running_mean,
+                                     float *running_var, float *scale_shift, float *mean_f32, int64_t rows, int32_t C, float eps,
+                                     float momentum, void *workspace, void *stream) {
+  if (int rc = check_c(C)) return rc;
+  SVR_CHECK(x && scale_shift && mean_f32 && workspace && rows > 0, SVR_E_BADARG, "bn_stats_finalize: bad argument");
+  hipStream_t s = (hipStream_t)stream;
+  int64_t rpb;
+  int blocks = stats_blocks(rows, &rpb);
+  hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(blocks), dim3(256), 0, s, x, (double *)workspace, rows, C, rpb);
+  bn_stats_finalize_launch((const double *)workspace, stats, rows, C, blocks, gamma, beta, running_mean, running_var, scale_shift,
+                           mean_f32, eps, momentum, s);
+  return launch_status("bn_stats_finalize");
 }
 
 extern "C" int svr_bn_finalize(const double *stats, const float *gamma, const float *beta, float *running_mean,
                                float *running_var, float *scale_shift, float *mean_f32, int64_t rows, int32_t C, float eps,
                                float momentum, int training, void *stream) {
   SVR_CHECK(scale_shift && mean_f32 && (training ? stats != nullptr : (running_mean && running_var)), SVR_E_BADARG, "bn_finalize: bad argument");
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 64)), dim3(64), 0, (hipStream_t)stream, stats, gamma, beta,
-                     running_mean, running_var, scale_shift, mean_f32, rows, C, eps, momentum, training);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 64)), dim3(64), 0, (hipStream_t)stream, stats,
+                     BnFinalize{gamma, beta, running_mean, running_var, scale_shift, mean_f32, eps, momentum}, rows, C, training);
   return launch_status("bn_finalize");
 }
 
@@ -402,7 +434,7 @@ extern "C" int svr_bn_bwd_reduce(const float *x, const float *dy, const float *d
   SVR_CHECK(cells < (1LL << 32), SVR_E_UNSUPPORTED, "bn_bwd: %ld cells (32-bit index arithmetic)", (long)cells);
   int blocks = bwd_blocks(cells, C);
   hipLaunchKernelGGL(bn_bwd_kernel<false>, dim3(blocks), dim3(256), 0, s, x, dy, dpooled, argmax, mean_f32, scale_shift,
-                     (const double *)nullptr, (double *)workspace, (float *)nullptr, v, cells, 0);
+                     (const double *)nullptr, (double *)workspace, (float *)nullptr, v, cells, 0, (float *)nullptr, (float *)nullptr);
   hipLaunchKernelGGL(sum_parts_kernel, dim3(2 * C), dim3(256), 0, s, (const double *)workspace, sums, 2 * C, blocks);
   return launch_status("bn_bwd_reduce");
 }
@@ -423,8 +455,6 @@ extern "C" int svr_bn_bwd_apply(const float *x, const float *dy, const float *dp
   int64_t blocks = cdiv(cells, CL);
   if (blocks > 65535 * 16) blocks = 65535 * 16;
   hipLaunchKernelGGL(bn_bwd_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, x, dy, dpooled, argmax, mean_f32,
-                     scale_shift, sums, (double *)nullptr, dx, v, cells, relu_mask);
-  if (dgamma || dbeta)
-    hipLaunchKernelGGL(bn_param_grads_kernel, dim3(cdiv(C, 64)), dim3(64), 0, s, sums, dgamma, dbeta, C);
+                     scale_shift, sums, (double *)nullptr, dx, v, cells, relu_mask, dgamma, dbeta);
   return launch_status("bn_bwd_apply");
 }

@@ -399,17 +399,36 @@ __global__ __launch_bounds__(256) void conv3d_brick_kernel(const float *__restri
   }
 }
 
-// dWp = ordered f64 sum of the workgroup slabs: 64 outputs x 4 part lanes per workgroup
+// dWp = ordered f64 sum of the workgroup slabs: 64 outputs x 4 part lanes per workgroup.  param_layout: the sums go
+// straight into the parameter's layout (Co,Ci,3,3,3) instead of [tap][ci][co] (no separate unpack launch).  Workgroups
+// past the weight's (blockIdx.x >= wblocks) reduce the bias-gradient partials dbpart [dbparts][Co] -> db instead: the
+// whole post-processing of a weight gradient is ONE launch (it was three launch-bound kernels per layer on the main stream).
 __global__ __launch_bounds__(256) void conv3d_bwd_weight_reduce_kernel(const float *__restrict__ slab,
                                                                        float *__restrict__ dWp, int Ci, int Co,
-                                                                       int ci_tiles, int co_tiles, int parts) {
+                                                                       int ci_tiles, int co_tiles, int parts,
+                                                                       int param_layout, int wblocks,
+                                                                       const float *__restrict__ dbpart,
+                                                                       float *__restrict__ db, int dbparts) {
+  __shared__ double red[256];
+  if ((int)blockIdx.x >= wblocks) {   // bias gradient of output channel co: ordered f64 tree over the partials
+    const int co = blockIdx.x - wblocks;
+    double sum = 0.0;
+    for (int p = threadIdx.x; p < dbparts; p += 256) sum += (double)dbpart[(int64_t)p * Co + co];
+    red[threadIdx.x] = sum;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) db[co] = (float)red[0];
+    return;
+  }
   const int per = 27 * ci_tiles * co_tiles * 1024;  // [tap][tile][32][32]
   const int idx = blockIdx.x * 64 + (threadIdx.x & 63);
   const int pl = threadIdx.x >> 6;
   double sum = 0.0;
   if (idx < per)
     for (int p = pl; p < parts; p += 4) sum += (double)slab[(int64_t)p * per + idx];
-  __shared__ double red[256];
   red[threadIdx.x] = sum;
   __syncthreads();
   if (pl == 0 && idx < per) {
@@ -417,7 +436,10 @@ __global__ __launch_bounds__(256) void conv3d_bwd_weight_reduce_kernel(const flo
     const int j = idx & 31, i = (idx >> 5) & 31;
     const int tile = (idx >> 10) % (ci_tiles * co_tiles), tap = idx / (1024 * ci_tiles * co_tiles);
     const int ci = (tile / co_tiles) * 32 + i, co = (tile % co_tiles) * 32 + j;
-    if (ci < Ci && co < Co) dWp[((size_t)tap * Ci + ci) * Co + co] = (float)tot;
+    if (ci < Ci && co < Co) {
+      if (param_layout) dWp[((size_t)co * Ci + ci) * 27 + tap] = (float)tot;
+      else dWp[((size_t)tap * Ci + ci) * Co + co] = (float)tot;
+    }
   }
 }
 
@@ -681,11 +703,19 @@ __global__ void conv3d_db_reduce_kernel(const float *__restrict__ dbpart, float 
 }
 
 // one workgroup per (tap, co): f64 tree over the per-wave partial slabs (fixed order)
+// (param_layout: dW(Co,1,3,3,3) instead of [tap][co]; workgroups >= 27 Co reduce the bias-gradient partials dbpart [parts][Co])
 __global__ __launch_bounds__(256) void conv3d_c1_bwd_weight_reduce_kernel(const float *__restrict__ slab,
-                                                                          float *__restrict__ dWp, int Co, int parts) {
+                                                                          float *__restrict__ dWp, int Co, int parts,
+                                                                          int param_layout, const float *__restrict__ dbpart,
+                                                                          float *__restrict__ db) {
+  const bool bias = (int)blockIdx.x >= 27 * Co;
   const int tap = blockIdx.x / Co, co = blockIdx.x % Co;
   double sum = 0.0;
-  for (int p = threadIdx.x; p < parts; p += 256) sum += (double)slab[(int64_t)p * 1024 + tap * 32 + co];
+  if (bias) {
+    for (int p = threadIdx.x; p < parts; p += 256) sum += (double)dbpart[(int64_t)p * Co + co];
+  } else {
+    for (int p = threadIdx.x; p < parts; p += 256) sum += (double)slab[(int64_t)p * 1024 + tap * 32 + co];
+  }
   __shared__ double red[256];
   red[threadIdx.x] = sum;
   __syncthreads();
@@ -693,7 +723,10 @@ __global__ __launch_bounds__(256) void conv3d_c1_bwd_weight_reduce_kernel(const 
     if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
     __syncthreads();
   }
-  if (threadIdx.x == 0) dWp[tap * Co + co] = (float)red[0];
+  if (threadIdx.x == 0) {
+    if (bias) db[co] = (float)red[0];
+    else dWp[param_layout ? co * 27 + tap : tap * Co + co] = (float)red[0];
+  }
 }
 
 // workgroups (= partial slabs) per channel-tile pair of the brick backward-weight kernel: ~2 per CU in total
@@ -716,16 +749,17 @@ int check_shape(int B, int D, int H, int W, int Ci, int Co) {
 namespace svr {
 // shared with conv3d_bwdw_bf16.hip: dWp = ordered f64 sum of `parts` slabs [part][tap][tile][32][32]
 void conv3d_bwd_weight_reduce_launch(const float *slab, float *dWp, int Ci, int Co, int cit, int cot, int parts,
-                                     hipStream_t s) {
+                                     hipStream_t s, int param_layout, const float *dbpart, float *db, int dbparts) {
   const int per = 27 * cit * cot * 1024;
-  hipLaunchKernelGGL(conv3d_bwd_weight_reduce_kernel, dim3(cdiv(per, 64)), dim3(256), 0, s, slab, dWp, Ci, Co, cit, cot, parts);
+  const int wblocks = (int)cdiv(per, 64);
+  hipLaunchKernelGGL(conv3d_bwd_weight_reduce_kernel, dim3(wblocks + (db ? Co : 0)), dim3(256), 0, s, slab, dWp, Ci, Co, cit, cot,
+                     parts, param_layout, wblocks, dbpart, db, dbparts);
 }
 // shared with stage1.hip: conv_in's dWp[tap][co] / db[co] = ordered f64 sums of per-workgroup slabs [part][32 taps][32] / [part][Co]
-void conv3d_c1_wgrad_reduce_launch(const float *slab, float *dWp, int Co, int parts, hipStream_t s) {
-  hipLaunchKernelGGL(conv3d_c1_bwd_weight_reduce_kernel, dim3(27 * Co), dim3(256), 0, s, slab, dWp, Co, parts);
-}
-void conv3d_db_reduce_launch(const float *dbpart, float *db, int Co, int parts, hipStream_t s) {
-  hipLaunchKernelGGL(conv3d_db_reduce_kernel, dim3(Co), dim3(256), 0, s, dbpart, db, Co, parts);
+void conv3d_c1_wgrad_reduce_launch(const float *slab, float *dWp, int Co, int parts, int param_layout, const float *dbpart,
+                                   float *db, hipStream_t s) {
+  hipLaunchKernelGGL(conv3d_c1_bwd_weight_reduce_kernel, dim3(27 * Co + (db ? Co : 0)), dim3(256), 0, s, slab, dWp, Co, parts,
+                     param_layout, dbpart, db);
 }
 }  // namespace svr
 
@@ -833,7 +867,8 @@ extern "C" int svr_conv3d_k3_bwd_weight(const float *in, const float *dout, floa
       }
     } else
       hipLaunchKernelGGL(conv3d_c1_bwd_weight_kernel, dim3(chunks), dim3(256), 0, s, in, dout, slab, sh);
-    hipLaunchKernelGGL(conv3d_c1_bwd_weight_reduce_kernel, dim3(27 * Co), dim3(256), 0, s, slab, dWp, Co, parts);
+    hipLaunchKernelGGL(conv3d_c1_bwd_weight_reduce_kernel, dim3(27 * Co), dim3(256), 0, s, slab, dWp, Co, parts, 0,
+                       (const float *)nullptr, (float *)nullptr);
     slab_floats = (int64_t)parts * 1024;
   } else {
     SVR_CHECK(Ci % 4 == 0 && Co % 4 == 0, SVR_E_UNSUPPORTED, "conv3d_bwd_weight: need Ci, Co %% 4 == 0 (Ci=%d Co=%d)", Ci, Co);
@@ -843,7 +878,8 @@ extern "C" int svr_conv3d_k3_bwd_weight(const float *in, const float *dout, floa
     dim3 grid((unsigned)parts, (unsigned)(cit * cot));
     hipLaunchKernelGGL(conv3d_bwd_weight_brick_kernel, grid, dim3(256), 0, s, in, dout, slab, sh, nbz, nby, nbx, cot);
     int per = 27 * cit * cot * 1024;
-    hipLaunchKernelGGL(conv3d_bwd_weight_reduce_kernel, dim3(cdiv(per, 64)), dim3(256), 0, s, slab, dWp, Ci, Co, cit, cot, parts);
+    hipLaunchKernelGGL(conv3d_bwd_weight_reduce_kernel, dim3(cdiv(per, 64)), dim3(256), 0, s, slab, dWp, Ci, Co, cit, cot, parts,
+                       0, (int)cdiv(per, 64), (const float *)nullptr, (float *)nullptr, 0);
     slab_floats = (int64_t)parts * per;
   }
   if (db) colsum_launch(dout, Co, db, slab + slab_floats, nrows * W, Co, s);

@@ -22,7 +22,7 @@ namespace svr {
 void colsum_launch(const float *Y, int64_t ldy, float *out, float *part, int64_t M, int64_t N, hipStream_t s);
 int64_t colsum_workspace_floats(int64_t M, int64_t N);
 void conv3d_bwd_weight_reduce_launch(const float *slab, float *dWp, int Ci, int Co, int cit, int cot, int parts,
-                                     hipStream_t s);
+                                     hipStream_t s, int param_layout, const float *dbpart, float *db, int dbparts);
 }  // namespace svr
 
 using namespace svr;
@@ -288,9 +288,28 @@ extern "C" int64_t svr_conv3d_k3_bwd_weight_bf16x3_workspace(int32_t B, int32_t 
   return (parts * 2 * 27 * tiles * 1024 + parts * Co) * (int64_t)sizeof(float);
 }
 
+namespace {
+int bwd_weight_x3(const float *in, const float *dout, float *dWp, float *db, int32_t B, int32_t D, int32_t H, int32_t W, int32_t Ci,
+                  int32_t Co, void *workspace, void *stream, int param_layout);
+}
+
 extern "C" int svr_conv3d_k3_bwd_weight_bf16x3(const float *in, const float *dout, float *dWp, float *db, int32_t B,
                                                int32_t D, int32_t H, int32_t W, int32_t Ci, int32_t Co, void *workspace,
                                                void *stream) {
+  return bwd_weight_x3(in, dout, dWp, db, B, D, H, W, Ci, Co, workspace, stream, 0);
+}
+
+// The same gradient written straight in the PARAMETER's layout dW(Co,Ci,3,3,3) (what autograd of nn.Conv3d returns):
+// no svr_conv3d_unpack_wgrad launch behind it.
+extern "C" int svr_conv3d_k3_bwd_weight_bf16x3_param(const float *in, const float *dout, float *dW, float *db, int32_t B,
+                                                     int32_t D, int32_t H, int32_t W, int32_t Ci, int32_t Co, void *workspace,
+                                                     void *stream) {
+  return bwd_weight_x3(in, dout, dW, db, B, D, H, W, Ci, Co, workspace, stream, 1);
+}
+
+namespace {
+int bwd_weight_x3(const float *in, const float *dout, float *dWp, float *db, int32_t B, int32_t D, int32_t H, int32_t W, int32_t Ci,
+                  int32_t Co, void *workspace, void *stream, int param_layout) {
   SVR_CHECK(B > 0 && D > 0 && H > 0 && W > 0, SVR_E_BADSHAPE, "conv3d_bwd_weight_bf16x3: empty volume %dx%dx%dx%d", B, D, H, W);
   SVR_CHECK(in && dout && dWp && workspace, SVR_E_BADARG, "conv3d_bwd_weight_bf16x3: null pointer");
   SVR_CHECK(Ci >= 4 && Ci % 4 == 0 && Co % 4 == 0 && Co >= 4, SVR_E_UNSUPPORTED,
@@ -305,7 +324,8 @@ extern "C" int svr_conv3d_k3_bwd_weight_bf16x3(const float *in, const float *dou
   float *dbpart = db ? slab + (int64_t)parts * 2 * 27 * cit * cot * 1024 : nullptr;
   hipLaunchKernelGGL(conv3d_bwd_weight_x3_kernel, dim3((unsigned)parts, (unsigned)(cit * cot)), dim3(NT), 0, s, in, dout,
                      slab, sh, nbz, nby, nbx, cot, dbpart);
-  conv3d_bwd_weight_reduce_launch(slab, dWp, Ci, Co, cit, cot, parts * 2, s);
-  if (db) hipLaunchKernelGGL(db_reduce_kernel, dim3((unsigned)Co), dim3(256), 0, s, dbpart, db, Co, parts);
+  // one launch: slabs -> dW (either layout) and, in its last Co workgroups, the bias-gradient partials -> db
+  conv3d_bwd_weight_reduce_launch(slab, dWp, Ci, Co, cit, cot, parts * 2, s, param_layout, dbpart, db, parts);
   return launch_status("conv3d_bwd_weight_bf16x3");
 }
+}  // namespace

@@ -34,11 +34,13 @@ using namespace svr;
 
 namespace svr {
 // bn_pool.hip
-void bn_stats_final_launch(const double *part, double *stats, int64_t rows, int C, int blocks, hipStream_t s);
+void bn_stats_finalize_launch(const double *part, double *stats, int64_t rows, int C, int blocks, const float *gamma,
+                              const float *beta, float *rmean, float *rvar, float *ss, float *mean_f32, float eps, float momentum,
+                              hipStream_t s);
 void bn_sum_parts_launch(const double *part, double *out, int cols, int blocks, hipStream_t s);
 // conv3d.hip
-void conv3d_c1_wgrad_reduce_launch(const float *slab, float *dWp, int Co, int parts, hipStream_t s);
-void conv3d_db_reduce_launch(const float *dbpart, float *db, int Co, int parts, hipStream_t s);
+void conv3d_c1_wgrad_reduce_launch(const float *slab, float *dWp, int Co, int parts, int param_layout, const float *dbpart,
+                                   float *db, hipStream_t s);
 }  // namespace svr
 
 namespace {
@@ -69,6 +71,7 @@ struct S1Args {
   const double *sums;                // BWD_APPLY: sum dy, sum dy*xhat
   double *part;                      // STATS / BWD_REDUCE: per-workgroup partial sums [grid][2][16]
   float *dout, *slab, *dbpart;       // BWD_APPLY: optional dconv, per-workgroup dW [grid][32][32], db [grid][16]
+  float *dgamma, *dbeta;             // BWD_APPLY: BatchNorm parameter gradients (= the sums; written by workgroup 0)
   int B, D, H, W, nbz, nby, nbx, nbricks, flags;
 };
 
@@ -170,6 +173,10 @@ __global__ __launch_bounds__(256) void stage1_kernel(const S1Args a) {
   float sc = 0.f, sh = 0.f, is = 0.f, mu = 0.f, m1 = 0.f, m2 = 0.f;
   if (MODE != S1_STATS) {
     sc = a.ss[l15]; sh = a.ss[CO + l15]; is = a.ss[2 * CO + l15]; mu = a.mean[l15];
+  }
+  if (MODE == S1_BWD_APPLY && blockIdx.x == 0 && t < CO) {
+    if (a.dbeta) a.dbeta[t] = (float)a.sums[t];
+    if (a.dgamma) a.dgamma[t] = (float)a.sums[CO + t];
   }
   if (MODE == S1_BWD_APPLY && !(a.flags & 2)) {
     const double n = (double)a.B * D * H * W;
@@ -428,13 +435,6 @@ __global__ __launch_bounds__(256) void stage1_kernel(const S1Args a) {
   }
 }
 
-__global__ void s1_param_grads_kernel(const double *__restrict__ sums, float *__restrict__ dgamma, float *__restrict__ dbeta) {
-  const int c = threadIdx.x;
-  if (c >= CO) return;
-  if (dbeta) dbeta[c] = (float)sums[c];
-  if (dgamma) dgamma[c] = (float)sums[CO + c];
-}
-
 void s1_fill(S1Args &a, int B, int D, int H, int W) {
   a.B = B; a.D = D; a.H = H; a.W = W;
   a.nbz = (int)cdiv(D, SB); a.nby = (int)cdiv(H, SB); a.nbx = (int)cdiv(W, SB);
@@ -496,11 +496,12 @@ extern "C" int svr_stage1_fwd(const float *x, const float *Wp, const float *bias
     a.part = (double *)workspace;
     const int grid = s1_grid<S1_STATS>(a.nbricks);
     hipLaunchKernelGGL(stage1_kernel<S1_STATS>, dim3(grid), dim3(256), 0, s, a);
-    bn_stats_final_launch(a.part, stats, rows, CO, grid, s);
-  }
-  if (int rc = svr_bn_finalize(stats, gamma, beta, running_mean, running_var, scale_shift, mean_f32, rows, CO, eps, momentum,
-                               training, stream))
+    bn_stats_finalize_launch(a.part, stats, rows, CO, grid, gamma, beta, running_mean, running_var, scale_shift, mean_f32, eps,
+                             momentum, s);
+  } else if (int rc = svr_bn_finalize(stats, gamma, beta, running_mean, running_var, scale_shift, mean_f32, rows, CO, eps,
+                                      momentum, 0, stream)) {
     return rc;
+  }
   a.ss = scale_shift; a.mean = mean_f32; a.y = y; a.pooled = pooled; a.argmax = argmax;
   hipLaunchKernelGGL(stage1_kernel<S1_APPLY>, dim3(s1_grid<S1_APPLY>(a.nbricks)), dim3(256), 0, s, a);
   return launch_status("stage1_fwd");
@@ -525,10 +526,9 @@ extern "C" int svr_stage1_bwd(const float *x, const float *Wp, const float *bias
   const int grid_r = s1_grid<S1_BWD_REDUCE>(a.nbricks), grid_a = s1_grid<S1_BWD_APPLY>(a.nbricks);
   hipLaunchKernelGGL(stage1_kernel<S1_BWD_REDUCE>, dim3(grid_r), dim3(256), 0, s, a);
   bn_sum_parts_launch(a.part, sums, 2 * CO, grid_r, s);
-  a.sums = sums; a.slab = slab; a.dbpart = dbpart; a.dout = dout;
+  a.sums = sums; a.slab = slab; a.dbpart = dbpart; a.dout = dout; a.dgamma = dgamma; a.dbeta = dbeta;
   hipLaunchKernelGGL(stage1_kernel<S1_BWD_APPLY>, dim3(grid_a), dim3(256), 0, s, a);
-  conv3d_c1_wgrad_reduce_launch(slab, dWp, CO, grid_a, s);
-  if (db) conv3d_db_reduce_launch(dbpart, db, CO, grid_a, s);
-  if (dgamma || dbeta) hipLaunchKernelGGL(s1_param_grads_kernel, dim3(1), dim3(64), 0, s, sums, dgamma, dbeta);
+  // slabs -> dW in the parameter's layout (16,1,3,3,3), partials -> db: one launch
+  conv3d_c1_wgrad_reduce_launch(slab, dWp, CO, grid_a, 1, dbpart, db, s);
   return launch_status("stage1_bwd");
 }

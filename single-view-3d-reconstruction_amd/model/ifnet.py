@@ -460,8 +460,7 @@ class _EncoderGatherFn(torch.autograd.Function):
                     inp, acts[1], conv.bias.detach(), gvols[si + 1], dpooled, argmax if dpooled is not None else None, mean, ss,
                     relu_mask=True, training=ctx.training, want_dout=need_x)
                 grads[bn.weight], grads[bn.bias] = dgamma, dbeta
-                grads[conv.weight] = ops.conv3d_unpack_wgrad(dwp, 1, conv.weight.shape[0])
-                grads[conv.bias] = db
+                grads[conv.weight], grads[conv.bias] = dwp, db
                 if need_x:
                     gx = ops.conv3d_k3_bwd_data(dout, conv.weight.detach())
                 continue
@@ -472,9 +471,7 @@ class _EncoderGatherFn(torch.autograd.Function):
                 conv = convs[k]
                 cin = acts[k - 1] if k > 0 else inp
                 Co, Ci = conv.weight.shape[0], conv.weight.shape[1]
-                dwp, db = ops.conv3d_k3_bwd_weight(cin, dout)
-                grads[conv.weight] = ops.conv3d_unpack_wgrad(dwp, Ci, Co)
-                grads[conv.bias] = db
+                grads[conv.weight], grads[conv.bias] = ops.conv3d_k3_bwd_weight(cin, dout, param_layout=True)
                 if k > 0:
                     dout = ops.conv3d_k3_bwd_data(dout, conv.weight.detach(), mask=acts[k - 1])
                 elif si > 0:

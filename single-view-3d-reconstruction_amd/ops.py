@@ -797,12 +797,23 @@ def conv3d_k3_bwd_data(dout, w, mask=None, mode=None):
 BACKWARD_CONV_WEIGHT = "bf16x3"
 
 
-def conv3d_k3_bwd_weight(x, dout, want_bias=True, mode=None):
-    """dWp [27][Ci][Co], db (Co)."""
+def conv3d_k3_bwd_weight(x, dout, want_bias=True, mode=None, param_layout=False):
+    """dWp [27][Ci][Co], db (Co).  param_layout: the weight gradient in the parameter's layout (Co,Ci,3,3,3) instead (the
+    bf16x3 kernel writes it directly; the other paths unpack)."""
     _f32(x, dout)
     B, D, H, W, Ci = x.shape
     Co = dout.shape[4]
     l = _lib.lib()
+    if (mode or BACKWARD_CONV_WEIGHT) == "bf16x3" and Ci % 4 == 0 and Co % 4 == 0 and param_layout:
+        ws = torch.empty(l.svr_conv3d_k3_bwd_weight_bf16x3_workspace(B, D, H, W, Ci, Co), device=x.device, dtype=torch.uint8)
+        dw = torch.empty(Co, Ci, 3, 3, 3, device=x.device, dtype=torch.float32)
+        db = torch.empty(Co, device=x.device, dtype=torch.float32) if want_bias else None
+        check(l.svr_conv3d_k3_bwd_weight_bf16x3_param(_p(x), _p(dout), _p(dw), _p(db), B, D, H, W, Ci, Co, _p(ws), _stream()),
+              "conv3d_k3_bwd_weight_bf16x3_param")
+        return dw, db
+    if param_layout:
+        dwp, db = conv3d_k3_bwd_weight(x, dout, want_bias, mode)
+        return conv3d_unpack_wgrad(dwp, Ci, Co), db
     if (mode or BACKWARD_CONV_WEIGHT) == "bf16x3" and Ci % 4 == 0 and Co % 4 == 0:
         ws = torch.empty(l.svr_conv3d_k3_bwd_weight_bf16x3_workspace(B, D, H, W, Ci, Co), device=x.device, dtype=torch.uint8)
         dwp = torch.empty(27, Ci, Co, device=x.device, dtype=torch.float32)
@@ -830,16 +841,15 @@ def bn_forward(x, gamma, beta, running_mean, running_var, training, eps=1e-5, mo
                          f"torch.Size([{B}, {Cc}, {D}, {H}, {W}])")
     l = _lib.lib()
     dev = x.device
-    if not training:
-        stats = None
-    elif stats is None:
-        stats = torch.empty(2 * Cc, device=dev, dtype=torch.float64)
-        ws = torch.empty(l.svr_bn_stats_workspace(rows, Cc), device=dev, dtype=torch.uint8)
-        check(l.svr_bn_stats(_p(x), _p(stats), rows, Cc, _p(ws), _stream()), "bn_stats")
     ss = torch.empty(3 * Cc, device=dev, dtype=torch.float32)
     mean = torch.empty(Cc, device=dev, dtype=torch.float32)
-    check(l.svr_bn_finalize(_p(stats), _p(gamma), _p(beta), _p(running_mean), _p(running_var), _p(ss), _p(mean), rows, Cc,
-                            eps, momentum, int(training), _stream()), "bn_finalize")
+    if training and stats is None:      # statistics + finalize: two launches
+        ws = torch.empty(l.svr_bn_stats_workspace(rows, Cc), device=dev, dtype=torch.uint8)
+        check(l.svr_bn_stats_finalize(_p(x), C.c_void_p(0), _p(gamma), _p(beta), _p(running_mean), _p(running_var), _p(ss), _p(mean),
+                                      rows, Cc, eps, momentum, _p(ws), _stream()), "bn_stats_finalize")
+    else:
+        check(l.svr_bn_finalize(_p(stats if training else None), _p(gamma), _p(beta), _p(running_mean), _p(running_var), _p(ss),
+                                _p(mean), rows, Cc, eps, momentum, int(training), _stream()), "bn_finalize")
     y = torch.empty_like(x)
     pooled = argmax = None
     if want_pool:
@@ -901,7 +911,7 @@ def stage1_fwd(x, w, bias, gamma, beta, running_mean, running_var, training, eps
 
 
 def stage1_bwd(x, wp, bias, dy, dpooled, argmax, mean, ss, relu_mask=True, training=True, want_dout=False):
-    """Backward of stage1_fwd -> dgamma, dbeta, dWp [27][1][16], db, dout (None unless want_dout)."""
+    """Backward of stage1_fwd -> dgamma, dbeta, dW (16,1,3,3,3), db, dout (None unless want_dout)."""
     _f32(x, wp, bias, dy, dpooled, mean, ss)
     B, D, H, W, _ = x.shape
     Co = wp.shape[2]
@@ -910,7 +920,7 @@ def stage1_bwd(x, wp, bias, dy, dpooled, argmax, mean, ss, relu_mask=True, train
     sums = torch.empty(2 * Co, device=dev, dtype=torch.float64)
     dgamma = torch.empty(Co, device=dev, dtype=torch.float32)
     dbeta = torch.empty(Co, device=dev, dtype=torch.float32)
-    dwp = torch.empty(27, 1, Co, device=dev, dtype=torch.float32)
+    dwp = torch.empty(Co, 1, 3, 3, 3, device=dev, dtype=torch.float32)      # the parameter's layout
     db = torch.empty(Co, device=dev, dtype=torch.float32)
     dout = torch.empty(B, D, H, W, Co, device=dev, dtype=torch.float32) if want_dout else None
     ws = torch.empty(l.svr_stage1_workspace(B, D, H, W), device=dev, dtype=torch.uint8)

@@ -369,6 +369,8 @@ def test_conv3d_fwd_bwd(B, dims, Ci, Co):
         dw = ops.conv3d_unpack_wgrad(dwp, Ci, Co)
         assert G.rel_err(dw.cpu().numpy(), gw.numpy()) < tol, mode
         assert G.rel_err(db.cpu().numpy(), gb.numpy()) < 3e-6
+        dw2, db2 = ops.conv3d_k3_bwd_weight(_cl(x.detach()), _cl(dy), mode=mode, param_layout=True)   # one-launch post-processing
+        assert torch.equal(dw2, dw) and torch.equal(db2, db), mode
     dx = ops.conv3d_k3(_cl(dy), wb)
     assert G.rel_err(_ncdhw(dx).numpy(), gx.numpy()) < 3e-6
     if Ci > 1:
@@ -469,8 +471,8 @@ def test_stage1_recomputed_conv_in_bn_pool(B, dims, training):
         dgamma, dbeta, dwp, db, dout = ops.stage1_bwd(_cl(x), wp, b.detach().cuda(), _cl(dy), _cl(dp) if pool else None,
                                                       argmax if pool else None, mean, ss, relu_mask=True, training=training,
                                                       want_dout=want_dout)
-        dw = ops.conv3d_unpack_wgrad(dwp, 1, 16)
-        assert G.rel_err(dw.cpu().numpy(), gw.numpy()) < 1e-5
+        dw = dwp                                      # already in the parameter's layout (16,1,3,3,3)
+        assert tuple(dw.shape) == (16, 1, 3, 3, 3) and G.rel_err(dw.cpu().numpy(), gw.numpy()) < 1e-5
         assert G.rel_err(db.cpu().numpy(), gb.numpy()) < 1e-5
         assert G.rel_err(dgamma.cpu().numpy(), gg.numpy()) < 1e-5 and G.rel_err(dbeta.cpu().numpy(), gbeta.numpy()) < 1e-5
         if want_dout:       # d(loss)/d(x) through the separate backward-data kernel, as the encoder's backward does
