@@ -431,6 +431,11 @@ def main():
         dist.destroy_process_group()
 
 
+def _ifn_mod():
+    from svr_amd.model import ifnet
+    return ifnet
+
+
 def _backward_arithmetic():
     from svr_amd import ops
     modes = {ops.BACKWARD_GEMM, ops.BACKWARD_CONV, ops.BACKWARD_CONV_WEIGHT}
@@ -516,6 +521,7 @@ def report(a, world, dt, loss, step_ms, host_ms, kt, kd, ranks, forms, fwd_ms, q
                                f"{a.batch}/GPU, full 3D conv encoder + 6-level trilinear gather + occupancy MLP, "
                                "fwd+bwd+grad all-reduce+Adam",
                    "global_batch": world * a.batch, "parallelism": f"dp{world}", "loss": loss, "points": a.dist,
+                   "deterministic_scatter": bool(_ifn_mod().DETERMINISTIC),
                    "arithmetic": "f32 storage everywhere; forward GEMMs/convs: 3-product f16 split on the f16 MFMA "
                                  "(f32-level, ~3e-7 of f64); backward dX/dW GEMMs, conv backward-data and conv weight "
                                  f"gradients: {_backward_arithmetic()}; conv_in, BN, gather/scatter: exact f32"},

@@ -67,7 +67,15 @@ def _get_side_stream(device, which=0):
 # Measured at config 3 (ms, levels 1/2/3): uniform points pull 0.56/0.38/0.57, items 1.07/0.99/0.45; points clustered on
 # planes pull 1.72/1.81/3.53, items 0.65/0.56/0.49 -- longest walk 13/24/94 against 1409/1669/3282.
 SCATTER_FORM = os.environ.get("SVR_SCATTER_FORM", "auto")
-PULL_MAX_WALK = 64
+# Bit-reproducible training step (SVR_DETERMINISTIC=1, or set ifnet.DETERMINISTIC before the step): every scatter of the
+# backward takes an atomic-free form -- pull plans for the levels with C <= 64 whatever the point distribution, the two-pass
+# form for the projected 128-channel levels -- so no float atomic is left in the step and two runs give the same bits
+# (every other reduction of the step already has a fixed order).  Measured on one box, configs[2], uniform points: 17.0 ms
+# against 16.2 ms per step (the atomic forms win inside the backward's fork, and level 3's pull form is bound by its longest
+# walk); with surface-clustered points the pull form is several times slower, so it is a mode, not
+# the default.  A level that has no atomic-free form (C = 128 without the projection: the 32-architecture) raises.
+DETERMINISTIC = os.environ.get("SVR_DETERMINISTIC") is not None
+PULL_MAX_WALK = int(os.environ.get("SVR_PULL_MAX_WALK", "64"))
 _pull_hint = {}       # (device, level, dims, C, B, N) -> {"use": last decision, "slots": [(pinned int32[2], event), ...]}
 
 
@@ -114,7 +122,7 @@ def _level_orders_async(pts, D, H, W, n_levels, align, layout=None, disp=None, p
     if arena is None:
         pts.record_stream(side)     # ... and must not return to the main stream's pool while the side stream reads it
     launched = False
-    form = SCATTER_FORM
+    form = "pull" if DETERMINISTIC else SCATTER_FORM
     fits32 = layout is not None and N > 0 and 7 * B * N < 2 ** 31 and B * N * layout.row_stride < 2 ** 31
     with torch.cuda.stream(side):
         for l in range(1, n_levels):
@@ -122,7 +130,7 @@ def _level_orders_async(pts, D, H, W, n_levels, align, layout=None, disp=None, p
             C = layout.channels[l] if layout is not None else 0
             tag = f"L{l}."
             if l in proj_levels:                     # backward-only projection: items by (cell, displacement)
-                if PROJ_TWO_PASS and min(dhw) >= PROJ_TWO_PASS_MIN_DIM:
+                if DETERMINISTIC or (PROJ_TWO_PASS and min(dhw) >= PROJ_TWO_PASS_MIN_DIM):
                     orders[l] = ops.project_plan(pts, dhw, disp, align)      # two-pass form: no float atomics
                     orders[l].record_stream(main)
                 else:
@@ -138,6 +146,10 @@ def _level_orders_async(pts, D, H, W, n_levels, align, layout=None, disp=None, p
                 else:
                     orders[l] = plan.items            # the plan's sorted item ids are this level's item order
                 launched = True
+            elif DETERMINISTIC and N > 0:
+                raise RuntimeError(f"IF-Net HIP path, DETERMINISTIC: level {l} ({C} channels, {dhw}) has no atomic-free scatter "
+                                   "(pull plans cover 16 / 32 / 64 channels, the projection the 128-channel levels of the "
+                                   "128-architecture)")
             elif form in ("auto", "pull", "items") and fits32:
                 orders[l] = ops.item_order(pts, dhw, disp, align, arena=arena, tag=tag)
                 if arena is None:
@@ -165,7 +177,7 @@ PROJECT_WIDE_LEVELS = os.environ.get("SVR_NO_PROJECTION") is None
 # per step inside the backward's fork (it is not on the critical stream), a 2.7 GB buffer and a longer allocator warm-up, so
 # the atomic form stays the default.  SVR_PROJ_TWO_PASS=1 selects it (at 8^3 the atomic form wins anyway: 0.49 vs 0.55 ms).
 PROJ_TWO_PASS = os.environ.get("SVR_PROJ_TWO_PASS") is not None
-PROJ_TWO_PASS_MIN_DIM = 16
+PROJ_TWO_PASS_MIN_DIM = int(os.environ.get("SVR_PROJ_TWO_PASS_MIN_DIM", "16"))
 # Fused gather -> fc_0 forward (gather_fc0.hip): the feature rows are never written to HBM; only the columns a backward
 # still needs (the levels that are not projected) are kept.  SVR_NO_FUSED_FC0=1 restores the two separate kernels.
 FUSE_FC0 = os.environ.get("SVR_NO_FUSED_FC0") is None
@@ -179,6 +191,8 @@ STAGE1_RECOMPUTE = os.environ.get("SVR_NO_STAGE1") is None
 SORT_ON_SIDE_STREAM = os.environ.get("SVR_SORT_ON_MAIN") is None
 # ... and so do the parameter-only preparations of the split-precision layers (SVR_NO_WEIGHT_PREP=1: in front of every layer)
 PREPARE_WEIGHTS_AHEAD = os.environ.get("SVR_NO_WEIGHT_PREP") is None
+# Level of the kept branch whose scatter runs on the third stream of the backward's fork (SVR_FORK_SPLIT_LEVEL=0: none)
+FORK_SPLIT_LEVEL = int(os.environ.get("SVR_FORK_SPLIT_LEVEL", "3"))
 # The step's large cross-stream buffers live in a per-module StepArena (arena.py); SVR_NO_ARENA=1: ordinary allocations
 USE_ARENA = os.environ.get("SVR_NO_ARENA") is None
 
@@ -411,20 +425,36 @@ class _EncoderGatherFn(torch.autograd.Function):
                 else:
                     gfeat = torch.empty_like(feat)
                 ops.linear_bwd_data(dh0, w0k, out=gfeat)
+                if fork:
+                    dx0_done = torch.cuda.Event()
+                    dx0_done.record(keep_stream)
             skip = tuple(l for l in range(len(levels)) if klay.col[l] < 0)
             if link is not None:
                 link.dh0 = dh0
         if link is not None and link.dh0 is None:
             raise RuntimeError("IF-Net HIP path: the projected backward needs dh0 from the point MLP's backward")
+        # the kept branch is the longest chain of the fork (dX0 -> scatter of levels 2, 1, 3 one after the other): its last
+        # level moves to the third stream, behind dW0, as soon as dX0 is there (FORK_SPLIT_LEVEL; arena buffers only)
+        split = FORK_SPLIT_LEVEL if (fork and arena is not None and ctx.fused and not need_pts and FORK_SPLIT_LEVEL not in skip
+                                     and FORK_SPLIT_LEVEL not in proj and 0 < FORK_SPLIT_LEVEL < len(levels)) else None
+        lo = [None if l in proj else o for l, o in enumerate(level_orders)]
         with torch.cuda.stream(keep_stream) if fork else contextlib.nullcontext():
             if ready is not None:
                 torch.cuda.current_stream().wait_event(ready)
             gpts = ops.gather_bwd(levels, gvols, pts, gfeat, scatter_layout, ext._disp, ext._align, want_gpoints=need_pts,
-                                  level_orders=[None if l in proj else o for l, o in enumerate(level_orders)],
-                                  level_plans=level_plans, skip_levels=skip)
+                                  level_orders=lo, level_plans=level_plans,
+                                  skip_levels=skip if split is None else tuple(skip) + (split,))
             if fork:
                 keep_done = torch.cuda.Event()
                 keep_done.record(keep_stream)
+        if split is not None:
+            with torch.cuda.stream(w_stream):
+                w_stream.wait_event(dx0_done)
+                if ready is not None:
+                    w_stream.wait_event(ready)
+                ops.gather_bwd(levels, gvols, pts, gfeat, scatter_layout, ext._disp, ext._align, want_gpoints=False,
+                               level_orders=lo, level_plans=level_plans,
+                               skip_levels=tuple(l for l in range(len(levels)) if l != split))
         dw0p = None
         if proj:
             # projected levels: dP = scatter of the dh0 rows, then two GEMMs over voxels (see gather_bwd_proj_kernel)

@@ -392,3 +392,48 @@ def test_fused_gather_fc0_step_equals_the_two_kernel_step():
         finally:
             for k, v in saved.items():
                 setattr(ops, k, v)
+
+
+def test_deterministic_mode_step_is_bit_reproducible_and_atomic_free():
+    """ifnet.DETERMINISTIC (SVR_DETERMINISTIC=1): every scatter of the backward takes an atomic-free form (pull plans for
+    levels 1-3, the two-pass form for the projected 128-channel levels), so two runs of the same step give the same bits in
+    EVERY gradient -- like the reference's CPU autograd -- and agree with the default (float-atomic) step
+    to the atomics' rounding noise.  The default step is not held to this: its level-3 and projected scatters use atomics."""
+    from svr_amd.model import ifnet as ifn
+    from svr_amd.trainer import bce_with_logits_sum_mean
+    g = torch.Generator().manual_seed(57)
+    B, D, N = 2, 32, 4000
+    x = (torch.rand(B, 1, D, D, D, generator=g) < 0.05).float().cuda()
+    pts = (torch.rand(B, N, 3, generator=g) - 0.5).cuda()
+    occ = (torch.rand(B, N, generator=g) < 0.5).float().cuda()
+
+    def step():
+        m = _model(128, {"gain": 3.0})
+        loss = bce_with_logits_sum_mean(m(x, pts), occ)
+        loss.backward()
+        torch.cuda.synchronize()
+        return loss.detach().clone(), {n: p.grad.detach().clone() for n, p in m.named_parameters()}
+
+    saved = ifn.DETERMINISTIC
+    try:
+        ifn.DETERMINISTIC = True
+        # the forms the mode selects: pull plans for C <= 64, two-pass plans for the projected levels, no item orders
+        layout = __import__("svr_amd").ops.FeatureLayout([1, 16, 32, 64, 128, 128])
+        orders, plans, ready = ifn._level_orders_async(pts, D, D, D, 6, False, layout.subset([0, 1, 2, 3]), float(np.float32(0.0722)),
+                                                       proj_levels=(4, 5))
+        torch.cuda.synchronize()
+        assert all(plans[l] is not None for l in (1, 2, 3)) and all(type(orders[l]).__name__ == "ProjPlan" for l in (4, 5))
+        l1, g1 = step()
+        l2, g2 = step()
+        assert torch.equal(l1, l2)
+        for n in g1:
+            assert torch.equal(g1[n], g2[n]), n
+        ifn.DETERMINISTIC = False
+        l3, g3 = step()
+        assert abs(float(l3) - float(l1)) <= 1e-6 * abs(float(l1))
+        for n in g1:
+            d = float((g3[n] - g1[n]).norm() / g1[n].norm().clamp_min(1e-30))
+            assert d < 1e-4, (n, d)
+    finally:
+        ifn.DETERMINISTIC = saved
+        ifn._pull_hint.clear()
