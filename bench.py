@@ -212,6 +212,10 @@ def main():
     ap.add_argument("--no-diag", action="store_true", help="skip the untimed single-stream steps behind the timed region")
     ap.add_argument("--alloc-trace", action="store_true",
                     help="record the caching allocator's history over the timed region and report the call sites of every hipMalloc")
+    ap.add_argument("--backward", choices=["production", "f32"], default="production",
+                    help="arithmetic of the backward GEMMs / convolutions: the production bf16x3 split, or exact-f32 MFMA "
+                         "everywhere (ops.BACKWARD_GEMM / BACKWARD_CONV / BACKWARD_CONV_WEIGHT = 'f32'): what the step costs "
+                         "without the split")
     ap.add_argument("--dist", choices=["uniform", "surface"], default="uniform",
                     help="query-point distribution; uniform (default) is the reported worst case")
     a = ap.parse_args()
@@ -235,6 +239,8 @@ def main():
     from svr_amd.trainer import ImplicitRefinementTrainer
     from oracle import ifnet_oracle as O            # name-seeded weights only (checker-side helper)
 
+    if a.backward == "f32":
+        ops.BACKWARD_GEMM = ops.BACKWARD_CONV = ops.BACKWARD_CONV_WEIGHT = "f32"
     torch.cuda.set_device(local_rank)
     if launched:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

@@ -193,6 +193,8 @@ SORT_ON_SIDE_STREAM = os.environ.get("SVR_SORT_ON_MAIN") is None
 PREPARE_WEIGHTS_AHEAD = os.environ.get("SVR_NO_WEIGHT_PREP") is None
 # Level of the kept branch whose scatter runs on the third stream of the backward's fork (SVR_FORK_SPLIT_LEVEL=0: none)
 FORK_SPLIT_LEVEL = int(os.environ.get("SVR_FORK_SPLIT_LEVEL", "3"))
+# Per-level events instead of one join in front of the encoder's backward (SVR_NO_FORK_PIPELINE=1: the single join)
+FORK_PIPELINED = os.environ.get("SVR_NO_FORK_PIPELINE") is None
 # The step's large cross-stream buffers live in a per-module StepArena (arena.py); SVR_NO_ARENA=1: ordinary allocations
 USE_ARENA = os.environ.get("SVR_NO_ARENA") is None
 
@@ -438,12 +440,32 @@ class _EncoderGatherFn(torch.autograd.Function):
         split = FORK_SPLIT_LEVEL if (fork and arena is not None and ctx.fused and not need_pts and FORK_SPLIT_LEVEL not in skip
                                      and FORK_SPLIT_LEVEL not in proj and 0 < FORK_SPLIT_LEVEL < len(levels)) else None
         lo = [None if l in proj else o for l, o in enumerate(level_orders)]
+        # PIPELINED join (FORK_PIPELINED): instead of joining every branch in front of the encoder's backward, every level's
+        # gradient volume gets its own event and stage s only waits for level s + 1 -- the deep stages' backward (1.3 ms of
+        # small, low-occupancy kernels) runs while the side streams still scatter the fine levels; the kept levels are
+        # scattered one call per level, coarse to fine (the order the stages need them), and the coarsest projected level
+        # gets a stream of its own beside the other one's scatter on the main stream.
+        pipelined = FORK_PIPELINED and split is not None
+        level_done = {}
+
+        def scatter_level(l):
+            ops.gather_bwd(levels, gvols, pts, gfeat, scatter_layout, ext._disp, ext._align, want_gpoints=False,
+                           level_orders=lo, level_plans=level_plans, skip_levels=tuple(k for k in range(len(levels)) if k != l))
+            level_done[l] = torch.cuda.Event()
+            level_done[l].record(torch.cuda.current_stream())
+
         with torch.cuda.stream(keep_stream) if fork else contextlib.nullcontext():
             if ready is not None:
                 torch.cuda.current_stream().wait_event(ready)
-            gpts = ops.gather_bwd(levels, gvols, pts, gfeat, scatter_layout, ext._disp, ext._align, want_gpoints=need_pts,
-                                  level_orders=lo, level_plans=level_plans,
-                                  skip_levels=skip if split is None else tuple(skip) + (split,))
+            if pipelined:
+                gpts = None
+                for l in range(len(levels) - 1, -1, -1):      # (level 0, the raw grid, only when d(loss)/d(input) is wanted)
+                    if l != split and l not in skip and l not in proj and gvols[l] is not None:
+                        scatter_level(l)
+            else:
+                gpts = ops.gather_bwd(levels, gvols, pts, gfeat, scatter_layout, ext._disp, ext._align, want_gpoints=need_pts,
+                                      level_orders=lo, level_plans=level_plans,
+                                      skip_levels=skip if split is None else tuple(skip) + (split,))
             if fork:
                 keep_done = torch.cuda.Event()
                 keep_done.record(keep_stream)
@@ -452,10 +474,9 @@ class _EncoderGatherFn(torch.autograd.Function):
                 w_stream.wait_event(dx0_done)
                 if ready is not None:
                     w_stream.wait_event(ready)
-                ops.gather_bwd(levels, gvols, pts, gfeat, scatter_layout, ext._disp, ext._align, want_gpoints=False,
-                               level_orders=lo, level_plans=level_plans,
-                               skip_levels=tuple(l for l in range(len(levels)) if l != split))
+                scatter_level(split)
         dw0p = None
+        p_stream = None
         if proj:
             # projected levels: dP = scatter of the dh0 rows, then two GEMMs over voxels (see gather_bwd_proj_kernel)
             lay, w0p, dh0 = ext._layout, ctx.w0p, link.dh0
@@ -463,7 +484,8 @@ class _EncoderGatherFn(torch.autograd.Function):
             if fork and ready is not None:
                 main.wait_event(ready)
             dw0p = dw0_keep if dw0_keep is not None else torch.zeros_like(w0p)
-            for l in proj:
+
+            def project_level(l):
                 v = levels[l]
                 B_, Dl, Hl, Wl, Cl = v.shape
                 c0 = lay.col[l]
@@ -473,17 +495,33 @@ class _EncoderGatherFn(torch.autograd.Function):
                 gvols[l] = ops.linear_bwd_data(dP2, wl).view(v.shape)
                 dwl, _ = ops.linear_bwd_weight(dP2, v.view(-1, Cl), want_bias=False)                                # (7*256, Cl)
                 dw0p[:, c0:c0 + 7 * Cl] = dwl.view(7, 256, Cl).permute(1, 0, 2).reshape(256, 7 * Cl)
-                del dP, dP2
-        if fork:
+
+            own = max(proj) if (pipelined and len(proj) > 1) else None     # the coarsest projected level: its own stream
+            if own is not None:
+                p_stream = _get_side_stream(gfeat.device, 2)
+                p_stream.wait_stream(main)
+                with torch.cuda.stream(p_stream):
+                    if ready is not None:
+                        p_stream.wait_event(ready)
+                    project_level(own)
+                    gvols[own].record_stream(main)       # allocated in this stream's pool, read by the stage's backward on main
+                    level_done[own] = torch.cuda.Event()
+                    level_done[own].record(p_stream)
+            for l in proj:
+                if l != own:
+                    project_level(l)
+        if fork and not pipelined:
             main.wait_event(keep_done)
             main.wait_stream(w_stream)
-        feat = None      # (only now: see the note at the fork)
+            feat = None      # (only now: see the note at the fork)
         grads = {}
         dpooled = None
         gx = None
         for si in range(len(ext._stages) - 1, -1, -1):
             convs, bn = ext._stages[si]
             inp, acts, argmax, ss, mean = saved[si]
+            if pipelined and (si + 1) in level_done:
+                main.wait_event(level_done[si + 1])        # this stage's gradient volume, from whichever stream scattered it
             if isinstance(acts, tuple):       # ("stage1", wp): BatchNorm backward + conv_in's weight gradient in two passes
                 conv = convs[0]
                 dgamma, dbeta, dwp, db, dout = ops.stage1_bwd(
@@ -509,9 +547,17 @@ class _EncoderGatherFn(torch.autograd.Function):
                 elif need_x:
                     gx = ops.conv3d_k3_bwd_data(dout, conv.weight.detach())
         if need_x:
+            if pipelined and 0 in level_done:
+                main.wait_event(level_done[0])
             gx = (gx + gvols[0]).view(ctx.x_shape)
         if dw0p is None:
             dw0p = dw0_keep
+        if pipelined:      # the leaves of the side streams (dW0's slices, db0) and everything that reads the arena
+            main.wait_event(keep_done)
+            main.wait_stream(w_stream)
+            if p_stream is not None:
+                main.wait_stream(p_stream)
+            feat = None
         ext._prepared.invalidate()      # the optimizer is about to change the parameters the planes were made from
         ops.set_prepared(None)
         if lease is not None:
