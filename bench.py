@@ -340,6 +340,23 @@ def main():
                 os.environ["SVR_NO_SIDE_STREAM"] = prev_env
             for mod, name, orig in diag:
                 setattr(mod, name, orig)
+    # what the step costs WITHOUT the bf16x3 split in the backward: a few extra steps behind the timed
+    # region with the backward GEMMs / convolutions on the exact-f32 MFMA kernels (rank 0's clock; never the headline)
+    f32_bwd_ms = None
+    if not a.no_diag and a.backward == "production":
+        prev = (ops.BACKWARD_GEMM, ops.BACKWARD_CONV, ops.BACKWARD_CONV_WEIGHT)
+        ops.BACKWARD_GEMM = ops.BACKWARD_CONV = ops.BACKWARD_CONV_WEIGHT = "f32"
+        try:
+            for _ in range(2):
+                dp.step(batch)
+            sync()
+            t1 = time.perf_counter()
+            for _ in range(5):
+                dp.step(batch)
+            sync()
+            f32_bwd_ms = (time.perf_counter() - t1) / 5 * 1e3
+        finally:
+            ops.BACKWARD_GEMM, ops.BACKWARD_CONV, ops.BACKWARD_CONV_WEIGHT = prev
     loss = float(loss_t)
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
     if launched:
@@ -384,7 +401,8 @@ def main():
         pts = batch["points"]
         with torch.no_grad():
             f32_gather = "gather_fc0_run" if _ifn.FUSE_FC0 else "gather_fwd"
-            for name, storage, gname in (("f32", "f32", f32_gather), ("bf16", "bf16", "gather_fwd_bf16")):
+            bf16_gather = "gather_fc0_bf16_run" if _ifn.FUSE_FC0_BF16 else "gather_fwd_bf16"
+            for name, storage, gname in (("f32", "f32", f32_gather), ("bf16", "bf16", bf16_gather)):
                 levels = net.encode(batch["input"], storage)
                 z = net.query(levels, pts, spatial_sort=True)
                 kq = _KernelTimer(torch)
@@ -429,6 +447,11 @@ def main():
 
     if rank == 0:
         res = report(a, world, dt, loss, step_ms, host_ms, kt, kd, ranks, forms, fwd_ms, query, arena, grown0)
+        if f32_bwd_ms is not None:
+            res["backward_exact_f32"] = {"ms_per_step": f32_bwd_ms, "value": world * a.batch * a.points / (f32_bwd_ms * 1e-3),
+                                         "unit": "query-points/s",
+                                         "note": "the same step with every backward GEMM / convolution on the exact-f32 MFMA kernels "
+                                                 "(ops.BACKWARD_* = 'f32') instead of the bf16x3 split: 5 steps behind the timed region"}
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(a.grid, a.points)
         print(json.dumps(res), flush=True)
@@ -560,8 +583,13 @@ def report(a, world, dt, loss, step_ms, host_ms, kt, kd, ranks, forms, fwd_ms, q
             q = query[name]
             if q["gather_op"] == "gather_fc0_run":
                 bpp = FUSED_BYTES_PER_POINT_F32          # gather_ms then covers gather AND fc_0
+            elif q["gather_op"] == "gather_fc0_bf16_run":
+                bpp = 7 * 8 * 369 * 2 + 12 + 256 * 2     # bf16 corner reads + coordinates + the bf16 h0 row
             q["value"] = npts / (q["ms"] * 1e-3)
             q["unit"] = "query-points/s"
+            if not q["gather_ms"]:
+                q["gather_ms"] = None
+                continue
             q["gather_algorithmic_GBps"] = npts * bpp / (q["gather_ms"] * 1e-3) / 1e9
             q["gather_algorithmic_frac_of_l2_peak_34500"] = q["gather_algorithmic_GBps"] / L2_PEAK_GBPS
         res["query_path"] = {"workload": f"cached {a.grid}^3 pyramid (batch {a.batch}), {npts} query points per pass: 6-level "

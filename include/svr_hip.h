@@ -188,6 +188,15 @@ int svr_gather_fc0_prepare(const svr_gather_desc *d, const float *W, int64_t ldw
 int svr_gather_fc0_run(const svr_gather_desc *d, const float *points, const float *bias, float *Y, int64_t ldy, int32_t n_out,
                        float *features, int64_t ldf, const int32_t *keep_cols, uint32_t keep_levels, int32_t epilogue,
                        void *workspace, void *stream);
+/* bf16-STORAGE variant of the fused kernel (the throughput mode of svr_gather_trilinear_fwd_bf16 + svr_linear_fwd_bf16 in
+ * one launch; never the default): the levels' `vol` pointers are bf16 volumes (8-byte aligned), W (n_out, ldw) is given in
+ * f32 and rounded to bf16 (round to nearest even), the feature values are rounded to bf16 once -- the bits
+ * svr_gather_trilinear_fwd_bf16 writes -- and multiplied on the bf16 matrix cores with f32 accumulation; Y (B*N, ldy) bf16.
+ * workspace: svr_gather_fc0_workspace(d, n_out) bytes; prepare once per pyramid and weight, run per point set.            */
+int svr_gather_fc0_bf16_prepare(const svr_gather_desc *d, const float *W, int64_t ldw, int32_t n_out, void *workspace,
+                                void *stream);
+int svr_gather_fc0_bf16_run(const svr_gather_desc *d, const float *points, const float *bias, uint16_t *Y, int64_t ldy,
+                            int32_t n_out, int32_t epilogue, void *workspace, void *stream);
 /* gvol[level] += scatter of gfeatures (autograd of grid_sample wrt the volume);
  * levels with gvol == NULL are skipped.  gpoints (B,N,3) may be NULL; when given it is
  * OVERWRITTEN with the gradient wrt the query points.                                   */

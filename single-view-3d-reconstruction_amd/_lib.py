@@ -62,6 +62,8 @@ SIGNATURES = {
     "svr_gather_fc0_fwd": (C.c_int, [C.POINTER(GatherDesc), P, P, I64, P, P, I64, I32, P, I64, P, C.c_uint32, I32, P, P]),
     "svr_gather_fc0_prepare": (C.c_int, [C.POINTER(GatherDesc), P, I64, I32, P, I64, P, C.c_uint32, P, P]),
     "svr_gather_fc0_run": (C.c_int, [C.POINTER(GatherDesc), P, P, P, I64, I32, P, I64, P, C.c_uint32, I32, P, P]),
+    "svr_gather_fc0_bf16_prepare": (C.c_int, [C.POINTER(GatherDesc), P, I64, I32, P, P]),
+    "svr_gather_fc0_bf16_run": (C.c_int, [C.POINTER(GatherDesc), P, P, P, I64, I32, I32, P, P]),
     "svr_gather_trilinear_bwd": (C.c_int, [C.POINTER(GatherDesc), P, P, P, P]),
     "svr_gather_corner_indices": (C.c_int, [C.POINTER(GatherDesc), I32, P, P, P]),
     "svr_cast_f32_to_bf16": (C.c_int, [P, P, I64, P]),

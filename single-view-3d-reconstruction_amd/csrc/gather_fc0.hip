@@ -21,6 +21,11 @@
 // Measurement switches (parts of the kernel turned off: wrong results by construction) exist only in builds with
 // -DSVR_FC0_MEASURE (tools/exp/prof_fc0.sh); the production kernel carries none.
 //
+// bf16-STORAGE variant (template flag BF; svr_gather_fc0_bf16_*: the throughput mode of bf16_path.hip, never the default):
+// volumes in bf16 (8-byte corner loads for the same four channels per lane), f32 corner sums in ATen's order, ONE rounding
+// to bf16 (the feature row bf16_path.hip's gather would have written, bit for bit), one LDS plane, W as one bf16 plane and
+// one v_mfma_f32_32x32x16_bf16 per block instead of three f16 products, h0 stored in bf16.  No kept columns.
+//
 // Build with -ffp-contract=off (gather_common.h).
 #include "common.h"
 #include "gather_common.h"
@@ -35,6 +40,14 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define GLOBAL_AS __attribute__((address_space(1)))
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pack_bf16_rne(float a, float b) {  // round to nearest even (v_cvt_pk_bf16_f32), NaN safe
+  f32x2_t v = {a, b};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
+}
 
 constexpr int FK = 16;                 // reduction elements per MFMA step
 constexpr int FLW = 10;                // dwords per LDS row of one k-step (16 halves + 8 B pad, as gemm_f16x3.hip)
@@ -92,8 +105,8 @@ __device__ __forceinline__ int fused_col(const FcArgs &A, int kk) {
 // Fragment-major W planes: the 16 halves x 32 rows of one MFMA B-fragment are 1 KB contiguous (lane l of the consumer wave
 // reads 16 bytes at lane * 16), k-step major: [k-step][hi / lo][row tile of 32][lane 64][8 halves].  A row-major plane
 // made every fragment load touch 32 cache lines for 32 bytes each and the L1 re-fetched every line four times.
-__device__ __forceinline__ int64_t wfrag_index(int kk, int plane, int n, int ntiles) {
-  return ((((int64_t)(kk >> 4) * 2 + plane) * ntiles + (n >> 5)) * 64 + ((kk >> 3) & 1) * 32 + (n & 31)) * 8 + (kk & 7);
+__device__ __forceinline__ int64_t wfrag_index(int kk, int plane, int n, int ntiles, int nplanes = 2) {
+  return ((((int64_t)(kk >> 4) * nplanes + plane) * ntiles + (n >> 5)) * 64 + ((kk >> 3) & 1) * 32 + (n & 31)) * 8 + (kk & 7);
 }
 
 // W[N][K] f32 -> fragment-major f16 planes in the fused K order: hi(Ws), lo(Ws)
@@ -107,6 +120,15 @@ __global__ void split_w_fused_kernel(FcArgs A, const float *__restrict__ W, int6
   const _Float16 l = (_Float16)(w - (float)h);
   p0[wfrag_index(kk, 0, n, N / 32)] = __builtin_bit_cast(uint16_t, h);
   p0[wfrag_index(kk, 1, n, N / 32)] = __builtin_bit_cast(uint16_t, l);
+}
+
+// bf16-storage variant: ONE fragment-major plane of bf16(W) (round to nearest even: the bits of svr_cast_f32_to_bf16)
+__global__ void split_w_fused_bf16_kernel(FcArgs A, const float *__restrict__ W, int64_t ldw, uint16_t *__restrict__ p0, int N) {
+  const int kk = blockIdx.x * blockDim.x + threadIdx.x, n = blockIdx.y;
+  if (kk >= A.KF || n >= N) return;
+  const int src = fused_col(A, kk);
+  const float w = src >= 0 ? W[(int64_t)n * ldw + src] : 0.f;
+  p0[wfrag_index(kk, 0, n, N / 32, 1)] = (uint16_t)(pack_bf16_rne(w, 0.f) & 0xffffu);
 }
 
 __device__ __forceinline__ f16x8 lds_frag(const uint32_t *plane, int row, int lh) {
@@ -128,7 +150,7 @@ __device__ __forceinline__ f16x8 lds_frag(const uint32_t *plane, int row, int lh
 //     (uniform base + 32-bit offset), sum_k v_k * w_k in ATen's corner order.  A corner outside the volume contributes
 //     v * 0 with v read from a clamped, i.e. existing, voxel: the sum is bit-identical to skipping it (ATen,
 //     gather.hip) for finite volumes.
-template <int LP, int NJ>
+template <int LP, int NJ, bool BF>
 __device__ __forceinline__ void produce_slab(const FcLevel L, const FcSlab S, uint32_t *__restrict__ buf,
                                              const float *__restrict__ points, int64_t m0, int64_t M, int N, float disp,
                                              int ac, float *__restrict__ feat, int row_stride, int pw, int lane) {
@@ -158,10 +180,11 @@ __device__ __forceinline__ void produce_slab(const FcLevel L, const FcSlab S, ui
     const float wt = (w.wx[k & 1] * w.wy[(k >> 1) & 1]) * w.wz[k >> 2];
     wk[k] = __float_as_int((vx[k & 1] && vy[(k >> 1) & 1] && vz[k >> 2]) ? wt : 0.f);
   }
+  constexpr uint32_t EB = BF ? 2u : 4u;   // bytes per stored channel value
 #pragma unroll
-  for (int i = 0; i < 4; ++i) ezy[i] = (int)((uint32_t)(((b * L.D + zc[i >> 1]) * L.H + yc[i & 1]) * L.W * C) * 4u);  // host: < 2^30 elements
+  for (int i = 0; i < 4; ++i) ezy[i] = (int)((uint32_t)(((b * L.D + zc[i >> 1]) * L.H + yc[i & 1]) * L.W * C) * EB);  // host: < 2^30 elements
 #pragma unroll
-  for (int a = 0; a < 2; ++a) ex[a] = (xc[a] * C + S.c0) * 4;
+  for (int a = 0; a < 2; ++a) ex[a] = (xc[a] * C + S.c0) * (int)EB;
   // ---- phase 2
   const int g = lane / LP, q = lane % LP, jj = q / LPI, c4 = (q % LPI) * 4;
   const int src0 = (g * NJ + jj) << 2;
@@ -180,20 +203,34 @@ __device__ __forceinline__ void produce_slab(const FcLevel L, const FcSlab S, ui
 #pragma unroll
     for (int i = 0; i < 4; ++i) zy[i] = (uint32_t)__builtin_amdgcn_ds_bpermute(src, ezy[i]);
 #pragma unroll
-    for (int a = 0; a < 2; ++a) x[a] = (uint32_t)__builtin_amdgcn_ds_bpermute(src, ex[a]) + (uint32_t)(c4 * 4);
+    for (int a = 0; a < 2; ++a) x[a] = (uint32_t)__builtin_amdgcn_ds_bpermute(src, ex[a]) + (uint32_t)c4 * EB;
 #pragma unroll
     for (int k = 0; k < 8; ++k) I.w[k] = __int_as_float(__builtin_amdgcn_ds_bpermute(src, wk[k]));
+    if constexpr (BF) {   // four bf16 channels = one 8-byte load; widened to f32 exactly (bf16 = the upper half of an f32)
+      u32x2_t raw[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) I.v[k] = *reinterpret_cast<const GLOBAL_AS f32x4 *>(vol + (zy[k >> 1] + x[k & 1]));
+      for (int k = 0; k < 8; ++k) raw[k] = *reinterpret_cast<const GLOBAL_AS u32x2_t *>(vol + (zy[k >> 1] + x[k & 1]));
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        I.v[k] = f32x4{__uint_as_float(raw[k].x << 16), __uint_as_float(raw[k].x & 0xffff0000u), __uint_as_float(raw[k].y << 16),
+                       __uint_as_float(raw[k].y & 0xffff0000u)};
+    } else {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) I.v[k] = *reinterpret_cast<const GLOBAL_AS f32x4 *>(vol + (zy[k >> 1] + x[k & 1]));
+    }
   };
   auto finish = [&](const Iter &I, int it) {
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int k = 0; k < 8; ++k) acc = acc + I.v[k] * I.w[k];
+    uint32_t *d = dstg + it * (PPW * FLW);
+    if constexpr (BF) {   // the feature values in bf16 (one rounding), one plane
+      *reinterpret_cast<uint2 *>(d) = make_uint2(pack_bf16_rne(acc.x, acc.y), pack_bf16_rne(acc.z, acc.w));
+      return;
+    }
     uint32_t h0, l0, h1, l1;
     split_x(acc.x, acc.y, h0, l0);
     split_x(acc.z, acc.w, h1, l1);
-    uint32_t *d = dstg + it * (PPW * FLW);
     *reinterpret_cast<uint2 *>(d) = make_uint2(h0, h1);
     *reinterpret_cast<uint2 *>(d + FPLANE) = make_uint2(l0, l1);
     if (S.keep && (PPW0 <= RPW || g < RPW) && RPW * pw + it * PPW + g < live)
@@ -211,10 +248,12 @@ __device__ __forceinline__ void produce_slab(const FcLevel L, const FcSlab S, ui
 
 // The C == 1 level (the raw input grid): 7 columns + 9 zero columns, one k-step.  One (row, displacement) item per
 // producer thread and round (4 rounds of 256; "displacement 7" stands for the zero columns), all 8 x 4 loads in flight.
+template <bool BF>
 __device__ __forceinline__ void produce_c1(const FcLevel L, const FcSlab S, uint32_t *__restrict__ buf,
                                            const float *__restrict__ points, int64_t m0, int64_t M, int N, float disp, int ac,
                                            float *__restrict__ feat, int row_stride, int tp) {
   const GLOBAL_AS float *vol = (const GLOBAL_AS float *)L.vol;
+  const GLOBAL_AS uint16_t *vol16 = (const GLOBAL_AS uint16_t *)L.vol;
   constexpr int C1R = FTM * 8 / 256;  // rounds of 256 (row, displacement) items
   float u[C1R][8], wk[C1R][8];
 #pragma unroll
@@ -230,7 +269,8 @@ __device__ __forceinline__ void produce_c1(const FcLevel L, const FcSlab S, uint
       const bool valid = z >= 0 && z < L.D && y >= 0 && y < L.H && x >= 0 && x < L.W && j < 7;
       const int zc = min(max(z, 0), L.D - 1), yc = min(max(y, 0), L.H - 1), xc = min(max(x, 0), L.W - 1);
       wk[r][k] = valid ? (w.wx[k & 1] * w.wy[(k >> 1) & 1]) * w.wz[k >> 2] : 0.f;
-      u[r][k] = vol[vb + (uint32_t)((zc * L.H + yc) * L.W + xc)];
+      const uint32_t vo = vb + (uint32_t)((zc * L.H + yc) * L.W + xc);
+      u[r][k] = BF ? __uint_as_float((uint32_t)vol16[vo] << 16) : vol[vo];
     }
   }
   uint16_t *b16 = reinterpret_cast<uint16_t *>(buf);
@@ -243,22 +283,24 @@ __device__ __forceinline__ void produce_c1(const FcLevel L, const FcSlab S, uint
     if (j == 7) acc = 0.f;  // (a volume with non-finite values must not leak into the zero columns)
     const _Float16 h = (_Float16)acc;
     const _Float16 l = (_Float16)((acc - (float)h) * 2048.f);
+    const uint16_t hb = BF ? (uint16_t)(pack_bf16_rne(acc, 0.f) & 0xffffu) : __builtin_bit_cast(uint16_t, h);
     if (j < 7) {
-      b16[(row * FLW) * 2 + j] = __builtin_bit_cast(uint16_t, h);
-      b16[(FPLANE + row * FLW) * 2 + j] = __builtin_bit_cast(uint16_t, l);
-      if (S.keep && m0 + row < M) feat[(m0 + row) * row_stride + L.kcol + j] = acc;
+      b16[(row * FLW) * 2 + j] = hb;
+      if (!BF) b16[(FPLANE + row * FLW) * 2 + j] = __builtin_bit_cast(uint16_t, l);
+      if (!BF && S.keep && m0 + row < M) feat[(m0 + row) * row_stride + L.kcol + j] = acc;
     } else {  // halves 7 .. 15 of the row: zeros
       b16[(row * FLW) * 2 + 7] = 0;
-      b16[(FPLANE + row * FLW) * 2 + 7] = 0;
+      if (!BF) b16[(FPLANE + row * FLW) * 2 + 7] = 0;
 #pragma unroll
       for (int p = 4; p < 8; ++p) {
         buf[row * FLW + p] = 0u;
-        buf[FPLANE + row * FLW + p] = 0u;
+        if (!BF) buf[FPLANE + row * FLW + p] = 0u;
       }
     }
   }
 }
 
+template <bool BF>
 __device__ __forceinline__ void produce(const FcArgs &A, int s, uint32_t *buf, const float *points, int64_t m0, int64_t M,
                                         int N, float disp, int ac, float *feat, int row_stride, int pw, int lane, int dbg) {
   const FcSlab S = A.S[s];
@@ -269,15 +311,15 @@ __device__ __forceinline__ void produce(const FcArgs &A, int s, uint32_t *buf, c
   (void)dbg;
 #endif
   if (S.lp == 0) {
-    produce_c1(L, S, buf, points, m0, M, N, disp, ac, feat, row_stride, pw * 64 + lane);
+    produce_c1<BF>(L, S, buf, points, m0, M, N, disp, ac, feat, row_stride, pw * 64 + lane);
     return;
   }
   switch (S.lp * 4 + S.nj) {
-    case 16 * 4 + 1: produce_slab<16, 1>(L, S, buf, points, m0, M, N, disp, ac, feat, row_stride, pw, lane); break;
-    case 16 * 4 + 2: produce_slab<16, 2>(L, S, buf, points, m0, M, N, disp, ac, feat, row_stride, pw, lane); break;
-    case 8 * 4 + 1: produce_slab<8, 1>(L, S, buf, points, m0, M, N, disp, ac, feat, row_stride, pw, lane); break;
-    case 8 * 4 + 2: produce_slab<8, 2>(L, S, buf, points, m0, M, N, disp, ac, feat, row_stride, pw, lane); break;
-    case 4 * 4 + 1: produce_slab<4, 1>(L, S, buf, points, m0, M, N, disp, ac, feat, row_stride, pw, lane); break;
+    case 16 * 4 + 1: produce_slab<16, 1, BF>(L, S, buf, points, m0, M, N, disp, ac, feat, row_stride, pw, lane); break;
+    case 16 * 4 + 2: produce_slab<16, 2, BF>(L, S, buf, points, m0, M, N, disp, ac, feat, row_stride, pw, lane); break;
+    case 8 * 4 + 1: produce_slab<8, 1, BF>(L, S, buf, points, m0, M, N, disp, ac, feat, row_stride, pw, lane); break;
+    case 8 * 4 + 2: produce_slab<8, 2, BF>(L, S, buf, points, m0, M, N, disp, ac, feat, row_stride, pw, lane); break;
+    case 4 * 4 + 1: produce_slab<4, 1, BF>(L, S, buf, points, m0, M, N, disp, ac, feat, row_stride, pw, lane); break;
   }
 }
 
@@ -301,6 +343,7 @@ __global__ void args_store_kernel(FcArgs A, FcArgs *__restrict__ dst) {
 #else
 #define FC_DBG(x) 0
 #endif
+template <bool BF>
 __global__ __launch_bounds__(512, FTM == 64 ? 4 : 2) void gather_fc0_kernel(const FcArgs *__restrict__ Ap, const float *__restrict__ points,
                                                             const uint16_t *__restrict__ W0,
                                                             const uint32_t *__restrict__ amax, const float *__restrict__ bias,
@@ -322,7 +365,7 @@ __global__ __launch_bounds__(512, FTM == 64 ? 4 : 2) void gather_fc0_kernel(cons
     // slab s + 1 is produced into the buffer the consumers are not reading, then the barrier hands both over (ONE call site:
     // with a second, peeled call for slab 0 the compiler inlined all five slab shapes twice and spilled 268 B / lane)
     for (int s = -1; s < S; ++s) {
-      if (s + 1 < S && !(dbg & 1)) produce(A, s + 1, lds + ((s + 1) & 1) * FSLAB, points, m0, M, N, disp, ac, feat, row_stride, pw, lane, dbg);
+      if (s + 1 < S && !(dbg & 1)) produce<BF>(A, s + 1, lds + ((s + 1) & 1) * FSLAB, points, m0, M, N, disp, ac, feat, row_stride, pw, lane, dbg);
       slab_barrier();
     }
     return;
@@ -333,12 +376,13 @@ __global__ __launch_bounds__(512, FTM == 64 ? 4 : 2) void gather_fc0_kernel(cons
   const uint16_t *wp = W0 + ((2 * wc) * 64 + lane) * 8;  // + jt * 512 halves, + plane * 8 * 512, + k-step * 2 * 8 * 512
   // W fragments of four k-steps in registers, rotating by NAME (a copy would have to wait for the load it moves)
   uint4 b0[2][2], b1[2][2], b2[2][2], b3[2][2];  // [tile][hi / lo]
+  constexpr int NPL = BF ? 1 : 2;   // W planes per k-step
   auto loadb = [&](uint4 (&r)[2][2], int kidx) {
-    const uint16_t *q = wp + (kidx < nk ? kidx : nk - 1) * (2 * (FTN / 32) * 512);
+    const uint16_t *q = wp + (kidx < nk ? kidx : nk - 1) * (NPL * (FTN / 32) * 512);
 #pragma unroll
     for (int jt = 0; jt < 2; ++jt) {
       r[jt][0] = *reinterpret_cast<const uint4 *>(q + jt * 512);
-      r[jt][1] = *reinterpret_cast<const uint4 *>(q + (FTN / 32) * 512 + jt * 512);
+      if constexpr (!BF) r[jt][1] = *reinterpret_cast<const uint4 *>(q + (FTN / 32) * 512 + jt * 512);
     }
   };
   f32x16 acc[FMT][2];
@@ -367,6 +411,19 @@ __global__ __launch_bounds__(512, FTM == 64 ? 4 : 2) void gather_fc0_kernel(cons
     if (mma_on) {
       loadb(fre, kidx + BDIST);
       const uint32_t *pa = lds + (s & 1) * FSLAB + kin * FKSTEP;
+      if constexpr (BF) {   // one bf16 product per block
+#pragma unroll
+        for (int i = 0; i < FMT; ++i) {
+          union { f16x8 h; bf16x8_t b; } ua;
+          ua.h = lds_frag(pa, i * 32 + l31, lh);
+#pragma unroll
+          for (int jt = 0; jt < 2; ++jt) {
+            union { uint4 q; bf16x8_t b; } ub;
+            ub.q = cur[jt][0];
+            acc[i][jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ua.b, ub.b, acc[i][jt], 0, 0, 0);
+          }
+        }
+      } else {
       f16x8 b[3][2];
 #pragma unroll
       for (int jt = 0; jt < 2; ++jt) {
@@ -386,6 +443,7 @@ __global__ __launch_bounds__(512, FTM == 64 ? 4 : 2) void gather_fc0_kernel(cons
           acc[i][jt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, b[1][jt], acc[i][jt], 0, 0, 0);  // hi(x) lo(w)
           acc[i][jt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, b[0][jt], acc[i][jt], 0, 0, 0);  // hi(x) hi(w)
         }
+      }
       }
     }
     ++kidx;
@@ -412,7 +470,7 @@ __global__ __launch_bounds__(512, FTM == 64 ? 4 : 2) void gather_fc0_kernel(cons
     }
   }
   if (dbg & 4) return;
-  const float inv = w_scale(amax[0], true);
+  const float inv = BF ? 1.f : w_scale(amax[0], true);
 #pragma unroll
   for (int i = 0; i < FMT; ++i)
 #pragma unroll
@@ -425,7 +483,8 @@ __global__ __launch_bounds__(512, FTM == 64 ? 4 : 2) void gather_fc0_kernel(cons
         if (m < M) {
           float v = acc[i][jt][r] * inv + bv;
           if (relu) v = fmaxf(v, 0.f);
-          Y[m * ldy + n] = v;
+          if constexpr (BF) reinterpret_cast<uint16_t *>(Y)[m * ldy + n] = (uint16_t)(pack_bf16_rne(v, 0.f) & 0xffffu);   // ldy in bf16 elements
+          else Y[m * ldy + n] = v;
         }
       }
     }
@@ -600,7 +659,7 @@ extern "C" int svr_gather_fc0_run(const svr_gather_desc *d, const float *points,
   const int64_t pad_start = keep_cols ? kend : kw;
   const FcWorkspace ws = carve(workspace, n_out, A.KF);
   static const hipError_t lds_attr =  // once per process (an immutable kernel attribute, the library's only global state)
-      hipFuncSetAttribute((const void *)gather_fc0_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FC_LDS_BYTES);
+      hipFuncSetAttribute((const void *)gather_fc0_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, FC_LDS_BYTES);
   SVR_CHECK(lds_attr == hipSuccess, (int)lds_attr, "gather_fc0_run: cannot reserve %d bytes of LDS: %s", FC_LDS_BYTES,
             hipGetErrorString(lds_attr));
   const float *eb = epilogue == SVR_EPI_NONE ? nullptr : bias;
@@ -610,7 +669,7 @@ extern "C" int svr_gather_fc0_run(const svr_gather_desc *d, const float *points,
 #else
   const int dbg = 0;
 #endif
-  hipLaunchKernelGGL(gather_fc0_kernel, dim3((unsigned)cdiv(M, FTM)), dim3(512), FC_LDS_BYTES, (hipStream_t)stream, ws.Ad, points,
+  hipLaunchKernelGGL(gather_fc0_kernel<false>, dim3((unsigned)cdiv(M, FTM)), dim3(512), FC_LDS_BYTES, (hipStream_t)stream, ws.Ad, points,
                      ws.p0, ws.amax, eb, Y, ldy, feat, (int)ldf, keep_levels ? (int)pad_start : -1, M, d->N, d->displacement,
                      d->align_corners, relu, dbg);
   return launch_status("gather_fc0_run");
@@ -622,4 +681,51 @@ extern "C" int svr_gather_fc0_fwd(const svr_gather_desc *d, const float *points,
   int rc = svr_gather_fc0_prepare(d, W, ldw, n_out, feat, ldf, keep_cols, keep_levels, workspace, stream);
   if (rc != SVR_OK) return rc;
   return svr_gather_fc0_run(d, points, bias, Y, ldy, n_out, feat, ldf, keep_cols, keep_levels, epilogue, workspace, stream);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// bf16-storage variant (see the file header): levels' `vol` pointers are bf16 volumes, W is given in f32 and rounded to
+// bf16 here, h0 (B*N, 256) is written in bf16.
+// ------------------------------------------------------------------------------------------------------------------
+extern "C" int svr_gather_fc0_bf16_prepare(const svr_gather_desc *d, const float *W, int64_t ldw, int32_t n_out, void *workspace,
+                                           void *stream) {
+  int rc = check_desc(d, "gather_fc0_bf16_prepare");
+  if (rc != SVR_OK) return rc;
+  if ((int64_t)d->B * d->N == 0) return SVR_OK;
+  SVR_CHECK(W && workspace, SVR_E_BADARG, "gather_fc0_bf16_prepare: null pointer");
+  SVR_CHECK(n_out == FTN, SVR_E_UNSUPPORTED, "gather_fc0_bf16_prepare: %d output columns (the kernel is built for %d)", n_out, FTN);
+  FcArgs A;
+  SVR_CHECK(build_slabs(d, 0, A), SVR_E_UNSUPPORTED, "gather_fc0_bf16_prepare: a level's channel count has no slab shape (1, 16, 32, 64 k)");
+  for (int l = 0; l < d->n_levels; ++l)
+    SVR_CHECK(((uintptr_t)d->level[l].vol & 7) == 0 || d->level[l].C == 1, SVR_E_ALIGN, "gather_fc0_bf16_prepare: level %d: 8-byte alignment", l);
+  hipStream_t s = (hipStream_t)stream;
+  const FcWorkspace ws = carve(workspace, n_out, A.KF);
+  hipLaunchKernelGGL(split_w_fused_bf16_kernel, dim3((unsigned)cdiv(A.KF, 64), (unsigned)n_out), dim3(64), 0, s, A, W, ldw, ws.p0, (int)n_out);
+  hipLaunchKernelGGL(args_store_kernel, dim3(1), dim3(256), 0, s, A, ws.Ad);
+  return launch_status("gather_fc0_bf16_prepare");
+}
+
+extern "C" int svr_gather_fc0_bf16_run(const svr_gather_desc *d, const float *points, const float *bias, uint16_t *Y, int64_t ldy,
+                                       int32_t n_out, int32_t epilogue, void *workspace, void *stream) {
+  int rc = check_desc(d, "gather_fc0_bf16_run");
+  if (rc != SVR_OK) return rc;
+  const int64_t M = (int64_t)d->B * d->N;
+  if (M == 0) return SVR_OK;
+  SVR_CHECK(points && Y && workspace, SVR_E_BADARG, "gather_fc0_bf16_run: null pointer");
+  SVR_CHECK(n_out == FTN, SVR_E_UNSUPPORTED, "gather_fc0_bf16_run: %d output columns (the kernel is built for %d)", n_out, FTN);
+  SVR_CHECK(epilogue == SVR_EPI_NONE || ((epilogue == SVR_EPI_BIAS || epilogue == SVR_EPI_BIAS_RELU) && bias), SVR_E_BADARG,
+            "gather_fc0_bf16_run: epilogue %d", epilogue);
+  FcArgs A;
+  SVR_CHECK(build_slabs(d, 0, A), SVR_E_UNSUPPORTED, "gather_fc0_bf16_run: a level's channel count has no slab shape (1, 16, 32, 64 k)");
+  const FcWorkspace ws = carve(workspace, n_out, A.KF);
+  static const hipError_t lds_attr =
+      hipFuncSetAttribute((const void *)gather_fc0_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, FC_LDS_BYTES);
+  SVR_CHECK(lds_attr == hipSuccess, (int)lds_attr, "gather_fc0_bf16_run: cannot reserve %d bytes of LDS: %s", FC_LDS_BYTES,
+            hipGetErrorString(lds_attr));
+  const float *eb = epilogue == SVR_EPI_NONE ? nullptr : bias;
+  const int relu = epilogue == SVR_EPI_BIAS_RELU ? 1 : 0;
+  hipLaunchKernelGGL(gather_fc0_kernel<true>, dim3((unsigned)cdiv(M, FTM)), dim3(512), FC_LDS_BYTES, (hipStream_t)stream, ws.Ad, points,
+                     ws.p0, ws.amax, eb, reinterpret_cast<float *>(Y), ldy, (float *)nullptr, 0, -1, M, d->N, d->displacement,
+                     d->align_corners, relu, 0);
+  return launch_status("gather_fc0_bf16_run");
 }

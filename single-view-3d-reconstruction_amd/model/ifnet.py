@@ -181,6 +181,8 @@ PROJ_TWO_PASS_MIN_DIM = int(os.environ.get("SVR_PROJ_TWO_PASS_MIN_DIM", "16"))
 # Fused gather -> fc_0 forward (gather_fc0.hip): the feature rows are never written to HBM; only the columns a backward
 # still needs (the levels that are not projected) are kept.  SVR_NO_FUSED_FC0=1 restores the two separate kernels.
 FUSE_FC0 = os.environ.get("SVR_NO_FUSED_FC0") is None
+# ... and its bf16-storage variant for the query path's throughput mode (SVR_NO_FUSED_FC0_BF16=1: gather + fc_0 as two kernels)
+FUSE_FC0_BF16 = os.environ.get("SVR_NO_FUSED_FC0_BF16") is None
 # Fused + projected backward: the kept-column branch on the side stream beside the projected branch (SVR_NO_BWD_OVERLAP=1: serial)
 OVERLAP_BACKWARD = os.environ.get("SVR_NO_BWD_OVERLAP") is None
 # First stage of the 128-architecture (conv_in -> ReLU -> BatchNorm -> pool) with conv_in's activation recomputed instead
@@ -840,11 +842,17 @@ class IFNet(nn.Module):
         return levels
 
     @torch.no_grad()
-    def _query_bf16(self, levels, points, row_map):
+    def _query_bf16(self, levels, points, row_map, prepared=None):
         B, N = points.shape[0], points.shape[1]
         ext = self.ifnet_feature_extractor
-        rows = ops.gather_fwd_bf16(levels, points, ext._layout, ext._disp, ext._align)
-        h = ops.linear_fwd_bf16(rows, ops.cast_bf16(self._fc0_internal()), self.fc_0.bias, relu=True)
+        if prepared is None and FUSE_FC0_BF16 and ops.gather_fc0_bf16_supported(levels, ext._layout, ext._disp, ext._align,
+                                                                                self.fc_0.out_channels):
+            prepared = ops.gather_fc0_bf16_prepare(levels, ext._layout, ext._disp, ext._align, self._fc0_internal())
+        if prepared is not None:      # fused gather -> fc_0 on bf16 storage: the bf16 feature rows never reach HBM
+            h = ops.gather_fc0_bf16_run(prepared, points, self.fc_0.bias, relu=True)
+        else:
+            rows = ops.gather_fwd_bf16(levels, points, ext._layout, ext._disp, ext._align)
+            h = ops.linear_fwd_bf16(rows, ops.cast_bf16(self._fc0_internal()), self.fc_0.bias, relu=True)
         h = ops.linear_fwd_bf16(h, ops.cast_bf16(self.fc_1.weight.squeeze(2).contiguous()), self.fc_1.bias, relu=True)
         h = ops.linear_fwd_bf16(h, ops.cast_bf16(self.fc_2.weight.squeeze(2).contiguous()), self.fc_2.bias, relu=True)
         return ops.fc_out_fwd_bf16(h, self.fc_out.weight.reshape(-1).contiguous(), self.fc_out.bias, row_map).view(B, N)
@@ -855,6 +863,10 @@ class IFNet(nn.Module):
         result to query(..., prepared=) when one pyramid is queried chunk by chunk (dense-grid inference); None when the
         fused kernel does not cover the shapes."""
         ext = self.ifnet_feature_extractor
+        if levels[0].dtype == torch.bfloat16:
+            if FUSE_FC0_BF16 and ops.gather_fc0_bf16_supported(levels, ext._layout, ext._disp, ext._align, self.fc_0.out_channels):
+                return ops.gather_fc0_bf16_prepare(levels, ext._layout, ext._disp, ext._align, self._fc0_internal())
+            return None
         if levels[0].dtype != torch.float32 or not FUSE_FC0 or self.fc_0.out_channels != 256:
             return None
         B = levels[0].shape[0]
@@ -874,7 +886,7 @@ class IFNet(nn.Module):
         if spatial_sort and N > 1:
             row_map, points = ops.morton_order(points, want_sorted=True)
         if levels[0].dtype == torch.bfloat16:
-            return self._query_bf16(levels, points, row_map)
+            return self._query_bf16(levels, points, row_map, prepared)
         ext = self.ifnet_feature_extractor
         if prepared is not None:
             h, _ = ops.gather_fc0_run(prepared, points, self.fc_0.bias)

@@ -448,6 +448,56 @@ def gather_fwd_bf16(vols, points, layout, displacement, align_corners, order=Non
     return out
 
 
+def _bf16_desc(vols, layout, B, N, displacement, align_corners):
+    _bf16(*vols)
+    d = GatherDesc()
+    d.order = C.c_void_p(0)
+    d.n_levels, d.B, d.N, d.row_stride = len(vols), B, N, layout.row_stride
+    d.align_corners, d.displacement = int(align_corners), displacement
+    for l, v in enumerate(vols):
+        if v.dim() != 5 or v.shape[0] != B or v.shape[4] != layout.channels[l]:
+            raise RuntimeError(f"level {l}: expected (B,D,H,W,{layout.channels[l]}) channels-last, got {tuple(v.shape)}")
+        L = d.level[l]
+        L.vol, L.C, L.D, L.H, L.W, L.col = _p(v), v.shape[4], v.shape[1], v.shape[2], v.shape[3], layout.col[l]
+    return d
+
+
+def gather_fc0_bf16_supported(vols, layout, displacement, align_corners, n_out):
+    """The fused bf16-storage kernel covers these (bf16) volumes and fc_0's width?"""
+    d = _bf16_desc(vols, layout, vols[0].shape[0], 1, displacement, align_corners)
+    return n_out == 256 and bool(_lib.lib().svr_gather_fc0_supported(C.byref(d)))
+
+
+def gather_fc0_bf16_prepare(vols, layout, displacement, align_corners, w):
+    """w (n_out, >= layout.width) f32 -> one bf16 plane in the fused kernel's fragment order + the slab table; -> a handle
+    for gather_fc0_bf16_run.  vols: the bf16 pyramid (IFNet.encode(x, storage="bf16"))."""
+    _f32(w)
+    B = vols[0].shape[0]
+    d = _bf16_desc(vols, layout, B, 1, displacement, align_corners)
+    l = _lib.lib()
+    n_out = w.shape[0]
+    assert w.stride(1) == 1 and w.shape[1] >= layout.width
+    ws_bytes = l.svr_gather_fc0_workspace(C.byref(d), n_out)
+    if ws_bytes <= 0:
+        raise RuntimeError("gather_fc0_bf16: unsupported level shapes (see svr_gather_fc0_supported)")
+    ws = torch.empty(ws_bytes, device=w.device, dtype=torch.uint8)
+    check(l.svr_gather_fc0_bf16_prepare(C.byref(d), C.c_void_p(w.data_ptr()), w.stride(0), n_out, _p(ws), _stream()),
+          "gather_fc0_bf16_prepare")
+    return {"vols": vols, "layout": layout, "disp": displacement, "ac": align_corners, "n_out": n_out, "ws": ws}
+
+
+def gather_fc0_bf16_run(prep, points, bias, relu=True):
+    """-> h0 (B*N, n_out) bf16 = [relu](bf16 features @ bf16(w).T + bias), the features never leave the chip."""
+    B, N, _ = points.shape
+    _f32(points, bias)
+    d = _bf16_desc(prep["vols"], prep["layout"], B, N, prep["disp"], prep["ac"])
+    out = torch.empty(B * N, prep["n_out"], device=points.device, dtype=torch.bfloat16)
+    epi = EPI_NONE if bias is None else (EPI_BIAS_RELU if relu else EPI_BIAS)
+    check(_lib.lib().svr_gather_fc0_bf16_run(C.byref(d), _p(points), _p(bias), _p(out), out.stride(0), prep["n_out"], epi,
+                                             _p(prep["ws"]), _stream()), "gather_fc0_bf16_run")
+    return out
+
+
 def linear_fwd_bf16(x, w, bias, relu=True):
     """y (bf16) = [relu](x (bf16) @ w (bf16).T + bias (f32)), f32 accumulation."""
     _bf16(x, w)

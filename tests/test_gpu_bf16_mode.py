@@ -168,3 +168,67 @@ def test_query_spatial_sort_is_result_neutral():
     for storage in ("f32", "bf16"):
         lv = m.encode(x.cuda(), storage)
         assert torch.equal(m.query(lv, pts.cuda()), m.query(lv, pts.cuda(), spatial_sort=True)), storage
+
+
+@pytest.mark.parametrize("B,dims,N,spread", [(2, (16, 16, 16), 777, 1.0), (1, (35, 26, 28), 500, 1.3), (3, (32, 32, 32), 1, 1.0),
+                                             (2, (24, 24, 24), 1280, 1.05)])
+def test_fused_bf16_gather_fc0_equals_the_two_bf16_kernels(B, dims, N, spread):
+    """gather_fc0.hip's bf16-storage variant (svr_gather_fc0_bf16_*) against the two kernels it fuses (bf16 gather +
+    svr_linear_fwd_bf16): the SAME bf16 feature values (the gather's arithmetic and single rounding) and the same bf16
+    weights meet in f32 accumulators, only the summation order over K differs -> h0 agrees to one bf16 ulp of the row
+    scale (1 / 128), and with the float64 product of the bit-exact bf16 rows to the same bound."""
+    ops = _ops()
+    chans = O.level_channels(128)
+    g = torch.Generator().manual_seed(11 + N)
+    vols, d = [], list(dims)
+    for i, c in enumerate(chans):
+        vols.append(torch.randn(B, c, *d, generator=g).bfloat16())
+        if i >= 1:
+            d = [max(1, s // 2) for s in d]
+    pts = ((torch.rand(B, N, 3, generator=g) - 0.5) * spread).cuda()
+    layout = ops.FeatureLayout(chans)
+    vols_g = [_cl(v) for v in vols]
+    w = (torch.randn(256, layout.row_stride, generator=g) / 30).cuda()
+    w[:, layout.width:] = 0
+    bias = torch.randn(256, generator=g).cuda()
+    assert ops.gather_fc0_bf16_supported(vols_g, layout, DISP, False, 256)
+    rows = ops.gather_fwd_bf16(vols_g, pts, layout, DISP, False)
+    want = ops.linear_fwd_bf16(rows, ops.cast_bf16(w), bias, relu=True).float()
+    prep = ops.gather_fc0_bf16_prepare(vols_g, layout, DISP, False, w)
+    h0 = ops.gather_fc0_bf16_run(prep, pts, bias, relu=True)
+    assert h0.dtype == torch.bfloat16 and tuple(h0.shape) == (B * N, 256)
+    scale = float(want.abs().max())
+    assert float((h0.float() - want).abs().max()) <= scale / 128
+    ref = torch.relu(rows.double().cpu() @ ops.cast_bf16(w).double().cpu().t() + bias.double().cpu())
+    assert float((h0.double().cpu() - ref).abs().max()) <= scale / 128
+    # most entries are identical bits (the order of an f32 sum rarely moves a bf16 rounding)
+    assert float((h0.float() == want).float().mean()) > 0.97
+    # no ReLU / another point set on the same preparation
+    h1 = ops.gather_fc0_bf16_run(prep, pts[:, : max(1, N // 2)].contiguous(), bias, relu=False)
+    assert tuple(h1.shape) == (B * max(1, N // 2), 256)
+    assert torch.equal(torch.relu(h1.float()).view(B, -1, 256), h0.float().view(B, N, 256)[:, : max(1, N // 2)])
+
+
+def test_bf16_query_uses_the_fused_kernel_and_matches_the_unfused_mode():
+    """IFNet.query on a bf16 pyramid: the fused path (default) against SVR_NO_FUSED_FC0_BF16's two-kernel path on the same
+    pyramid -- logits within bf16 noise of each other (3e-3 of the logit scale), and the prepared form gives the fused bits."""
+    import svr_amd  # noqa: F401
+    from svr_amd.model import IFNet
+    from svr_amd.model import ifnet as ifn
+    m = IFNet(net_res=128)
+    m.load_state_dict(O.name_seeded_state(128), strict=False)
+    m = m.cuda().eval()
+    g = torch.Generator().manual_seed(91)
+    x = (torch.rand(2, 1, 32, 32, 32, generator=g) < 0.05).float().cuda()
+    pts = (torch.rand(2, 3000, 3, generator=g) - 0.5).cuda()
+    levels = m.encode(x, storage="bf16")
+    assert ifn.FUSE_FC0_BF16
+    z_fused = m.query(levels, pts)
+    prep = m.prepare_query(levels, 3000)
+    assert prep is not None and torch.equal(m.query(levels, pts, prepared=prep), z_fused)
+    saved, ifn.FUSE_FC0_BF16 = ifn.FUSE_FC0_BF16, False
+    try:
+        z_two = m.query(levels, pts)
+    finally:
+        ifn.FUSE_FC0_BF16 = saved
+    assert float((z_fused - z_two).abs().max()) <= 3e-3 * float(z_two.abs().max())

@@ -10,7 +10,7 @@ for path in sys.argv[1:]:
         continue
     print("==", path)
     for k in ("value", "ms_per_step", "step_ms", "step_ms_list", "step_max_over_median", "host_enqueue_ms", "allocator",
-              "scatter_forms", "all_reduce_ms", "fwd_only", "encoder_ms_per_step", "mlp_gemm_ms_per_step"):
+              "scatter_forms", "all_reduce_ms", "backward_exact_f32", "fwd_only", "encoder_ms_per_step", "mlp_gemm_ms_per_step"):
         if k in d:
             v = d[k]
             if isinstance(v, dict):
