@@ -677,12 +677,16 @@ def report(a, world, dt, loss, step_ms, host_ms, kt, kd, ranks, forms, fwd_ms, q
             enc_ms[op] += ms
             per_vox = (8 + 64 + 8 + 2) if op == "stage1_fwd" else (8 + 128 + 20)
             byts = vox * per_vox * calls
-            rate = byts / (ms * 1e-3) / 1e9
+            # counter-measured HBM bytes of the two passes (profiles/gather_traffic.json, same workload) where available
+            tkeys = ("stage1_stats_hbm_bytes", "stage1_apply_hbm_bytes") if op == "stage1_fwd" else ("stage1_bwd_reduce_hbm_bytes", "stage1_bwd_apply_hbm_bytes")
+            pmc = sum(t[k] for k in tkeys) * calls if all(k in t for k in tkeys) else None
+            rate = (pmc if pmc else byts) / (ms * 1e-3) / 1e9
             what1 = ("forward: conv_in -> ReLU -> BatchNorm statistics, then again -> y, pooled, argmax" if op == "stage1_fwd" else
                      "backward: BatchNorm reduce, then BatchNorm apply -> conv_in weight / bias gradient (no dconv tensor)")
             kernels.append({"kernel": f"encoder stage 1 recomputed ({what1}) {shape}", "bound": "hbm", "unit": "GB/s",
                             "peak": HBM_PEAK_GBPS, "achieved": rate, "frac": rate / HBM_PEAK_GBPS, "ms_per_step": ms,
-                            "calls_per_step": calls, "algorithmic_bytes_per_step": byts,
+                            "calls_per_step": calls, "algorithmic_bytes_per_step": byts, "traffic": pmc,
+                            "traffic_source": t.get("source") if pmc else None,
                             "mfma_f32_TFLOPs": (vox * (2 if op == "stage1_fwd" else 2 + 2 * 32 / 27.0) * 2 * 27 * 16 * calls) / (ms * 1e-3) / 1e12})
         elif op in ("bn_fwd", "bn_bwd"):
             # BatchNorm + pool passes: HBM bound.  Algorithmic bytes per element of the (B,D,H,W,C) volume: forward =

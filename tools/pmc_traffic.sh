@@ -9,7 +9,7 @@
 set -u
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
-TAG=${1:-r02}; shift || true
+TAG=${1:-r03}; shift || true
 for C in FETCH_SIZE WRITE_SIZE; do
   rm -rf "$R/gpurun_out/pmc_traffic_$C"
   timeout -k 10 420 rocprofv3 --kernel-trace --pmc $C --output-format csv -d "$R/gpurun_out/pmc_traffic_$C" -o p -- \
@@ -31,7 +31,7 @@ for f in glob.glob(f"{R}/gpurun_out/pmc_traffic_*/**/*counter_collection.csv", r
     for r in rd:
         n = r["Kernel_Name"]
         for key in ("gather_fc0_kernel", "gather_bwd_proj_kernel", "gather_fwd_fused_kernel", "gather_bwd_fused_kernel", "gather_bwd_pull_kernel<16", "gather_bwd_pull_kernel<32",
-                    "gather_bwd_pull_kernel<64"):
+                    "gather_bwd_pull_kernel<64", "stage1_kernel<0>", "stage1_kernel<1>", "stage1_kernel<2>", "stage1_kernel<3>"):
             if key in n:
                 agg[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
                 rows[r["Counter_Name"]].append(r)
@@ -67,6 +67,10 @@ pv = out.get("gather_bwd_proj_kernel")
 if pv and "FETCH_SIZE_KB" in pv and "WRITE_SIZE_KB" in pv:          # projected scatter: per launch (two launches per step)
     out["proj_hbm_bytes_per_launch"] = 2 * pv["FETCH_SIZE_KB"] * 1024 + pv["WRITE_SIZE_KB"] * 1024
     out["proj_atomic_bytes_per_launch"] = pv["WRITE_SIZE_KB"] * 1024
+for i, name in enumerate(("stats", "apply", "bwd_reduce", "bwd_apply")):      # recomputed first stage (stage1.hip)
+    k = out.get(f"stage1_kernel<{i}>")
+    if k and "FETCH_SIZE_KB" in k and "WRITE_SIZE_KB" in k:
+        out[f"stage1_{name}_hbm_bytes"] = 2 * k["FETCH_SIZE_KB"] * 1024 + k["WRITE_SIZE_KB"] * 1024
 if "gather_bwd_fused_kernel" in out:
     out["gather_bwd_write_bytes"] = out["gather_bwd_fused_kernel"].get("WRITE_SIZE_KB", 0.0) * 1024   # = float atomics issued
 out["source"] = (f"separate rocprofv3 --pmc passes (FETCH_SIZE; WRITE_SIZE) of `bench.py --steps 2 --warmup 1 {' '.join(extra)}` "
