@@ -16,8 +16,8 @@ from oracle import scene_oracle as S  # noqa: E402
 from svr_amd.trainer import SceneNetTrainer, default_hparams  # noqa: E402
 
 ap = argparse.ArgumentParser()
-ap.add_argument("--steps", type=int, default=5)
-ap.add_argument("--warmup", type=int, default=2)
+ap.add_argument("--steps", type=int, default=10)
+ap.add_argument("--warmup", type=int, default=8, help="the step arena and the scatter-form decision (fixed lag 3) settle in the first steps")
 ap.add_argument("--batch", type=int, default=4)
 ap.add_argument("--points", type=int, default=50000)
 ap.add_argument("--graph", action="store_true", help="capture the whole step into a HIP graph (svr_amd.graphs.GraphedStep)")
