@@ -23,11 +23,15 @@ class _Lease:
 
     def __init__(self, arena):
         self.arena = arena
+        self.on_release = []      # callbacks: state that is only valid while this forward's graph is (prepared weight planes)
 
     def release(self):
         a, self.arena = self.arena, None
         if a is not None:
             a._leased = False
+            cbs, self.on_release = self.on_release, []
+            for cb in cbs:
+                cb()
 
     def __del__(self):
         self.release()

@@ -560,10 +560,9 @@ class _EncoderGatherFn(torch.autograd.Function):
             if p_stream is not None:
                 main.wait_stream(p_stream)
             feat = None
-        ext._prepared.invalidate()      # the optimizer is about to change the parameters the planes were made from
-        ops.set_prepared(None)
         if lease is not None:
             lease.release()     # every kernel that touches the arena is enqueued; the next step orders itself behind them
+            #                     (also expires the prepared weight planes: the optimizer is about to change the parameters)
         out = [None, None, None, None, dw0p, db0, gx, gpts]
         for p in ext._param_list:
             out.append(grads.get(p))
@@ -807,11 +806,12 @@ class IFNet(nn.Module):
         return _PermuteColumnsFn.apply(self.fc_0.weight.squeeze(2), self._fc0_src, self._fc0_mask, self._fc0_inv)
 
     @torch.no_grad()
-    def _prepare_weights_async(self):
+    def _prepare_weights_async(self, lease):
         """Training step: the weight planes of every split-precision layer (encoder convolutions behind conv_in, fc_1,
         fc_2; forward and backward-data forms) are made on the side stream, in front of the Morton sort, instead of in
         2-4 launch-bound kernels in front of each layer call on the main stream (~40 launches per step).  Valid until
-        the encoder's backward has been enqueued; ops find them by the parameter's address (ops.PreparedWeights)."""
+        the encoder's backward has been enqueued -- or the forward's graph is dropped without one (they expire with the
+        arena lease) -- ops find them by the parameter's address + version (ops.PreparedWeights)."""
         if not PREPARE_WEIGHTS_AHEAD:
             return
         ext = self.ifnet_feature_extractor
@@ -828,6 +828,12 @@ class IFNet(nn.Module):
             prep.add_linear(self.fc_2.weight.detach().squeeze(2))
             prep.finish(side)
         ops.set_prepared(prep)
+
+        def expire():       # with the lease: at the end of the backward, or when the graph is dropped without one
+            prep.invalidate()
+            if ops._prepared is prep:
+                ops.set_prepared(None)
+        lease.on_release.append(expire)
 
     @torch.no_grad()
     def encode(self, x, storage="f32"):
@@ -918,7 +924,7 @@ class IFNet(nn.Module):
         if spatial_sort and N > 1:
             pts = points.detach().float().contiguous()
             if arena is not None and SORT_ON_SIDE_STREAM and not os.environ.get("SVR_NO_SIDE_STREAM"):
-                self._prepare_weights_async()
+                self._prepare_weights_async(lease)
                 # the Morton sort (a chain of ~25 launch-bound radix-sort kernels, 0.2 ms) is only needed by the gather and
                 # by the scatter plans: it runs on the side stream, in front of the plans, while the encoder starts on the
                 # main stream at once; the main stream waits for it in front of the gather (_EncoderGatherFn.forward).
