@@ -23,7 +23,7 @@ SOURCES = {
     "gemm_bf16x6.hip": [],
     "gemm_f16x3.hip": [],
     "conv3d.hip": [],
-    "conv3d_bf16.hip": [],
+    "conv3d_bf16.hip": [f"-DSVR_CONV_EXP={os.environ['SVR_CONV_EXP']}"] if os.environ.get("SVR_CONV_EXP") else [],   # measurement builds
     "conv3d_bwdw_bf16.hip": [],
     "bn_pool.hip": [],
     "stage1.hip": [f"-DS1_EXP={os.environ['SVR_S1_EXP']}"] if os.environ.get("SVR_S1_EXP") else [],   # measurement builds

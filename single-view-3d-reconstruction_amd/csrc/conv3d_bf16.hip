@@ -232,7 +232,11 @@ __global__ __launch_bounds__(256) void conv3d_brick_x3_kernel(const float *__res
 #pragma unroll
       for (int tg = 0; tg < TG; ++tg) {
         const int tap = tap0 + tg;
+#if defined(SVR_CONV_EXP) && SVR_CONV_EXP == 1   // measurement build: the three dx taps read ONE fragment (wrong results)
+        const int arow = hrow + ((tap / 9 - 1) * HLY + ((tap / 3) % 3 - 1)) * HLX;
+#else
         const int arow = hrow + ((tap / 9 - 1) * HLY + ((tap / 3) % 3 - 1)) * HLX + (tap % 3 - 1);
+#endif
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
           const int kw = ks * 8 + lh * 4;
