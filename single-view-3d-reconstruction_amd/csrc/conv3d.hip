@@ -427,8 +427,18 @@ __global__ __launch_bounds__(256) void conv3d_bwd_weight_reduce_kernel(const flo
   const int idx = blockIdx.x * 64 + (threadIdx.x & 63);
   const int pl = threadIdx.x >> 6;
   double sum = 0.0;
-  if (idx < per)
-    for (int p = pl; p < parts; p += 4) sum += (double)slab[(int64_t)p * per + idx];
+  {  // eight slab loads in flight per lane (one at a time was a latency chain of parts / 4 round trips), fixed order
+    const int ic = idx < per ? idx : per - 1;
+    int p = pl;
+    for (; p + 28 < parts; p += 32) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = slab[(int64_t)(p + 4 * u) * per + ic];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) sum += (double)v[u];
+    }
+    for (; p < parts; p += 4) sum += (double)slab[(int64_t)p * per + ic];
+  }
   red[threadIdx.x] = sum;
   __syncthreads();
   if (pl == 0 && idx < per) {

@@ -604,19 +604,32 @@ __global__ __launch_bounds__(256) void dy_db_reduce_kernel(const float *__restri
   if (threadIdx.x == 0) db[n] = (float)red[0];
 }
 
-__global__ void slab_reduce_x3_kernel(const float *__restrict__ slab, float *__restrict__ out, int64_t rows, int64_t cols,
-                                      int64_t ldo, int splits) {
-  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= rows * cols) return;
-  float s = 0.f;  // fixed order; four slabs in flight
+// out = sum over the split-K slabs, in a FIXED order (bit-reproducible): a workgroup owns 64 outputs, its four 64-lane groups
+// each walk every fourth slab with eight loads in flight, and the four partial sums are combined in lane-group order.  (One
+// thread per output walking all 110-384 slabs four at a time was a latency chain: 46-110 us per call on the main stream.)
+__global__ __launch_bounds__(256) void slab_reduce_x3_kernel(const float *__restrict__ slab, float *__restrict__ out, int64_t rows,
+                                                             int64_t cols, int64_t ldo, int splits) {
   const int64_t st = rows * cols;
-  int z = 0;
-  for (; z + 4 <= splits; z += 4) {
-    const float a = slab[z * st + idx], b = slab[(z + 1) * st + idx], c = slab[(z + 2) * st + idx], d = slab[(z + 3) * st + idx];
-    s = (((s + a) + b) + c) + d;
+  const int64_t idx = (int64_t)blockIdx.x * 64 + (threadIdx.x & 63);
+  const int pl = threadIdx.x >> 6;
+  const int64_t ic = idx < st ? idx : st - 1;      // (clamped: every lane loads, only valid ones store)
+  float s = 0.f;
+  int z = pl;
+  for (; z + 28 < splits; z += 32) {               // slabs z, z + 4, ..., z + 28
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = slab[(int64_t)(z + 4 * u) * st + ic];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += v[u];
   }
-  for (; z < splits; ++z) s += slab[z * st + idx];
-  out[(idx / cols) * ldo + (idx % cols)] = s;
+  for (; z < splits; z += 4) s += slab[(int64_t)z * st + ic];
+  __shared__ float red[256];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  if (pl == 0 && idx < st) {
+    const int t = threadIdx.x;
+    out[(idx / cols) * ldo + (idx % cols)] = ((red[t] + red[t + 64]) + red[t + 128]) + red[t + 192];
+  }
 }
 
 int tn_splits(int64_t M, int64_t N, int64_t K, int64_t *rows_per_split) {
@@ -696,13 +709,13 @@ extern "C" int svr_linear_bwd_weight_bf16x3(const float *dY, int64_t lddy, const
     else
       hipLaunchKernelGGL(linear_tn_x3_tr_kernel<1>, grid, dim3(256), 0, s, dY, lddy, X, ldx, slab, db ? dbpart : nullptr, M, N, K,
                          rps, splits);
-    hipLaunchKernelGGL(slab_reduce_x3_kernel, dim3((unsigned)cdiv(N * K, 256)), dim3(256), 0, s, slab, dW, N, K, lddw, splits);
+    hipLaunchKernelGGL(slab_reduce_x3_kernel, dim3((unsigned)cdiv(N * K, 64)), dim3(256), 0, s, slab, dW, N, K, lddw, splits);
     if (db) hipLaunchKernelGGL(dy_db_reduce_kernel, dim3((unsigned)N), dim3(256), 0, s, dbpart, db, N, (int64_t)splits);
     return launch_status("linear_bwd_weight_bf16x3");
   }
   hipLaunchKernelGGL(dy_planes_kernel, dim3((unsigned)parts), dim3(256), 0, s, dY, lddy, ph, pm, Mpad, M, N, db ? dbpart : nullptr);
   hipLaunchKernelGGL(linear_tn_x3_kernel, grid, dim3(256), 0, s, ph, pm, Mpad, X, ldx, slab, M, N, K, rps, splits);
-  hipLaunchKernelGGL(slab_reduce_x3_kernel, dim3((unsigned)cdiv(N * K, 256)), dim3(256), 0, s, slab, dW, N, K, lddw, splits);
+  hipLaunchKernelGGL(slab_reduce_x3_kernel, dim3((unsigned)cdiv(N * K, 64)), dim3(256), 0, s, slab, dW, N, K, lddw, splits);
   if (db) hipLaunchKernelGGL(dy_db_reduce_kernel, dim3((unsigned)N), dim3(256), 0, s, dbpart, db, N, parts);
   return launch_status("linear_bwd_weight_bf16x3");
 }
