@@ -210,6 +210,7 @@ def main():
     ap.add_argument("--no-fwd-only", action="store_true")
     ap.add_argument("--no-query", action="store_true", help="skip the query-path (f32 / bf16 storage / lattice) measurement")
     ap.add_argument("--no-diag", action="store_true", help="skip the untimed single-stream steps behind the timed region")
+    ap.add_argument("--no-f32-backward", action="store_true", help="skip the extra steps with the exact-f32 backward kernels")
     ap.add_argument("--alloc-trace", action="store_true",
                     help="record the caching allocator's history over the timed region and report the call sites of every hipMalloc")
     ap.add_argument("--backward", choices=["production", "f32"], default="production",
@@ -343,7 +344,7 @@ def main():
     # what the step costs WITHOUT the bf16x3 split in the backward: a few extra steps behind the timed
     # region with the backward GEMMs / convolutions on the exact-f32 MFMA kernels (rank 0's clock; never the headline)
     f32_bwd_ms = None
-    if not a.no_diag and a.backward == "production":
+    if not a.no_diag and not a.no_f32_backward and a.backward == "production":
         prev = (ops.BACKWARD_GEMM, ops.BACKWARD_CONV, ops.BACKWARD_CONV_WEIGHT)
         ops.BACKWARD_GEMM = ops.BACKWARD_CONV = ops.BACKWARD_CONV_WEIGHT = "f32"
         try:

@@ -346,6 +346,14 @@ class _EncoderGatherFn(torch.autograd.Function):
                 proj = ctx.link.levels if ctx.link is not None else ()
                 ctx.gvols = [None] + [None if l in proj else _gvol(arena, l, v, zero=ctx.level_plans[l] is None)
                                       for l, v in enumerate(levels) if l >= 1]
+                # ... and the zeroed (voxel, displacement, 256) slabs the projected levels' atomic scatter accumulates into
+                ctx.dP = {}
+                if arena is not None:
+                    for l in proj:
+                        if not isinstance(ctx.level_orders[l], ops.ProjPlan):      # (the two-pass form overwrites its own)
+                            v = levels[l]
+                            ctx.dP[l] = arena.get(f"dP{l}", (B, v.shape[1] * v.shape[2] * v.shape[3], 7, 256), torch.float32,
+                                                  x.device).zero_()
                 if arena is None:
                     for g in ctx.gvols[1:]:
                         if g is not None:
@@ -479,6 +487,7 @@ class _EncoderGatherFn(torch.autograd.Function):
                 scatter_level(split)
         dw0p = None
         p_stream = None
+        dPs, ctx.dP = (getattr(ctx, "dP", None) or {}), None
         if proj:
             # projected levels: dP = scatter of the dh0 rows, then two GEMMs over voxels (see gather_bwd_proj_kernel)
             lay, w0p, dh0 = ext._layout, ctx.w0p, link.dh0
@@ -491,7 +500,7 @@ class _EncoderGatherFn(torch.autograd.Function):
                 v = levels[l]
                 B_, Dl, Hl, Wl, Cl = v.shape
                 c0 = lay.col[l]
-                dP = ops.gather_project_bwd(pts, dh0, (Dl, Hl, Wl), level_orders[l], ext._disp, ext._align)
+                dP = ops.gather_project_bwd(pts, dh0, (Dl, Hl, Wl), level_orders[l], ext._disp, ext._align, out=dPs.get(l))
                 dP2 = dP.view(B_ * Dl * Hl * Wl, 7 * 256)
                 wl = w0p[:, c0:c0 + 7 * Cl].reshape(256, 7, Cl).permute(1, 0, 2).reshape(7 * 256, Cl).contiguous()   # rows (j, n)
                 gvols[l] = ops.linear_bwd_data(dP2, wl).view(v.shape)

@@ -225,7 +225,7 @@ def project_plan(points, dims, displacement, align_corners=False):
     return ProjPlan(items, keys, sidx, first_slot, int(l.svr_gather_project_slots(B, N, dims[0], dims[1], dims[2])))
 
 
-def gather_project_bwd(points, dh, dims, items, displacement, align_corners=False):
+def gather_project_bwd(points, dh, dims, items, displacement, align_corners=False, out=None):
     """dP (B, D*H*W, 7, 256) = scatter of the 256-wide rows of dh (B*N, >= 256) with the trilinear weights of every
     (point, displacement) item; `items` = item_order(..., with_j=True) (float atomics into a zeroed dP) or a ProjPlan
     (two passes, no atomics, dP written once, bit-reproducible)."""
@@ -246,7 +246,9 @@ def gather_project_bwd(points, dh, dims, items, displacement, align_corners=Fals
                                                  dims[2], int(align_corners), displacement, _p(plan.items), _p(plan.sidx),
                                                  _p(plan.first_slot), _p(partials), _p(dP), _stream()), "gather_project_bwd2")
         return dP
-    dP = torch.zeros(B, dims[0] * dims[1] * dims[2], 7, 256, device=points.device, dtype=torch.float32)
+    # out: a ZEROED (B, D*H*W, 7, 256) buffer of the caller (the training step zero-fills it on the side stream during the forward)
+    dP = out if out is not None else torch.zeros(B, dims[0] * dims[1] * dims[2], 7, 256, device=points.device, dtype=torch.float32)
+    assert tuple(dP.shape) == (B, dims[0] * dims[1] * dims[2], 7, 256) and dP.is_contiguous()
     check(_lib.lib().svr_gather_project_bwd(_p(points), C.c_void_p(dh.data_ptr()), dh.stride(0), B, N, dims[0], dims[1], dims[2],
                                             int(align_corners), displacement, _p(items), _p(dP), _stream()), "gather_project_bwd")
     return dP

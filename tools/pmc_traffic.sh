@@ -13,7 +13,7 @@ TAG=${1:-r03}; shift || true
 for C in FETCH_SIZE WRITE_SIZE; do
   rm -rf "$R/gpurun_out/pmc_traffic_$C"
   timeout -k 10 420 rocprofv3 --kernel-trace --pmc $C --output-format csv -d "$R/gpurun_out/pmc_traffic_$C" -o p -- \
-      python3 "$R/bench.py" --no-cpu-baseline --no-fwd-only --no-query --steps 2 --warmup 1 "$@" > "$R/gpurun_out/pmc_traffic_$C.log" 2>&1
+      python3 "$R/bench.py" --no-cpu-baseline --no-fwd-only --no-query --no-f32-backward --steps 2 --warmup 1 "$@" > "$R/gpurun_out/pmc_traffic_$C.log" 2>&1
   rc=$?
   if [ $rc -ne 0 ]; then
     echo "pmc_traffic: rocprofv3 --pmc $C failed (rc=$rc)"; tail -15 "$R/gpurun_out/pmc_traffic_$C.log"; exit 1
