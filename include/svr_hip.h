@@ -338,6 +338,13 @@ int64_t svr_conv3d_fwd_f16x3_workspace(int32_t Ci, int32_t Co);
 int svr_conv3d_k3_fwd_f16x3(const float *in, const float *W, const float *bias, float *out, int32_t B,
                              int32_t D, int32_t H, int32_t Wd, int32_t Ci, int32_t Co, int epilogue,
                              void *workspace, void *stream);
+/* ... + the BatchNorm statistics of `out` from the kernel's epilogue: part[blocks][2][Co] float64 partial sums (sum, sum of
+ * squares of the stored values), blocks = svr_conv3d_fwd_f16x3_stats_blocks(same shape); finish with svr_bn_finalize_parts.
+ * (model/ifnet.py:170-172 etc.: the last convolution of a stage -> ReLU -> BatchNorm3d.)                              */
+int32_t svr_conv3d_fwd_f16x3_stats_blocks(int32_t B, int32_t D, int32_t H, int32_t Wd, int32_t Ci, int32_t Co);
+int svr_conv3d_k3_fwd_f16x3_stats(const float *in, const float *W, const float *bias, float *out, double *part, int32_t B,
+                                  int32_t D, int32_t H, int32_t Wd, int32_t Ci, int32_t Co, int epilogue,
+                                  void *workspace, void *stream);
 /* Backward-data on the bf16 matrix cores with the 3-term split (see svr_linear_bwd_data_bf16x3):
  * din(B,D,H,W,Ci) = epi( conv^T(dout(B,D,H,W,Co), W(Co,Ci,3,3,3)) ), epilogue NONE or MASK (mask like din).
  * Takes the UNPACKED weights; workspace: svr_conv3d_bwd_data_bf16x3_workspace(Ci, Co) bytes.  Ci even.   */
@@ -377,6 +384,11 @@ int svr_bn_stats(const float *x, double *stats, int64_t rows /*B*D*H*W*/, int32_
 int svr_bn_stats_finalize(const float *x, double *stats, const float *gamma, const float *beta, float *running_mean,
                           float *running_var, float *scale_shift, float *mean_f32, int64_t rows, int32_t C,
                           float eps, float momentum, void *workspace, void *stream);
+/* The same from per-workgroup partial sums part[blocks][2][C] (float64 sum / sum of squares of the BatchNorm's input, left by
+ * svr_conv3d_k3_fwd_f16x3_stats): no pass over the tensor at all.                                                   */
+int svr_bn_finalize_parts(const double *part, int32_t blocks, double *stats, const float *gamma, const float *beta,
+                          float *running_mean, float *running_var, float *scale_shift, float *mean_f32, int64_t rows,
+                          int32_t C, float eps, float momentum, void *stream);
 /* scale_shift[0:C] = gamma*invstd, [C:2C] = beta - mean*gamma*invstd, [2C:3C] = invstd (f32);
  * training != 0 also updates running_mean/var (momentum, unbiased var) like torch.          */
 int svr_bn_finalize(const double *stats, const float *gamma, const float *beta, float *running_mean,

@@ -93,6 +93,8 @@ SIGNATURES = {
     "svr_conv3d_k3_fwd_bf16x6": (C.c_int, [P, P, P, P, I32, I32, I32, I32, I32, I32, C.c_int, P, P]),
     "svr_conv3d_fwd_f16x3_workspace": (I64, [I32, I32]),
     "svr_conv3d_k3_fwd_f16x3": (C.c_int, [P, P, P, P, I32, I32, I32, I32, I32, I32, C.c_int, P, P]),
+    "svr_conv3d_fwd_f16x3_stats_blocks": (I32, [I32, I32, I32, I32, I32, I32]),
+    "svr_conv3d_k3_fwd_f16x3_stats": (C.c_int, [P, P, P, P, P, I32, I32, I32, I32, I32, I32, C.c_int, P, P]),
     "svr_conv3d_bwd_data_bf16x3_workspace": (I64, [I32, I32]),
     "svr_conv3d_k3_bwd_data_bf16x3": (C.c_int, [P, P, P, I32, I32, I32, I32, I32, I32, C.c_int, P, P, P]),
     "svr_conv3d_c1_fwd_stats_workspace": (I64, [I32, I32, I32, I32, I32]),
@@ -105,6 +107,7 @@ SIGNATURES = {
     "svr_bn_stats_workspace": (I64, [I64, I32]),
     "svr_bn_stats": (C.c_int, [P, P, I64, I32, P, P]),
     "svr_bn_stats_finalize": (C.c_int, [P, P, P, P, P, P, P, P, I64, I32, F32, F32, P, P]),
+    "svr_bn_finalize_parts": (C.c_int, [P, I32, P, P, P, P, P, P, P, I64, I32, F32, F32, P]),
     "svr_bn_finalize": (C.c_int, [P, P, P, P, P, P, P, I64, I32, F32, F32, C.c_int, P]),
     "svr_bn_apply_pool": (C.c_int, [P, P, P, P, P, I32, I32, I32, I32, I32, P]),
     "svr_bn_bwd_reduce": (C.c_int, [P, P, P, P, P, P, P, I32, I32, I32, I32, I32, P, P]),

@@ -400,6 +400,17 @@ extern "C" int svr_bn_stats_finalize(const float *x, double *stats, const float 
   return launch_status("bn_stats_finalize");
 }
 
+// Finalize from per-workgroup partial sums part[blocks][2][C] (sum, sum of squares; what svr_conv3d_k3_fwd_f16x3_stats and
+// svr_conv3d_c1_fwd_stats' kernels leave): mean / biased variance (stats, may be NULL) + svr_bn_finalize(training = 1), one launch.
+extern "C" int svr_bn_finalize_parts(const double *part, int32_t blocks, double *stats, const float *gamma, const float *beta,
+                                     float *running_mean, float *running_var, float *scale_shift, float *mean_f32, int64_t rows,
+                                     int32_t C, float eps, float momentum, void *stream) {
+  SVR_CHECK(part && blocks > 0 && scale_shift && mean_f32 && rows > 0 && C > 0, SVR_E_BADARG, "bn_finalize_parts: bad argument");
+  bn_stats_finalize_launch(part, stats, rows, C, blocks, gamma, beta, running_mean, running_var, scale_shift, mean_f32, eps, momentum,
+                           (hipStream_t)stream);
+  return launch_status("bn_finalize_parts");
+}
+
 extern "C" int svr_bn_finalize(const double *stats, const float *gamma, const float *beta, float *running_mean,
                                float *running_var, float *scale_shift, float *mean_f32, int64_t rows, int32_t C, float eps,
                                float momentum, int training, void *stream) {

@@ -124,7 +124,8 @@ __global__ __launch_bounds__(256) void conv3d_brick_x3_kernel(const float *__res
                                                               int64_t plane_stride, const float *__restrict__ bias,
                                                               float *__restrict__ out, const float *__restrict__ mask,
                                                               ConvShape s, int nbz, int nby, int nbx, int mode,
-                                                              const uint32_t *__restrict__ amax = nullptr) {
+                                                              const uint32_t *__restrict__ amax = nullptr,
+                                                              double *__restrict__ spart = nullptr) {
   constexpr int BZ = BRZ * VT, HV = (BZ + 2) * HLY * HLX;  // brick depth and halo voxels of this instantiation
   constexpr int XW = (CK + 4) / 2;           // dwords per LDS row (CK bf16 + 8 B pad)
   constexpr int NC = TNB * 32;               // output columns of this workgroup
@@ -295,6 +296,11 @@ __global__ __launch_bounds__(256) void conv3d_brick_x3_kernel(const float *__res
       if (st + 1 < STEPS) step(st + 1, wregA, wregB);
     }
   }
+  // BatchNorm statistics of what this workgroup stores (spart: per-workgroup partial sums [brick][2][Co] in f64): the
+  // stage's last convolution delivers them and the separate statistics pass over its output disappears
+  float ssum[TNB], ssq[TNB];
+#pragma unroll
+  for (int j = 0; j < TNB; ++j) ssum[j] = ssq[j] = 0.f;
 #pragma unroll
   for (int v = 0; v < VT; ++v)
 #pragma unroll
@@ -325,7 +331,29 @@ __global__ __launch_bounds__(256) void conv3d_brick_x3_kernel(const float *__res
         if (mode == SVR_EPI_BIAS_RELU) val = fmaxf(val, 0.f);
         if (mode == SVR_EPI_MASK) val = mk[r] > 0.f ? val : 0.f;
         out[o] = val;
+        ssum[j] += val;
+        ssq[j] = fmaf(val, val, ssq[j]);
       }
+    }
+  }
+  if (spart) {  // (uniform) lanes l31 / l31 + 32 of the four waves hold the same channel: fixed-order f64 sum of the 8 partials
+    float *red = reinterpret_cast<float *>(&sw[0][0][0][0]);   // the weight buffers are free now: [thread][TNB][2] floats
+    static_assert(sizeof(sw) >= 256 * TNB * 2 * sizeof(float), "weight buffer too small for the statistics reduction");
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < TNB; ++j) {
+      red[(t * TNB + j) * 2] = ssum[j];
+      red[(t * TNB + j) * 2 + 1] = ssq[j];
+    }
+    __syncthreads();
+    if (t < 2 * NC) {
+      const int which = t / NC, col = t % NC, j = col / 32, c31 = col % 32;
+      double acc = 0.0;
+#pragma unroll
+      for (int w = 0; w < 4; ++w)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) acc += (double)red[(((w * 64 + h * 32 + c31) * TNB) + j) * 2 + which];
+      if (n0 + col < s.Co) spart[((int64_t)blockIdx.x * 2 + which) * s.Co + n0 + col] = acc;
     }
   }
 }
@@ -403,9 +431,44 @@ extern "C" int64_t svr_conv3d_fwd_f16x3_workspace(int32_t Ci, int32_t Co) { retu
 
 // out(B,D,H,W,Co) = epi( conv(in(B,D,H,W,Ci), W(Co,Ci,3,3,3)) ) with the 3-product f16 split: f32-level accuracy for
 // |in| < 65504 (see gemm_f16x3.hip); epilogue NONE / BIAS / BIAS_RELU.
+namespace {
+int fwd_f16x3(const float *in, const float *W, const float *bias, float *out, int32_t B, int32_t D, int32_t H, int32_t Wd, int32_t Ci,
+              int32_t Co, int epilogue, void *workspace, void *stream, double *spart, int *blocks);
+}
+
 extern "C" int svr_conv3d_k3_fwd_f16x3(const float *in, const float *W, const float *bias, float *out, int32_t B, int32_t D,
                                        int32_t H, int32_t Wd, int32_t Ci, int32_t Co, int epilogue, void *workspace,
                                        void *stream) {
+  return fwd_f16x3(in, W, bias, out, B, D, H, Wd, Ci, Co, epilogue, workspace, stream, nullptr, nullptr);
+}
+
+// The same convolution + the BatchNorm statistics of its output as per-workgroup partial sums: part[blocks][2][Co] float64
+// (sum, sum of squares), blocks = svr_conv3d_fwd_f16x3_stats_blocks(...); svr_bn_finalize_parts turns them into the
+// BatchNorm's scale / shift / running statistics -- no statistics pass over the output.
+extern "C" int32_t svr_conv3d_fwd_f16x3_stats_blocks(int32_t B, int32_t D, int32_t H, int32_t Wd, int32_t Ci, int32_t Co) {
+  int blocks = 0;
+  (void)fwd_f16x3(nullptr, nullptr, nullptr, nullptr, B, D, H, Wd, Ci, Co, SVR_EPI_NONE, nullptr, nullptr, nullptr, &blocks);
+  return blocks;
+}
+extern "C" int svr_conv3d_k3_fwd_f16x3_stats(const float *in, const float *W, const float *bias, float *out, double *part, int32_t B,
+                                             int32_t D, int32_t H, int32_t Wd, int32_t Ci, int32_t Co, int epilogue,
+                                             void *workspace, void *stream) {
+  SVR_CHECK(in && part, SVR_E_BADARG, "conv3d_fwd_f16x3_stats: null pointer");
+  return fwd_f16x3(in, W, bias, out, B, D, H, Wd, Ci, Co, epilogue, workspace, stream, part, nullptr);
+}
+
+namespace {
+int fwd_f16x3(const float *in, const float *W, const float *bias, float *out, int32_t B, int32_t D, int32_t H, int32_t Wd, int32_t Ci,
+              int32_t Co, int epilogue, void *workspace, void *stream, double *spart, int *blocks) {
+  if (blocks) {   // query: the number of workgroup rows (= partial-sum rows) of the variant this shape takes
+    const int nbz = (int)cdiv(D, BRZ), nby = (int)cdiv(H, BRY), nbx = (int)cdiv(Wd, BRX);
+    const int64_t bricks = (int64_t)B * nbz * nby * nbx;
+    int tn = Co <= 32 ? 1 : (Co <= 64 ? 2 : 4);
+    while (tn > 1 && bricks * cdiv(Co, tn * 32) < 512) tn /= 2;
+    const int nbz2 = (int)cdiv(D, 2 * BRZ);
+    *blocks = (tn == 1 && (int64_t)B * nbz2 * nby * nbx * cdiv(Co, 32) >= 512) ? (int)((int64_t)B * nbz2 * nby * nbx) : (int)bricks;
+    return SVR_OK;
+  }
   // in == NULL: PREPARE only (W -> scale + split planes in the workspace);  W == NULL: RUN on a workspace prepared earlier
   SVR_CHECK((in || W) && (!in || out) && workspace, SVR_E_BADARG, "conv3d_fwd_f16x3: null pointer");
   SVR_CHECK(Ci % 16 == 0 && Co >= 1, SVR_E_UNSUPPORTED, "conv3d_fwd_f16x3: need Ci %% 16 == 0 (Ci=%d Co=%d)", Ci, Co);
@@ -427,13 +490,13 @@ extern "C" int svr_conv3d_k3_fwd_f16x3(const float *in, const float *W, const fl
   const unsigned bricks = (unsigned)((int64_t)B * nbz * nby * nbx);
 #define LAUNCH_H3(CKV, TNV)                                                                                                 \
   hipLaunchKernelGGL((conv3d_brick_x3_kernel<CKV, TNV, 2, true>), dim3(bricks, (unsigned)cdiv(Co, TNV * 32)), dim3(256), 0, s, \
-                     in, p0, ps, bias, out, (const float *)nullptr, sh, nbz, nby, nbx, epilogue, amax)
+                     in, p0, ps, bias, out, (const float *)nullptr, sh, nbz, nby, nbx, epilogue, amax, spart)
   int tn = Co <= 32 ? 1 : (Co <= 64 ? 2 : 4);
   while (tn > 1 && (int64_t)bricks * cdiv(Co, tn * 32) < 512) tn /= 2;   // see svr_conv3d_k3_bwd_data_bf16x3
   const int nbz2 = (int)cdiv(D, 2 * BRZ);
   if (tn == 1 && (int64_t)B * nbz2 * nby * nbx * cdiv(Co, 32) >= 512) {  // two z-slices per wave (8x4x8 bricks, 16-channel chunks)
     hipLaunchKernelGGL((conv3d_brick_x3_kernel<16, 1, 2, true, 2>), dim3((unsigned)((int64_t)B * nbz2 * nby * nbx), (unsigned)cdiv(Co, 32)),
-                       dim3(256), 0, s, in, p0, ps, bias, out, (const float *)nullptr, sh, nbz2, nby, nbx, epilogue, amax);
+                       dim3(256), 0, s, in, p0, ps, bias, out, (const float *)nullptr, sh, nbz2, nby, nbx, epilogue, amax, spart);
   } else if (Ci % 32 == 0) {
     if (tn == 1) LAUNCH_H3(32, 1); else if (tn == 2) LAUNCH_H3(32, 2); else LAUNCH_H3(32, 4);
   } else {
@@ -442,3 +505,4 @@ extern "C" int svr_conv3d_k3_fwd_f16x3(const float *in, const float *W, const fl
 #undef LAUNCH_H3
   return launch_status("conv3d_fwd_f16x3");
 }
+}  // namespace

@@ -197,6 +197,8 @@ PREPARE_WEIGHTS_AHEAD = os.environ.get("SVR_NO_WEIGHT_PREP") is None
 FORK_SPLIT_LEVEL = int(os.environ.get("SVR_FORK_SPLIT_LEVEL", "3"))
 # Per-level events instead of one join in front of the encoder's backward (SVR_NO_FORK_PIPELINE=1: the single join)
 FORK_PIPELINED = os.environ.get("SVR_NO_FORK_PIPELINE") is None
+# BatchNorm statistics of stages 2..5 from the epilogue of the stage's last convolution (SVR_NO_CONV_STATS=1: a separate pass)
+STATS_IN_CONV_EPILOGUE = os.environ.get("SVR_NO_CONV_STATS") is None
 # The step's large cross-stream buffers live in a per-module StepArena (arena.py); SVR_NO_ARENA=1: ordinary allocations
 USE_ARENA = os.environ.get("SVR_NO_ARENA") is None
 
@@ -313,6 +315,9 @@ class _EncoderGatherFn(torch.autograd.Function):
                 if training and len(convs) == 1 and conv.weight.shape[1] == 1 and conv.weight.shape[0] in (16, 32):
                     # conv_in: the statistics of the BatchNorm that follows come out of the conv kernel's epilogue
                     cur, stats = ops.conv3d_c1_fwd_stats(cur, conv.weight.detach(), conv.bias.detach(), relu=True)
+                elif training and conv is convs[-1] and STATS_IN_CONV_EPILOGUE:
+                    # the stage's last convolution: its epilogue also leaves the BatchNorm's partial sums (no statistics pass)
+                    cur, stats = ops.conv3d_k3_fwd(cur, conv.weight.detach(), conv.bias.detach(), relu=True, want_stats=True)
                 else:
                     cur = ops.conv3d_k3_fwd(cur, conv.weight.detach(), conv.bias.detach(), relu=True)
                 acts.append(cur)

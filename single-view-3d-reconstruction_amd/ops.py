@@ -782,8 +782,17 @@ BACKWARD_CONV = "bf16x3"
 FORWARD_CONV = "f16x3"
 
 
-def conv3d_k3_fwd(x, w, bias, relu=True, mode=None):
-    """relu(conv(x (B,D,H,W,Ci), w (Co,Ci,3,3,3)) + bias) -> (B,D,H,W,Co)."""
+class StatParts:
+    """Per-workgroup partial sums (sum, sum of squares; float64 [blocks][2][C]) of a tensor a kernel has just written: the
+    BatchNorm that follows finalizes from them (bn_forward(stats=...)) instead of reading the tensor again."""
+
+    def __init__(self, part, blocks):
+        self.part, self.blocks = part, blocks
+
+
+def conv3d_k3_fwd(x, w, bias, relu=True, mode=None, want_stats=False):
+    """relu(conv(x (B,D,H,W,Ci), w (Co,Ci,3,3,3)) + bias) -> (B,D,H,W,Co).  want_stats: -> (out, StatParts or None): the
+    BatchNorm statistics of the output come out of the kernel's epilogue where the f16x3 kernel runs."""
     _f32(x, w, bias)
     B, D, H, W, Ci = x.shape
     Co = w.shape[0]
@@ -794,9 +803,18 @@ def conv3d_k3_fwd(x, w, bias, relu=True, mode=None):
         wptr = C.c_void_p(0) if ws is not None else _p(w)                          # W NULL: the workspace is prepared
         if ws is None:
             ws = torch.empty(l.svr_conv3d_fwd_f16x3_workspace(Ci, Co), device=x.device, dtype=torch.uint8)
-        check(l.svr_conv3d_k3_fwd_f16x3(_p(x), wptr, _p(bias), _p(out), B, D, H, W, Ci, Co,
-                                        EPI_BIAS_RELU if relu else EPI_BIAS, _p(ws), _stream()), "conv3d_fwd_f16x3")
+        epi = EPI_BIAS_RELU if relu else EPI_BIAS
+        if want_stats:
+            blocks = l.svr_conv3d_fwd_f16x3_stats_blocks(B, D, H, W, Ci, Co)
+            part = torch.empty(blocks, 2, Co, device=x.device, dtype=torch.float64)
+            check(l.svr_conv3d_k3_fwd_f16x3_stats(_p(x), wptr, _p(bias), _p(out), _p(part), B, D, H, W, Ci, Co, epi, _p(ws),
+                                                  _stream()), "conv3d_fwd_f16x3_stats")
+            return out, StatParts(part, blocks)
+        check(l.svr_conv3d_k3_fwd_f16x3(_p(x), wptr, _p(bias), _p(out), B, D, H, W, Ci, Co, epi, _p(ws), _stream()),
+              "conv3d_fwd_f16x3")
         return out
+    if want_stats:
+        return conv3d_k3_fwd(x, w, bias, relu, mode), None
     if (mode or FORWARD_CONV) == "bf16x6" and Ci % 16 == 0:
         l = _lib.lib()
         out = torch.empty(B, D, H, W, Co, device=x.device, dtype=torch.float32)
@@ -895,7 +913,10 @@ def bn_forward(x, gamma, beta, running_mean, running_var, training, eps=1e-5, mo
     dev = x.device
     ss = torch.empty(3 * Cc, device=dev, dtype=torch.float32)
     mean = torch.empty(Cc, device=dev, dtype=torch.float32)
-    if training and stats is None:      # statistics + finalize: two launches
+    if training and isinstance(stats, StatParts):      # partial sums from the producing kernel's epilogue: one launch
+        check(l.svr_bn_finalize_parts(_p(stats.part), stats.blocks, C.c_void_p(0), _p(gamma), _p(beta), _p(running_mean),
+                                      _p(running_var), _p(ss), _p(mean), rows, Cc, eps, momentum, _stream()), "bn_finalize_parts")
+    elif training and stats is None:      # statistics + finalize: two launches
         ws = torch.empty(l.svr_bn_stats_workspace(rows, Cc), device=dev, dtype=torch.uint8)
         check(l.svr_bn_stats_finalize(_p(x), C.c_void_p(0), _p(gamma), _p(beta), _p(running_mean), _p(running_var), _p(ss), _p(mean),
                                       rows, Cc, eps, momentum, _p(ws), _stream()), "bn_stats_finalize")

@@ -720,3 +720,36 @@ def test_prepared_weight_planes_give_the_same_bits_and_expire():
         assert prep.lookup("lf", wl) is None
     finally:
         ops.set_prepared(None)
+
+
+@pytest.mark.parametrize("B,dims,Ci,Co", [(2, (10, 6, 12), 16, 32), (1, (9, 9, 9), 32, 32), (2, (7, 5, 6), 32, 64), (1, (6, 6, 6), 64, 64),
+                                          (2, (4, 5, 6), 64, 128), (8, (16, 16, 16), 32, 32)])
+def test_conv_epilogue_batchnorm_statistics(B, dims, Ci, Co):
+    """svr_conv3d_k3_fwd_f16x3_stats + svr_bn_finalize_parts: the BatchNorm that follows a stage's last convolution gets its
+    statistics from the convolution kernel's epilogue (per-workgroup f64 partial sums of the values it stores).  Same output
+    bits as the plain call; BatchNorm output, pooled output and running statistics equal the separate statistics pass to f32
+    rounding (both sum in f64, in different orders); odd volumes (partial bricks) and every tile variant."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(Ci + Co + B)
+    x = torch.randn(B, *dims, Ci, generator=g).cuda()
+    w = (torch.randn(Co, Ci, 3, 3, 3, generator=g) / (27 * Ci) ** 0.5).cuda()
+    b = torch.randn(Co, generator=g).cuda()
+    gamma, beta = (torch.rand(Co, generator=g) + 0.5).cuda(), (torch.rand(Co, generator=g) - 0.5).cuda()
+    y0 = ops.conv3d_k3_fwd(x, w, b, relu=True)
+    y1, st = ops.conv3d_k3_fwd(x, w, b, relu=True, want_stats=True)
+    assert st is not None and torch.equal(y0, y1)
+    n = B * dims[0] * dims[1] * dims[2]
+    sums = st.part.sum(0)                                             # (2, Co) float64
+    ref = y0.double().reshape(-1, Co)
+    assert G.rel_err(sums[0].cpu().numpy(), ref.sum(0).cpu().numpy()) < 1e-6
+    assert G.rel_err(sums[1].cpu().numpy(), (ref * ref).sum(0).cpu().numpy()) < 1e-6
+    pool = min(dims) >= 2
+    rm0, rv0 = torch.zeros(Co).cuda(), torch.ones(Co).cuda()
+    rm1, rv1 = torch.zeros(Co).cuda(), torch.ones(Co).cuda()
+    a0 = ops.bn_forward(y0, gamma, beta, rm0, rv0, True, want_pool=pool)
+    a1 = ops.bn_forward(y1, gamma, beta, rm1, rv1, True, want_pool=pool, stats=st)
+    assert G.rel_err(a1[0].cpu().numpy(), a0[0].cpu().numpy()) < 1e-6
+    if pool:
+        assert G.rel_err(a1[1].cpu().numpy(), a0[1].cpu().numpy()) < 1e-6
+    assert G.rel_err(rm1.cpu().numpy(), rm0.cpu().numpy()) < 1e-6 and G.rel_err(rv1.cpu().numpy(), rv0.cpu().numpy()) < 1e-6
+    assert G.rel_err(a1[3].cpu().numpy(), a0[3].cpu().numpy()) < 1e-6 and abs(n - B * dims[0] * dims[1] * dims[2]) == 0
