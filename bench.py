@@ -441,6 +441,24 @@ def main():
                                 "workload": f"one sample, {a.grid}^3 lattice incl. the +-0.5 planes (model/ifnet.py:202-229), "
                                             f"{chunk}-point chunks, cached pyramid, fc_0 prepared once, sigmoid, values on device"}
             del levels, lat
+            # BASELINE configs[1] as stated: 64^3 grid, 10 000 points, batch 4, bf16 storage, gather + MLP kernels only
+            g1 = torch.Generator(device="cpu").manual_seed(102)
+            x1 = (torch.rand(4, 1, 64, 64, 64, generator=g1) < 0.05).float().to(dev)
+            p1 = (torch.rand(4, 10000, 3, generator=g1) - 0.5).to(dev)
+            lv1 = net.encode(x1, "bf16")
+            prep1 = net.prepare_query(lv1, 10000)
+            net.query(lv1, p1, spatial_sort=True, prepared=prep1)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            reps1 = 20
+            for _ in range(reps1):
+                net.query(lv1, p1, spatial_sort=True, prepared=prep1)
+            torch.cuda.synchronize()
+            ms1 = (time.perf_counter() - t1) / reps1 * 1e3
+            query["config1_bf16"] = {"ms": ms1, "points": 40000, "value": 40000 / (ms1 * 1e-3), "unit": "query-points/s",
+                                     "workload": "BASELINE configs[1]: 64^3 pyramid (batch 4) in bf16 storage, 10 000 points per sample, "
+                                                 "Morton sort + fused gather -> fc_0 + fc_1, fc_2, fc_out; launch bound at this size"}
+            del lv1, prep1
         zf, zb = query["f32"].pop("logits"), query["bf16"].pop("logits")
         query["bf16"]["logits_rel_dev_vs_f32_storage"] = float((zb - zf).abs().max() / zf.abs().max())
     if launched:
@@ -596,6 +614,7 @@ def report(a, world, dt, loss, step_ms, host_ms, kt, kd, ranks, forms, fwd_ms, q
         res["query_path"] = {"workload": f"cached {a.grid}^3 pyramid (batch {a.batch}), {npts} query points per pass: 6-level "
                                          "trilinear gather + point MLP forward, no grad, points visited in Morton order (dense-grid inference kernels)",
                              "dtype_f32": query["f32"], "dtype_bf16": query["bf16"], "lattice": query.get("lattice"),
+                             "config1_bf16": query.get("config1_bf16"),
                              "note": "bf16 = separately named bf16-STORAGE mode (bf16 volumes / feature rows / activations, "
                                      "f32 accumulation; never the default, not held to the fp32 1e-4 gate)"}
     kernels = []

@@ -20,7 +20,7 @@ for path in sys.argv[1:]:
     print("  roofline", {k: r.get(k) for k in ("ms_per_launch", "ms_per_launch_stats", "ms_per_launch_single_stream", "frac",
                                               "traffic_over_compulsory", "mfma_frac_of_f16_peak")})
     q = d.get("query_path") or {}
-    for k in ("dtype_f32", "dtype_bf16", "lattice"):
+    for k in ("dtype_f32", "dtype_bf16", "lattice", "config1_bf16"):
         if q.get(k):
             print("  query", k, {a: (round(b, 3) if isinstance(b, float) else b) for a, b in q[k].items() if a not in ("workload",)})
     for k in d.get("roofline_kernels", []):
