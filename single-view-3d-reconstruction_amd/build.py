@@ -24,7 +24,7 @@ SOURCES = {
     "gemm_f16x3.hip": [],
     "conv3d.hip": [],
     "conv3d_bf16.hip": [f"-DSVR_CONV_EXP={os.environ['SVR_CONV_EXP']}"] if os.environ.get("SVR_CONV_EXP") else [],   # measurement builds
-    "conv3d_bwdw_bf16.hip": [],
+    "conv3d_bwdw_bf16.hip": [f"-DSVR_WG_EXP={os.environ['SVR_WG_EXP']}"] if os.environ.get("SVR_WG_EXP") else [],   # measurement builds
     "bn_pool.hip": [],
     "stage1.hip": [f"-DS1_EXP={os.environ['SVR_S1_EXP']}"] if os.environ.get("SVR_S1_EXP") else [],   # measurement builds
     "projection.hip": ["-ffp-contract=off"],
@@ -59,17 +59,23 @@ def build(force=False, verbose=False):
     os.makedirs(objdir, exist_ok=True)
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     headers.append(os.path.join(INCLUDE, "svr_hip.h"))
-    objs, procs = [], []
+    objs, procs, cmd_of = [], [], {}
     for src, extra in SOURCES.items():
         path = os.path.join(CSRC, src)
         if not os.path.exists(path):
             continue
         obj = os.path.join(objdir, src.rsplit(".", 1)[0] + ".o")
         objs.append(obj)
-        if force or _stale(obj, [path] + headers):
-            cmd = [_hipcc()] + COMMON + extra + (["-x", "hip"] if src.endswith(".cpp") else []) + ["-c", path, "-o", obj]
+        cmd = [_hipcc()] + COMMON + extra + (["-x", "hip"] if src.endswith(".cpp") else []) + ["-c", path, "-o", obj]
+        # an object built with other flags (a measurement build, SVR_*_EXP) is stale even if the source did not change
+        flagfile = obj[:-2] + ".flags"
+        same_flags = os.path.exists(flagfile) and open(flagfile).read() == " ".join(cmd)
+        if force or not same_flags or _stale(obj, [path] + headers):
+            if os.path.exists(flagfile):
+                os.remove(flagfile)
             if verbose:
                 print(" ".join(cmd), file=sys.stderr)
+            cmd_of[obj] = cmd
             procs.append((src, obj, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
     for src, obj, p in procs:
         out, _ = p.communicate()
@@ -77,6 +83,8 @@ def build(force=False, verbose=False):
             raise RuntimeError(f"hipcc failed on {src}:\n{out.decode(errors='replace')}")
         with open(obj[:-2] + ".log", "wb") as f:
             f.write(out)
+        with open(obj[:-2] + ".flags", "w") as f:
+            f.write(" ".join(cmd_of[obj]))
     if force or procs or _stale(LIB, objs):
         cmd = [_hipcc(), "-shared", "-fPIC", "--offload-arch=gfx950", "-o", LIB] + objs + ["-lz"]
         r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)

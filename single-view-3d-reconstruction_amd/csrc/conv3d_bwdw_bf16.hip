@@ -11,11 +11,13 @@
 //   x = hi + mid, products mid*hi + hi*mid + hi*hi, f32 accumulation (~1.5e-5 relative per product; the weight
 //   gradient sums 10^4..10^6 such products of mixed sign, see gemm_bf16x3.hip for the error argument).
 //
-// Workgroup = 6 waves, persistent over bricks: wave (dz, h) owns the 9 taps of one dz for half of the brick's
-// voxels (h), 9 accumulator tiles (32 ci x 32 co) stay in registers over all bricks; the two halves and the
-// workgroups land in partial slabs that conv3d.hip's ordered f64 reduce sums (deterministic).  LDS is double
-// buffered: the next brick's global loads are issued before the MFMA phase and written to the other buffer
-// after it, one barrier per brick.  73 KB per buffer -> one workgroup per CU.
+// Workgroup = 8 waves, persistent over bricks: wave (g, h) owns the taps 7g .. 7g+6 (g = 3: six taps) for half of the
+// brick's voxels (h), its 7 accumulator tiles (32 ci x 32 co) stay in registers over all bricks; the two halves and the
+// workgroups land in partial slabs that conv3d.hip's ordered f64 reduce sums (deterministic).  (Until round 3: 6 waves
+// = 3 dz x 2 halves with 9 tiles each -- two of the four SIMDs carried two waves, the other two one, and the barrier
+// per brick waited for the loaded pair: 6 912 MFMA cycles per brick on the critical SIMD instead of 5 376 now.)
+// LDS is double buffered: the next brick's global loads are issued before the MFMA phase and written to the other
+// buffer after it, one barrier per brick.  73 KB per buffer -> one workgroup per CU.
 #include "common.h"
 
 namespace svr {
@@ -46,13 +48,19 @@ constexpr int CIS = HROWS * ROWDW + 2;            // 218 dwords per input channe
 constexpr int COS = BRZ * BRY * 4 + 4;            // 68 dwords per output channel (b128 reads conflict free)
 constexpr int IN_PLANE = 32 * CIS, DO_PLANE = 32 * COS;
 constexpr int BUF = 2 * IN_PLANE + 2 * DO_PLANE;  // dwords per stage: 18 304 (73 216 B)
-constexpr int NT = 384;
+constexpr int NT = 512;
 constexpr int IN_ITEMS = HROWS * 5 * 8;           // (halo row, voxel pair, 4-channel group) = 1440
-constexpr int DO_ITEMS = BRZ * BRY * 4 * 8;       // (row, voxel pair, 4-channel group)      = 512
-constexpr int IN_IT = (IN_ITEMS + NT - 1) / NT;   // 4
-constexpr int DO_IT = (DO_ITEMS + NT - 1) / NT;   // 2
+constexpr int DO_ITEMS = BRZ * BRY * 4 * 8;       // (row, voxel pair, 4-channel group)      = 512: one per thread
+constexpr int IN_IT = (IN_ITEMS + NT - 1) / NT;   // 3: two travel in the first half of a brick's prefetch, one + the dout item in the second
+static_assert(IN_IT == 3 && DO_ITEMS == NT, "prefetch phases below are written for 3 + 1 items per thread");
+constexpr int TAPS_PER_WAVE = 7;                  // 27 taps over 4 tap groups: 7 / 7 / 7 / 6
 
 __device__ __forceinline__ void split2(float x0, float x1, uint32_t &hi, uint32_t &mid) {
+#if defined(SVR_WG_EXP) && SVR_WG_EXP == 3   // measurement build: no split arithmetic
+  hi = __float_as_uint(x0);
+  mid = __float_as_uint(x1);
+  return;
+#endif
   f32x2 v = {x0, x1};
   bf16x2 h = __builtin_convertvector(v, bf16x2);
   hi = __builtin_bit_cast(uint32_t, h);
@@ -67,6 +75,49 @@ __device__ __forceinline__ bf16x8 frag(uint32_t a, uint32_t b, uint32_t c, uint3
   return f.v;
 }
 
+// MFMA phase of one x-row pair (kq) for tap group G: rows R = (dz, dy) pairs touched by the taps 7G .. 7G+6
+template <int G>
+__device__ __forceinline__ void wgrad_rows(const uint32_t *__restrict__ ibuf, const uint32_t *__restrict__ dbuf, int l31, int r,
+                                           f32x16 (&acc)[TAPS_PER_WAVE]) {
+  constexpr int T0 = G * TAPS_PER_WAVE, T1 = (T0 + TAPS_PER_WAVE < 27) ? T0 + TAPS_PER_WAVE : 27;
+  const int vz = r >> 2, vy = r & 3;
+  const uint4 bh = *reinterpret_cast<const uint4 *>(dbuf + l31 * COS + r * 4);
+  const uint4 bm = *reinterpret_cast<const uint4 *>(dbuf + DO_PLANE + l31 * COS + r * 4);
+  const bf16x8 b_hi = frag(bh.x, bh.y, bh.z, bh.w), b_mid = frag(bm.x, bm.y, bm.z, bm.w);
+#pragma unroll
+  for (int R = T0 / 3; R <= (T1 - 1) / 3; ++R) {
+    const int dzi = R / 3, dyi = R % 3;
+    const uint32_t *ph = ibuf + l31 * CIS + ((vz + dzi) * HLY + vy + dyi) * ROWDW;
+    const uint2 m01 = *reinterpret_cast<const uint2 *>(ph + IN_PLANE), m23 = *reinterpret_cast<const uint2 *>(ph + IN_PLANE + 2);
+    const uint32_t m4 = ph[IN_PLANE + 4];
+    const uint2 h01 = *reinterpret_cast<const uint2 *>(ph), h23 = *reinterpret_cast<const uint2 *>(ph + 2);
+    const uint32_t h4 = ph[4];
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) {
+      const int tap = R * 3 + dx;
+      if (tap < T0 || tap >= T1) continue;
+      const int i = tap - T0;
+      // one 24-byte halo row serves the three dx taps: dx = 0 / 2 are dword-aligned sub-rows, dx = 1 a 16-bit funnel shift
+      const bf16x8 am = dx == 0 ? frag(m01.x, m01.y, m23.x, m23.y)
+                      : dx == 2 ? frag(m01.y, m23.x, m23.y, m4)
+                                : frag(__builtin_amdgcn_alignbit(m01.y, m01.x, 16), __builtin_amdgcn_alignbit(m23.x, m01.y, 16),
+                                       __builtin_amdgcn_alignbit(m23.y, m23.x, 16), __builtin_amdgcn_alignbit(m4, m23.y, 16));
+      const bf16x8 ah = dx == 0 ? frag(h01.x, h01.y, h23.x, h23.y)
+                      : dx == 2 ? frag(h01.y, h23.x, h23.y, h4)
+                                : frag(__builtin_amdgcn_alignbit(h01.y, h01.x, 16), __builtin_amdgcn_alignbit(h23.x, h01.y, 16),
+                                       __builtin_amdgcn_alignbit(h23.y, h23.x, 16), __builtin_amdgcn_alignbit(h4, h23.y, 16));
+      // mid plane of the input x hi plane of dout first (small terms first)
+#if defined(SVR_WG_EXP) && SVR_WG_EXP == 1   // measurement build: no matrix instructions (fragments still read and shifted)
+      acc[i][0] += (float)am[0] * (float)b_hi[1] + (float)ah[2] * (float)b_mid[3] + (float)ah[7];
+#else
+      acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, b_hi, acc[i], 0, 0, 0);
+      acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b_mid, acc[i], 0, 0, 0);
+      acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b_hi, acc[i], 0, 0, 0);
+#endif
+    }
+  }
+}
+
 __global__ __launch_bounds__(NT) void conv3d_bwd_weight_x3_kernel(const float *__restrict__ in,
                                                                   const float *__restrict__ dout,
                                                                   float *__restrict__ slab, ConvShape s, int nbz, int nby,
@@ -74,15 +125,16 @@ __global__ __launch_bounds__(NT) void conv3d_bwd_weight_x3_kernel(const float *_
   __shared__ uint32_t lds[2 * BUF];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int l31 = lane & 31, lh = lane >> 5;
-  const int dzi = wave % 3, half = wave / 3;
+  const int grp = wave & 3, half = wave >> 2;
   const int pair = blockIdx.y;
   const int ci0 = (pair / co_tiles) * 32, co0 = (pair % co_tiles) * 32;
   const int64_t bricks = (int64_t)s.B * nbz * nby * nbx;
 
-  float4 ia[IN_IT / 2][2], da[DO_IT / 2][2];  // one half of the next brick in flight at a time
-  int iok[IN_IT / 2], dok[DO_IT / 2];            // bit v: voxel v of the pair is inside the volume
-  // bias gradient: dout passes through this thread's registers exactly once per brick; its 4 channels (cg = t & 7
-  // for every item, 384 % 8 == 0) are summed here by the workgroups of the first ci tile -> no separate pass over dout
+  // the next brick travels in two phases: phase 0 = input items 0, 1 of this thread, phase 1 = input item 2 + its dout item
+  float4 ia[2][2], da[2];
+  int iok[2], dok = 0;  // bit v: voxel v of the pair is inside the volume
+  // bias gradient: dout passes through this thread's registers exactly once per brick; its 4 channels (cg = t & 7,
+  // NT % 8 == 0) are summed here by the workgroups of the first ci tile -> no separate pass over dout
   const bool want_db = dbpart != nullptr && ci0 == 0;
   float4 dbs = make_float4(0.f, 0.f, 0.f, 0.f);
 
@@ -94,10 +146,9 @@ __global__ __launch_bounds__(NT) void conv3d_bwd_weight_x3_kernel(const float *_
     const int64_t b = q / nbz;
     const int z0 = bz * BRZ, y0 = by * BRY, x0 = bx * BRX;
     const float *inb = in + b * (int64_t)s.D * s.H * s.W * s.Ci;
-    const float *dob = dout + b * (int64_t)s.D * s.H * s.W * s.Co;
 #pragma unroll
-    for (int j = 0; j < IN_IT / 2; ++j) {
-      const int idx = t + NT * (ph * (IN_IT / 2) + j);
+    for (int j = 0; j < (ph == 0 ? 2 : 1); ++j) {
+      const int idx = min(t + NT * (ph * 2 + j), IN_ITEMS - 1);
       const int hrow = idx / 40, rem = idx % 40, pr = rem >> 3, cg = rem & 7;
       const int gz = z0 + hrow / HLY - 1, gy = y0 + hrow % HLY - 1, gx = x0 + 2 * pr - 1;
       // unconditional loads from clamped coordinates (a load inside a branch makes the compiler wait for it at the
@@ -105,28 +156,37 @@ __global__ __launch_bounds__(NT) void conv3d_bwd_weight_x3_kernel(const float *_
       const bool rowok = gz >= 0 && gz < s.D && gy >= 0 && gy < s.H && ci0 + cg * 4 < s.Ci;
       const int cz = min(max(gz, 0), s.D - 1), cy = min(max(gy, 0), s.H - 1), cc = min(ci0 + cg * 4, s.Ci - 4);
       const float *p = inb + ((int64_t)cz * s.H + cy) * s.W * s.Ci + cc;
+#if defined(SVR_WG_EXP) && SVR_WG_EXP == 2   // measurement build: no global loads of the next brick
+      ia[j][0] = make_float4((float)idx, 1.f, (float)brick, 3.f);
+      ia[j][1] = make_float4((float)(uintptr_t)p, 1.f, 2.f, 3.f);
+#else
       ia[j][0] = *reinterpret_cast<const float4 *>(p + (int64_t)min(max(gx, 0), s.W - 1) * s.Ci);
       ia[j][1] = *reinterpret_cast<const float4 *>(p + (int64_t)min(max(gx + 1, 0), s.W - 1) * s.Ci);
+#endif
       iok[j] = (rowok && gx >= 0 && gx < s.W ? 1 : 0) | (rowok && gx + 1 >= 0 && gx + 1 < s.W ? 2 : 0);
     }
-#pragma unroll
-    for (int j = 0; j < DO_IT / 2; ++j) {
-      const int idx = t + NT * (ph * (DO_IT / 2) + j);
-      const int row = idx >> 5, pr = (idx & 31) >> 3, cg = idx & 7;
+    if (ph == 1) {
+      const float *dob = dout + b * (int64_t)s.D * s.H * s.W * s.Co;
+      const int row = t >> 5, pr = (t & 31) >> 3, cg = t & 7;
       const int gz = z0 + (row >> 2), gy = y0 + (row & 3), gx = x0 + 2 * pr;
       const bool rowok = gz < s.D && gy < s.H && co0 + cg * 4 < s.Co;
       const int cz = min(gz, s.D - 1), cy = min(gy, s.H - 1), cc = min(co0 + cg * 4, s.Co - 4);
       const float *p = dob + ((int64_t)cz * s.H + cy) * s.W * s.Co + cc;
-      da[j][0] = *reinterpret_cast<const float4 *>(p + (int64_t)min(gx, s.W - 1) * s.Co);
-      da[j][1] = *reinterpret_cast<const float4 *>(p + (int64_t)min(gx + 1, s.W - 1) * s.Co);
-      dok[j] = (rowok && gx < s.W ? 1 : 0) | (rowok && gx + 1 < s.W ? 2 : 0);
+#if defined(SVR_WG_EXP) && SVR_WG_EXP == 2
+      da[0] = make_float4((float)t, 1.f, (float)brick, 3.f);
+      da[1] = make_float4((float)(uintptr_t)p, 1.f, 2.f, 3.f);
+#else
+      da[0] = *reinterpret_cast<const float4 *>(p + (int64_t)min(gx, s.W - 1) * s.Co);
+      da[1] = *reinterpret_cast<const float4 *>(p + (int64_t)min(gx + 1, s.W - 1) * s.Co);
+#endif
+      dok = (rowok && gx < s.W ? 1 : 0) | (rowok && gx + 1 < s.W ? 2 : 0);
     }
   };
 
   auto store = [&](uint32_t *buf, int ph) {
 #pragma unroll
-    for (int j = 0; j < IN_IT / 2; ++j) {
-      const int idx = t + NT * (ph * (IN_IT / 2) + j);
+    for (int j = 0; j < (ph == 0 ? 2 : 1); ++j) {
+      const int idx = t + NT * (ph * 2 + j);
       if (idx < IN_ITEMS) {
         const int hrow = idx / 40, rem = idx % 40, pr = rem >> 3, cg = rem & 7;
         uint32_t *d = buf + (cg * 4) * CIS + hrow * ROWDW + pr;
@@ -141,34 +201,30 @@ __global__ __launch_bounds__(NT) void conv3d_bwd_weight_x3_kernel(const float *_
         }
       }
     }
-    uint32_t *dbuf = buf + 2 * IN_PLANE;
+    if (ph == 1) {
+      uint32_t *dbuf = buf + 2 * IN_PLANE;
+      const int row = t >> 5, pr = (t & 31) >> 3, cg = t & 7;
+      uint32_t *d = dbuf + (cg * 4) * COS + row * 4 + pr;
+      float v0[4] = {da[0].x, da[0].y, da[0].z, da[0].w};
+      float v1[4] = {da[1].x, da[1].y, da[1].z, da[1].w};
 #pragma unroll
-    for (int j = 0; j < DO_IT / 2; ++j) {
-      const int idx = t + NT * (ph * (DO_IT / 2) + j);
-      if (idx < DO_ITEMS) {
-        const int row = idx >> 5, pr = (idx & 31) >> 3, cg = idx & 7;
-        uint32_t *d = dbuf + (cg * 4) * COS + row * 4 + pr;
-        float v0[4] = {da[j][0].x, da[j][0].y, da[j][0].z, da[j][0].w};
-        float v1[4] = {da[j][1].x, da[j][1].y, da[j][1].z, da[j][1].w};
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          v0[c] = (dok[j] & 1) ? v0[c] : 0.f;
-          v1[c] = (dok[j] & 2) ? v1[c] : 0.f;
-          uint32_t h, m;
-          split2(v0[c], v1[c], h, m);
-          d[c * COS] = h;
-          d[DO_PLANE + c * COS] = m;
-        }
-        if (want_db) {
-          dbs.x += v0[0] + v1[0]; dbs.y += v0[1] + v1[1]; dbs.z += v0[2] + v1[2]; dbs.w += v0[3] + v1[3];
-        }
+      for (int c = 0; c < 4; ++c) {
+        v0[c] = (dok & 1) ? v0[c] : 0.f;
+        v1[c] = (dok & 2) ? v1[c] : 0.f;
+        uint32_t h, m;
+        split2(v0[c], v1[c], h, m);
+        d[c * COS] = h;
+        d[DO_PLANE + c * COS] = m;
+      }
+      if (want_db) {
+        dbs.x += v0[0] + v1[0]; dbs.y += v0[1] + v1[1]; dbs.z += v0[2] + v1[2]; dbs.w += v0[3] + v1[3];
       }
     }
   };
 
-  f32x16 acc[9];
+  f32x16 acc[TAPS_PER_WAVE];
 #pragma unroll
-  for (int i = 0; i < 9; ++i)
+  for (int i = 0; i < TAPS_PER_WAVE; ++i)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
@@ -189,39 +245,13 @@ __global__ __launch_bounds__(NT) void conv3d_bwd_weight_x3_kernel(const float *_
 #pragma unroll 1
     for (int kq = 0; kq < 4; ++kq) {
       const int r = 2 * (half * 4 + kq) + lh;  // x-row of the brick handled by this half-wave: r = vz*4 + vy
-      const int vz = r >> 2, vy = r & 3;
-      const uint4 bh = *reinterpret_cast<const uint4 *>(dbuf + l31 * COS + r * 4);
-      const uint4 bm = *reinterpret_cast<const uint4 *>(dbuf + DO_PLANE + l31 * COS + r * 4);
-      const bf16x8 b_hi = frag(bh.x, bh.y, bh.z, bh.w), b_mid = frag(bm.x, bm.y, bm.z, bm.w);
-#pragma unroll
-      for (int dyi = 0; dyi < 3; ++dyi) {
-        const uint32_t *ph = ibuf + l31 * CIS + ((vz + dzi) * HLY + vy + dyi) * ROWDW;
-        {  // mid plane of the input x hi plane of dout (small terms first)
-          const uint2 m01 = *reinterpret_cast<const uint2 *>(ph + IN_PLANE), m23 = *reinterpret_cast<const uint2 *>(ph + IN_PLANE + 2);
-          const uint32_t m4 = ph[IN_PLANE + 4];
-          acc[dyi * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(m01.x, m01.y, m23.x, m23.y), b_hi, acc[dyi * 3 + 0], 0, 0, 0);
-          acc[dyi * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-              frag(__builtin_amdgcn_alignbit(m01.y, m01.x, 16), __builtin_amdgcn_alignbit(m23.x, m01.y, 16),
-                   __builtin_amdgcn_alignbit(m23.y, m23.x, 16), __builtin_amdgcn_alignbit(m4, m23.y, 16)),
-              b_hi, acc[dyi * 3 + 1], 0, 0, 0);
-          acc[dyi * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag(m01.y, m23.x, m23.y, m4), b_hi, acc[dyi * 3 + 2], 0, 0, 0);
-        }
-        {
-          const uint2 h01 = *reinterpret_cast<const uint2 *>(ph), h23 = *reinterpret_cast<const uint2 *>(ph + 2);
-          const uint32_t h4 = ph[4];
-          bf16x8 a = frag(h01.x, h01.y, h23.x, h23.y);
-          acc[dyi * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b_mid, acc[dyi * 3 + 0], 0, 0, 0);
-          acc[dyi * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b_hi, acc[dyi * 3 + 0], 0, 0, 0);
-          a = frag(__builtin_amdgcn_alignbit(h01.y, h01.x, 16), __builtin_amdgcn_alignbit(h23.x, h01.y, 16),
-                   __builtin_amdgcn_alignbit(h23.y, h23.x, 16), __builtin_amdgcn_alignbit(h4, h23.y, 16));
-          acc[dyi * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b_mid, acc[dyi * 3 + 1], 0, 0, 0);
-          acc[dyi * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b_hi, acc[dyi * 3 + 1], 0, 0, 0);
-          a = frag(h01.y, h23.x, h23.y, h4);
-          acc[dyi * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b_mid, acc[dyi * 3 + 2], 0, 0, 0);
-          acc[dyi * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b_hi, acc[dyi * 3 + 2], 0, 0, 0);
-        }
+      switch (grp) {  // wave-uniform
+        case 0: wgrad_rows<0>(ibuf, dbuf, l31, r, acc); break;
+        case 1: wgrad_rows<1>(ibuf, dbuf, l31, r, acc); break;
+        case 2: wgrad_rows<2>(ibuf, dbuf, l31, r, acc); break;
+        default: wgrad_rows<3>(ibuf, dbuf, l31, r, acc); break;
       }
-      if (kq == 1 && more) {  // first half of the next brick has arrived: park it in the other buffer, fetch the rest
+      if (kq == 1 && more) {  // first part of the next brick has arrived: park it in the other buffer, fetch the rest
         store(lds + (cur ^ 1) * BUF, 0);
         load(next, 1);
       }
@@ -231,7 +261,7 @@ __global__ __launch_bounds__(NT) void conv3d_bwd_weight_x3_kernel(const float *_
     cur ^= 1;
   }
 
-  if (want_db) {  // fixed-order sum of the 48 threads per channel group through LDS (free after the last barrier)
+  if (want_db) {  // fixed-order sum of the 64 threads per channel group through LDS (free after the last barrier)
     float *sred = reinterpret_cast<float *>(lds);
     sred[t * 4 + 0] = dbs.x; sred[t * 4 + 1] = dbs.y; sred[t * 4 + 2] = dbs.z; sred[t * 4 + 3] = dbs.w;
     __syncthreads();
@@ -246,11 +276,13 @@ __global__ __launch_bounds__(NT) void conv3d_bwd_weight_x3_kernel(const float *_
   const int pairs = gridDim.y;
   const int64_t part = (int64_t)blockIdx.x * 2 + half;
 #pragma unroll
-  for (int i = 0; i < 9; ++i) {
-    const int tap = dzi * 9 + i;
-    float *o = slab + ((part * 27 + tap) * pairs + pair) * 1024;
+  for (int i = 0; i < TAPS_PER_WAVE; ++i) {
+    const int tap = grp * TAPS_PER_WAVE + i;
+    if (tap < 27) {
+      float *o = slab + ((part * 27 + tap) * pairs + pair) * 1024;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) o[((r & 3) + 8 * (r >> 2) + 4 * lh) * 32 + l31] = acc[i][r];
+      for (int r = 0; r < 16; ++r) o[((r & 3) + 8 * (r >> 2) + 4 * lh) * 32 + l31] = acc[i][r];
+    }
   }
 }
 

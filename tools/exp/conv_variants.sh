@@ -2,7 +2,7 @@
 # conv3d_bf16.hip measurement builds on the GPU box: encoder conv kernel times with parts of the inner loop changed
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
-for e in 0 1; do
+for e in ${CONV_EXPS:-0 1 2 3 4}; do
   SVR_CONV_EXP=$e python3 -c "
 import importlib,sys,os
 sys.path.insert(0,'.')
