@@ -50,7 +50,7 @@ __device__ __forceinline__ uint32_t pack_bf16_rne(float a, float b) {  // round 
 }
 
 constexpr int FK = 16;                 // reduction elements per MFMA step
-constexpr int FLW = 10;                // dwords per LDS row of one k-step (16 halves + 8 B pad, as gemm_f16x3.hip)
+constexpr int FLW = 8;                 // dwords per LDS row of one k-step: 16 halves = two 16-byte slots (fc_slot_dw), as gemm_f16x3.hip
 #ifndef FC_TM
 #define FC_TM 64
 #endif
@@ -62,7 +62,7 @@ constexpr int RPW = FTM / 4;           // rows per producer wave
 constexpr int FMT = FTM / 32;          // 32-row MFMA tiles per consumer wave
 constexpr int FTN = 256;               // output columns (fc_0's width)
 constexpr int FPLANE = FTM * FLW;      // dwords per plane and k-step
-constexpr int FKSTEP = 2 * FPLANE + 20;  // hi + lo; + 20 dwords: the k-steps of one producer store land on different banks
+constexpr int FKSTEP = 2 * FPLANE + 8;   // hi + lo; + 8 dwords: the four k-steps of one producer store (64-column slabs) land on different banks
 constexpr int FSLAB_K = 4;             // k-steps per slab buffer
 constexpr int FSLAB = FSLAB_K * FKSTEP;
 constexpr int FC_MAX_SLABS = 44;
@@ -131,11 +131,14 @@ __global__ void split_w_fused_bf16_kernel(FcArgs A, const float *__restrict__ W,
   p0[wfrag_index(kk, 0, n, N / 32, 1)] = (uint16_t)(pack_bf16_rne(w, 0.f) & 0xffffu);
 }
 
+// LDS rows of the feature tile: slot (16 bytes = 8 halves) h of a row sits at 2 row + (h ^ bit 3 of the row), so that a
+// consumer's fragment is ONE ds_read_b128 (256 B/clk; the padded 8-byte aligned rows of the first version made it a
+// ds_read2_b64 at 128 B/clk) and its 16-lane groups hit 16 different slots (see gemm_f16x3.hip / conv3d_bf16.hip).
+__device__ __forceinline__ int fc_slot_dw(int row, int h) { return (row * 2 + (h ^ ((row >> 3) & 1))) * 4; }
+
 __device__ __forceinline__ f16x8 lds_frag(const uint32_t *plane, int row, int lh) {
-  const uint2 a = *reinterpret_cast<const uint2 *>(plane + row * FLW + lh * 4);
-  const uint2 b = *reinterpret_cast<const uint2 *>(plane + row * FLW + lh * 4 + 2);
   union { uint4 q; f16x8 v; } f;
-  f.q = make_uint4(a.x, a.y, b.x, b.y);
+  f.q = *reinterpret_cast<const uint4 *>(plane + fc_slot_dw(row, lh));
   return f.v;
 }
 
@@ -189,7 +192,12 @@ __device__ __forceinline__ void produce_slab(const FcLevel L, const FcSlab S, ui
   const int g = lane / LP, q = lane % LP, jj = q / LPI, c4 = (q % LPI) * 4;
   const int src0 = (g * NJ + jj) << 2;
   const int col = jj * NC + c4;  // column inside the slab
-  uint32_t *dstg = buf + (col >> 4) * FKSTEP + ((col & 15) >> 1) + (RPW * pw + g) * FLW;
+  // row of pass `it` = RPW pw + g + it PPW: its swizzle bit (bit 3) is known at compile time when PPW <= 8 (g < PPW), else
+  // (PPW = 16) it is bit 3 of g: at most one v_xor per pass
+  static_assert(RPW % 16 == 0 && (PPW == 4 || PPW == 8 || PPW == 16), "swizzle bit of the producer rows");
+  // (FKSTEP, FLW and the pass stride are multiples of 8 dwords: bit 2 of the dword offset IS the slot bit, `^ 4` toggles it)
+  static_assert(FKSTEP % 8 == 0 && FLW == 8, "slot bit of the producer's destination");
+  const int dsto = ((col >> 4) * FKSTEP + (RPW * pw + g) * FLW + ((col & 15) >> 1)) ^ (PPW == 16 ? ((g >> 3) & 1) * 4 : 0);
   GLOBAL_AS char *featt = (GLOBAL_AS char *)(feat + m0 * row_stride);
   const uint32_t fo0 = (uint32_t)((RPW * pw + g) * row_stride + L.kcol + (S.j0 + jj) * C + S.c0 + c4) * 4u;
   const int live = M - m0 < FTM ? (int)(M - m0) : FTM;
@@ -223,7 +231,7 @@ __device__ __forceinline__ void produce_slab(const FcLevel L, const FcSlab S, ui
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int k = 0; k < 8; ++k) acc = acc + I.v[k] * I.w[k];
-    uint32_t *d = dstg + it * (PPW * FLW);
+    uint32_t *d = buf + (dsto ^ (PPW == 16 ? 0 : (((it * PPW) >> 3) & 1) * 4)) + it * (PPW * FLW);
     if constexpr (BF) {   // the feature values in bf16 (one rounding), one plane
       *reinterpret_cast<uint2 *>(d) = make_uint2(pack_bf16_rne(acc.x, acc.y), pack_bf16_rne(acc.z, acc.w));
       return;
@@ -284,17 +292,18 @@ __device__ __forceinline__ void produce_c1(const FcLevel L, const FcSlab S, uint
     const _Float16 h = (_Float16)acc;
     const _Float16 l = (_Float16)((acc - (float)h) * 2048.f);
     const uint16_t hb = BF ? (uint16_t)(pack_bf16_rne(acc, 0.f) & 0xffffu) : __builtin_bit_cast(uint16_t, h);
+    const int s0 = fc_slot_dw(row, 0), s1 = fc_slot_dw(row, 1);   // halves 0 .. 7 / 8 .. 15 of the row
     if (j < 7) {
-      b16[(row * FLW) * 2 + j] = hb;
-      if (!BF) b16[(FPLANE + row * FLW) * 2 + j] = __builtin_bit_cast(uint16_t, l);
+      b16[s0 * 2 + j] = hb;
+      if (!BF) b16[(FPLANE + s0) * 2 + j] = __builtin_bit_cast(uint16_t, l);
       if (!BF && S.keep && m0 + row < M) feat[(m0 + row) * row_stride + L.kcol + j] = acc;
     } else {  // halves 7 .. 15 of the row: zeros
-      b16[(row * FLW) * 2 + 7] = 0;
-      if (!BF) b16[(FPLANE + row * FLW) * 2 + 7] = 0;
+      b16[s0 * 2 + 7] = 0;
+      if (!BF) b16[(FPLANE + s0) * 2 + 7] = 0;
 #pragma unroll
-      for (int p = 4; p < 8; ++p) {
-        buf[row * FLW + p] = 0u;
-        if (!BF) buf[FPLANE + row * FLW + p] = 0u;
+      for (int p = 0; p < 4; ++p) {
+        buf[s1 + p] = 0u;
+        if (!BF) buf[FPLANE + s1 + p] = 0u;
       }
     }
   }

@@ -32,15 +32,19 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int YK = 16;   // reduction elements per step
-constexpr int YLW = 10;  // dwords per LDS row (16 halves + 8 B pad: ds_read_b64 fragment reads conflict free)
+constexpr int YLW = 8;   // dwords per LDS row: 16 halves = two 16-byte slots, no padding
 constexpr int TM = 128;
 constexpr int APLANE = TM * YLW;  // dwords per X plane
 
+// A fragment (8 halves of one row) is one 16-byte slot and comes out of ONE ds_read_b128 (256 B/clk; the 8-byte aligned
+// padded rows of the first version made it a ds_read2_b64: 128 B/clk).  Slot of (row, half h) = 2 row + (h ^ bit 3 of row):
+// the 16-lane groups of ds_read_b128 ({0-3,12-15,20-27}, {4-11,16-19,28-31}, + 32: MI355X_MICROARCH.md "LDS") hold rows that
+// pair up mod 8 at distances 8 and 24, so the 16 lanes hit 16 different slots mod 16 -- conflict free.
+__device__ __forceinline__ int slot_dw(int row, int h) { return (row * 2 + (h ^ ((row >> 3) & 1))) * 4; }
+
 __device__ __forceinline__ f16x8 read_frag(const uint32_t *plane, int row, int lh) {
-  const uint2 a = *reinterpret_cast<const uint2 *>(plane + row * YLW + lh * 4);
-  const uint2 b = *reinterpret_cast<const uint2 *>(plane + row * YLW + lh * 4 + 2);
   union { uint4 q; f16x8 v; } f;
-  f.q = make_uint4(a.x, a.y, b.x, b.y);
+  f.q = *reinterpret_cast<const uint4 *>(plane + slot_dw(row, lh));
   return f.v;
 }
 
@@ -78,7 +82,7 @@ __global__ __launch_bounds__(2 * TN, 1024 / (2 * TN) >= 4 ? 3 : 2) void linear_n
     const uint32_t *__restrict__ amax, const float *__restrict__ bias, float *__restrict__ Y, int64_t ldy, int64_t M,
     int64_t N, int64_t K, int relu) {
   constexpr int NT = 2 * TN, BPLANE = TN * YLW, XPT = 512 / NT, STAGE = 2 * APLANE + 2 * BPLANE;
-  __shared__ uint32_t lds[2 * STAGE];  // two stages of (hi/lo planes of X and W)
+  __shared__ __attribute__((aligned(16))) uint32_t lds[2 * STAGE];  // two stages of (hi/lo planes of X and W)
   const int t = threadIdx.x;
   const int lane = t & 63, wave = t >> 6;
   const int wr = wave / (TN / 64), wc = wave % (TN / 64);   // 2 x (TN/64) waves of 64 x 64
@@ -127,17 +131,14 @@ __global__ __launch_bounds__(2 * TN, 1024 / (2 * TN) >= 4 ? 3 : 2) void linear_n
       uint32_t h0, l0, h1, l1;
       split_x(r.x[i].x, r.x[i].y, h0, l0);
       split_x(r.x[i].z, r.x[i].w, h1, l1);
-      const int off = ((t >> 2) + (NT / 4) * i) * YLW + (t & 3) * 2;
+      const int off = slot_dw((t >> 2) + (NT / 4) * i, (t & 3) >> 1) + (t & 1) * 2;   // 4 halves = half a slot
       *reinterpret_cast<uint2 *>(st + off) = make_uint2(h0, h1);
       *reinterpret_cast<uint2 *>(st + APLANE + off) = make_uint2(l0, l1);
     }
     uint32_t *sb = st + 2 * APLANE;
-    const int offb = (t >> 1) * YLW + (t & 1) * 4;
+    const int offb = slot_dw(t >> 1, t & 1);
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
-      *reinterpret_cast<uint2 *>(sb + p * BPLANE + offb) = make_uint2(r.w[p].x, r.w[p].y);
-      *reinterpret_cast<uint2 *>(sb + p * BPLANE + offb + 2) = make_uint2(r.w[p].z, r.w[p].w);
-    }
+    for (int p = 0; p < 2; ++p) *reinterpret_cast<uint4 *>(sb + p * BPLANE + offb) = r.w[p];
   };
 
   f32x16 acc[2][2];
