@@ -429,17 +429,21 @@ int svr_bn_bwd_apply(const float *x, const float *dy, const float *dpooled, cons
  *                    sum dy_total, sum dy_total*xhat; dgamma, dbeta; dW(16,1,3,3,3) (the PARAMETER's layout) and db[16]
  *                    (may be NULL) of conv_in; dout (may be NULL)
  *                    = d(loss)/d(conv_in output) for a caller that needs d(loss)/d(x).  relu_mask as svr_bn_bwd_apply.
+ *   f16x3 != 0: the recomputed convolution runs as the 3-product f16 split of svr_conv3d_k3_fwd_f16x3 (f32-level
+ *                    accuracy for |x| < 65504, 3 matrix instructions per 16 voxels instead of 7 exact-f32 ones); 0: exact
+ *                    f32.  The backward must be called with the flag the forward was called with (it recomputes the same
+ *                    activation: ReLU mask and xhat bit for bit).
  *   workspace: svr_stage1_workspace(B, D, H, W) bytes.  Wp = svr_conv3d_pack_weight's Wp_fwd ([27][1][16]).          */
 int32_t svr_stage1_supported(int32_t B, int32_t D, int32_t H, int32_t W, int32_t Co);
 int64_t svr_stage1_workspace(int32_t B, int32_t D, int32_t H, int32_t W);
 int svr_stage1_fwd(const float *x, const float *Wp, const float *bias, const float *gamma, const float *beta,
                    float *running_mean, float *running_var, float *y, float *pooled, uint8_t *argmax,
                    float *scale_shift, float *mean_f32, double *stats, int32_t B, int32_t D, int32_t H, int32_t W,
-                   int32_t Co, float eps, float momentum, int training, void *workspace, void *stream);
+                   int32_t Co, float eps, float momentum, int training, int f16x3, void *workspace, void *stream);
 int svr_stage1_bwd(const float *x, const float *Wp, const float *bias, const float *dy, const float *dpooled,
                    const uint8_t *argmax, const float *mean_f32, const float *scale_shift, double *sums,
                    float *dgamma, float *dbeta, float *dW, float *db, float *dout, int32_t B, int32_t D,
-                   int32_t H, int32_t W, int32_t Co, int relu_mask, void *workspace, void *stream);
+                   int32_t H, int32_t W, int32_t Co, int relu_mask, int f16x3, void *workspace, void *stream);
 
 /* ---------------------------------------------------------------------------------------
  * Depth -> point cloud -> voxel grid  (model/projection.py).

@@ -114,8 +114,8 @@ SIGNATURES = {
     "svr_bn_bwd_apply": (C.c_int, [P, P, P, P, P, P, P, P, P, P, P, I32, I32, I32, I32, I32, C.c_int, P]),
     "svr_stage1_supported": (I32, [I32, I32, I32, I32, I32]),
     "svr_stage1_workspace": (I64, [I32, I32, I32, I32]),
-    "svr_stage1_fwd": (C.c_int, [P, P, P, P, P, P, P, P, P, P, P, P, P, I32, I32, I32, I32, I32, F32, F32, C.c_int, P, P]),
-    "svr_stage1_bwd": (C.c_int, [P, P, P, P, P, P, P, P, P, P, P, P, P, P, I32, I32, I32, I32, I32, C.c_int, P, P]),
+    "svr_stage1_fwd": (C.c_int, [P, P, P, P, P, P, P, P, P, P, P, P, P, I32, I32, I32, I32, I32, F32, F32, C.c_int, C.c_int, P, P]),
+    "svr_stage1_bwd": (C.c_int, [P, P, P, P, P, P, P, P, P, P, P, P, P, P, I32, I32, I32, I32, I32, C.c_int, C.c_int, P, P]),
     "svr_conv2d_im2col": (C.c_int, [C.POINTER(Conv2dDesc), P, P]),
     "svr_conv2d_col2im": (C.c_int, [C.POINTER(Conv2dDesc), P, P, P, P, P]),
     "svr_mesh_hash_entries": (I64, [P, I64, P, I64, I32, P]),

@@ -234,7 +234,11 @@ __global__ __launch_bounds__(256) void conv3d_brick_x3_kernel(const float *__res
       const int hv = idx / (CK / 4), c4 = (idx % (CK / 4)) * 4;
       const int hd = slot_dw<SL>((hv / HLX) * HP + hv % HLX, c4 / 8) + (c4 % 8) / 2;   // (hz*HLY + hy)*HP + hx; half a slot
       const bool ok = (hok >> i) & 1ull;
+#if defined(SVR_CONV_EXP) && SVR_CONV_EXP == 5   // measurement build: the halo loads are issued but nobody waits for them here
+      const float4 v = make_float4(ok ? (float)hv : 0.f, 1.f, 2.f, ok ? 3.f : 0.f);
+#else
       const float4 v = make_float4(ok ? hreg[i].x : 0.f, ok ? hreg[i].y : 0.f, ok ? hreg[i].z : 0.f, ok ? hreg[i].w : 0.f);
+#endif
       uint32_t h0, m0, l0 = 0, h1, m1, l1 = 0;
       if constexpr (NP == 3) {
         split3(v.x, v.y, h0, m0, l0);
@@ -330,6 +334,10 @@ __global__ __launch_bounds__(256) void conv3d_brick_x3_kernel(const float *__res
       step(st, wregB, wregA);
       if (st + 1 < STEPS) step(st + 1, wregA, wregB);
     }
+#if defined(SVR_CONV_EXP) && SVR_CONV_EXP == 5   // ... the loads land behind the chunk's MFMAs
+#pragma unroll
+    for (int i = 0; i < HIT; ++i) asm volatile("" ::"v"(hreg[i].x), "v"(hreg[i].y), "v"(hreg[i].z), "v"(hreg[i].w));
+#endif
   }
   // BatchNorm statistics of what this workgroup stores (spart: per-workgroup partial sums [brick][2][Co] in f64): the
   // stage's last convolution delivers them and the separate statistics pass over its output disappears

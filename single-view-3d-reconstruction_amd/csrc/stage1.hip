@@ -17,6 +17,13 @@
 // saved / temporary tensors.  The recomputed `a` is bit-identical in all four passes (same MFMA sequence), so the ReLU
 // mask and xhat of the backward are exactly the forward's.
 //
+// Arithmetic of the recomputed convolution: either exact f32 (7 x v_mfma_f32_16x16x4_f32 per tile: 224 matrix cycles) or
+// the 3-product f16 split of the other forward convolutions (template flag H3; f16x3.h / gemm_f16x3.hip: f32-level accuracy
+// for |x| < 65504): the 27 taps fit ONE k = 32 step of v_mfma_f32_16x16x32_f16, three of them per tile = 48 matrix cycles.
+// The halo tile then holds each voxel as a packed pair (f16 hi | f16 lo * 2^11), split once per brick by the threads that
+// stage it; a lane fetches its 8 taps and sorts the halves into the two A fragments with 8 v_perm_b32.  The weights are
+// normalised by 2^s (amax of the 432 weights, found by the workgroup itself) and the accumulator is scaled back by 2^-s.
+//
 // Tile = 16 voxels = two x-adjacent 2x2x2 pool cells.  v_mfma_f32_16x16x4_f32 lane mapping (lane = 16 kq + l15):
 //   A[i = l15][k = kq], B[k = kq][j = l15], D[i = 4 kq + r][j = l15] in register r.
 // conv:  i = voxel, k = tap (7 MFMAs cover taps 0..27), j = output channel; voxel i = 8 cell + 4 dz + 2 dy + dx, so a lane's
@@ -24,7 +31,9 @@
 //        16 lanes away (one ds_bpermute for the pool maximum).
 // dW:    i = tap (two 16-row tiles), k = voxel, j = output channel; B is the lane's own dconv register r (voxel 4 kq + r),
 //        A one LDS read of the halo tile at (voxel + tap).
+// v_mfma_f32_16x16x32_f16 (H3): A[i = l15][k = 8 kq + m], B[k = 8 kq + m][j = l15], m = 0..7; D as above.
 #include "common.h"
+#include "f16x3.h"
 
 #ifndef S1_EXP
 #define S1_EXP 0   // measurement switches (build.py: SVR_S1_EXP): 1 no tail, 2 no MFMA
@@ -146,9 +155,11 @@ struct S1Grad {
 };
 constexpr int S1_PD = 4;   // prefetch distance in tiles: the loads of tile t + 4 are issued when tile t is processed
 
-template <int MODE>
+template <int MODE, bool H3>
 __global__ __launch_bounds__(256) void stage1_kernel(const S1Args a) {
-  __shared__ float tile[NHP];
+  // f32 halo tile: the exact path's conv operand and, in BWD_APPLY, the dW operand of both paths; packed f16 pairs: H3
+  __shared__ float tile[(H3 && MODE != S1_BWD_APPLY) ? 1 : NHP];
+  __shared__ uint32_t tileh[H3 ? NHP : 1];
   __shared__ __attribute__((aligned(16))) double redd[(MODE == S1_BWD_APPLY) ? 2048 : 512];
   constexpr bool BWD = MODE == S1_BWD_REDUCE || MODE == S1_BWD_APPLY;
   constexpr int PS = MODE == S1_BWD_APPLY ? 123 : 122;
@@ -167,7 +178,49 @@ __global__ __launch_bounds__(256) void stage1_kernel(const S1Args a) {
   }
   // A rows: voxel i = l15 of the tile -> offset in the halo tile (tile origin = brick origin - 1)
   const int vA = (2 * wave + ((l15 >> 2) & 1) + 1) * PS + (((l15 >> 1) & 1) + 1) * RS + (2 * (l15 >> 3) + (l15 & 1) + 1);
-  const float bv = a.bias ? a.bias[l15] : 0.f;
+  float bv = a.bias ? a.bias[l15] : 0.f;
+  // H3: taps 8 kq .. 8 kq + 7 of this lane (28 .. 31 do not exist: weight 0, operand read from tap 26), weight fragments
+  int toffH[8];
+  f16x8 wh, wl, wq;
+  float winv = 1.f;
+  if constexpr (H3) {
+    float *redf = reinterpret_cast<float *>(redd);
+    float m = fabsf(a.Wp[t]);                                      // 27 x 16 = 432 weights
+    if (t + 256 < 27 * CO) m = fmaxf(m, fabsf(a.Wp[t + 256]));
+    redf[t] = m;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if (t < o) redf[t] = fmaxf(redf[t], redf[t + o]);
+      __syncthreads();
+    }
+    const uint32_t amax = __float_as_uint(redf[0]);
+    __syncthreads();   // (redd is used again at the end)
+    const float wsc = w_scale(amax, false);
+    winv = w_scale(amax, true);
+    bv *= wsc;         // the bias rides in the accumulator, which carries the weights' scale
+    uint32_t hp[4], lp[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      float w2[2];
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int tap = 8 * kq + 2 * d + e;
+        w2[e] = tap < 27 ? a.Wp[tap * CO + l15] * wsc : 0.f;
+      }
+      hp[d] = pack_f16(w2[0], w2[1]);
+      const f32x2 h = unpack_f16(hp[d]);
+      lp[d] = pack_f16(w2[0] - h.x, w2[1] - h.y);
+    }
+    union { uint4 q; f16x8 v; } uh, ul;
+    uh.q = make_uint4(hp[0], hp[1], hp[2], hp[3]);
+    ul.q = make_uint4(lp[0], lp[1], lp[2], lp[3]);
+    wh = uh.v; wl = ul.v; wq = scale_2m11(wh);
+#pragma unroll
+    for (int m8 = 0; m8 < 8; ++m8) {
+      const int tap = 8 * kq + m8, tc = tap < 27 ? tap : 26;
+      toffH[m8] = (tc / 9 - 1) * PS + ((tc / 3) % 3 - 1) * RS + (tc % 3 - 1);
+    }
+  }
   // D rows: this lane's four voxels = cell ciD, slice dzD, (dy, dx) = (r >> 1, r & 1); channel l15
   const int ciD = kq >> 1, dzD = kq & 1;
   float sc = 0.f, sh = 0.f, is = 0.f, mu = 0.f, m1 = 0.f, m2 = 0.f;
@@ -255,7 +308,15 @@ __global__ __launch_bounds__(256) void stage1_kernel(const S1Args a) {
 #pragma unroll
     for (int i = 0; i < HIT; ++i)   // unconditional (a predicated store pulls its load into the branch: vmcnt(0) at the join;
       //                               threads past the 1000th voxel repeat voxel 999 with the same value)
-      tile[hst[i]] = __uint_as_float(__float_as_uint(hv[i]) & (((hok >> i) & 1u) ? 0xffffffffu : 0u));
+    {
+      const float v = __uint_as_float(__float_as_uint(hv[i]) & (((hok >> i) & 1u) ? 0xffffffffu : 0u));
+      if constexpr (!H3 || MODE == S1_BWD_APPLY) tile[hst[i]] = v;
+      if constexpr (H3) {   // (f16 hi | f16 lo * 2^11) of the voxel, split once per brick
+        uint32_t hi2, lo2;
+        split_x(v, 0.f, hi2, lo2);
+        tileh[hst[i]] = (hi2 & 0xffffu) | (lo2 << 16);
+      }
+    }
     __syncthreads();
     float *yb = a.y + (int64_t)gc.b * D * H * W * CO;                 // this sample's volumes (wave-uniform bases)
     float *doutb = a.dout + (int64_t)gc.b * D * H * W * CO;
@@ -263,8 +324,14 @@ __global__ __launch_bounds__(256) void stage1_kernel(const S1Args a) {
     float f1 = 0.f, f2 = 0.f;   // f32 runs of one brick (32 values per lane), carried in f64
     // A operand of tile 0; inside the loop the next tile's seven values are read while this tile's MFMAs run
     float ac[7];
+    uint32_t pc[8];
+    if constexpr (H3) {
 #pragma unroll
-    for (int m = 0; m < 7; ++m) ac[m] = tile[vA + toffA[m]];
+      for (int m = 0; m < 8; ++m) pc[m] = tileh[vA + toffH[m]];
+    } else {
+#pragma unroll
+      for (int m = 0; m < 7; ++m) ac[m] = tile[vA + toffA[m]];
+    }
 #pragma unroll
     for (int tt = 0; tt < 8; ++tt) {
       const int cy = tt >> 1, cxp = tt & 1;
@@ -279,20 +346,44 @@ __global__ __launch_bounds__(256) void stage1_kernel(const S1Args a) {
         else S1_GRAD_LOAD(slot[tt % S1_PD], gn, tt + S1_PD - 8)
       }
       float an[7];
+      uint32_t pn[8];
       if (tt < 7) {
         const int va = vA + (2 * ((tt + 1) >> 1)) * RS + 4 * ((tt + 1) & 1);
+        if constexpr (H3) {
 #pragma unroll
-        for (int m = 0; m < 7; ++m) an[m] = tile[va + toffA[m]];
+          for (int m = 0; m < 8; ++m) pn[m] = tileh[va + toffH[m]];
+        } else {
+#pragma unroll
+          for (int m = 0; m < 7; ++m) an[m] = tile[va + toffA[m]];
+        }
       }
       __builtin_amdgcn_sched_barrier(0);
       // ---- recompute a = relu(conv + bias) for the tile
       f32x4 acc = {bv, bv, bv, bv};   // the bias rides in the accumulator (every register of a lane is channel l15)
 #if S1_EXP == 2     // measurement build: no matrix instructions
+      if constexpr (H3) {
 #pragma unroll
-      for (int m = 0; m < 7; ++m) acc[m & 3] += ac[m] * bw[m];
+        for (int m = 0; m < 8; ++m) acc[m & 3] += __uint_as_float(pc[m]) * bw[m & 3];
+      } else {
+#pragma unroll
+        for (int m = 0; m < 7; ++m) acc[m & 3] += ac[m] * bw[m];
+      }
 #else
+      if constexpr (H3) {
+        // the lane's 8 taps -> fragments of the hi halves and of the lo * 2^11 halves (one v_perm_b32 per dword)
+        union { uint4 q; f16x8 v; } xh, xl;
+        xh.q = make_uint4(__builtin_amdgcn_perm(pc[1], pc[0], 0x05040100u), __builtin_amdgcn_perm(pc[3], pc[2], 0x05040100u),
+                          __builtin_amdgcn_perm(pc[5], pc[4], 0x05040100u), __builtin_amdgcn_perm(pc[7], pc[6], 0x05040100u));
+        xl.q = make_uint4(__builtin_amdgcn_perm(pc[1], pc[0], 0x07060302u), __builtin_amdgcn_perm(pc[3], pc[2], 0x07060302u),
+                          __builtin_amdgcn_perm(pc[5], pc[4], 0x07060302u), __builtin_amdgcn_perm(pc[7], pc[6], 0x07060302u));
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(xl.v, wq, acc, 0, 0, 0);   // lo(x) hi(w)
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh.v, wl, acc, 0, 0, 0);   // hi(x) lo(w)
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh.v, wh, acc, 0, 0, 0);   // hi(x) hi(w)
+        acc = acc * winv;
+      } else {
 #pragma unroll
-      for (int m = 0; m < 7; ++m) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[m], bw[m], acc, 0, 0, 0);
+        for (int m = 0; m < 7; ++m) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[m], bw[m], acc, 0, 0, 0);
+      }
 #endif
       float av[4];
 #pragma unroll
@@ -383,8 +474,13 @@ __global__ __launch_bounds__(256) void stage1_kernel(const S1Args a) {
         }
       }
       if (tt < 7) {
+        if constexpr (H3) {
 #pragma unroll
-        for (int m = 0; m < 7; ++m) ac[m] = an[m];
+          for (int m = 0; m < 8; ++m) pc[m] = pn[m];
+        } else {
+#pragma unroll
+          for (int m = 0; m < 7; ++m) ac[m] = an[m];
+        }
       }
       // keep the tiles in program order.  The running sums are pure arithmetic with their only use behind the loop: left
       // alone, instruction selection parks every tile's tail behind all loads of the brick (8 accumulators + 8 tiles of
@@ -444,13 +540,13 @@ void s1_fill(S1Args &a, int B, int D, int H, int W) {
 // Persistent grid of one pass: exactly the workgroups that are resident at once (CUs x occupancy of that kernel), so that
 // every workgroup walks the same number of bricks -- a fixed 2048 ran as one full round plus a round at a third of the chip.
 // The occupancy query is cached per kernel (immutable after the first call: the only global state of this file).
-template <int MODE>
+template <int MODE, bool H3>
 int s1_grid(int nbricks) {
   static int resident = 0;
   if (resident == 0) {
     int dev = 0, cus = 256, per_cu = 2;
     if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, stage1_kernel<MODE>, 256, 0) != hipSuccess || per_cu < 1) per_cu = 2;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, stage1_kernel<MODE, H3>, 256, 0) != hipSuccess || per_cu < 1) per_cu = 2;
     (void)hipGetLastError();
     int r = cus * per_cu;
     resident = r > S1_MAX_BLOCKS ? S1_MAX_BLOCKS : (r < 1 ? 1 : r);
@@ -465,6 +561,20 @@ int s1_check(const char *what, int B, int D, int H, int W, int Co) {
   SVR_CHECK((int64_t)D * H * W * CO < (1LL << 31) && (int64_t)B * cdiv(D, SB) * cdiv(H, SB) * cdiv(W, SB) < (1LL << 31),
             SVR_E_UNSUPPORTED, "%s: volume %dx%dx%dx%d too large for 32-bit offsets", what, B, D, H, W);
   return SVR_OK;
+}
+
+// one pass: grid of the instantiation + launch
+template <int MODE>
+int s1_launch(const S1Args &a, int f16x3, hipStream_t s) {
+  int grid;
+  if (f16x3) {
+    grid = s1_grid<MODE, true>(a.nbricks);
+    hipLaunchKernelGGL((stage1_kernel<MODE, true>), dim3(grid), dim3(256), 0, s, a);
+  } else {
+    grid = s1_grid<MODE, false>(a.nbricks);
+    hipLaunchKernelGGL((stage1_kernel<MODE, false>), dim3(grid), dim3(256), 0, s, a);
+  }
+  return grid;
 }
 
 }  // namespace
@@ -483,7 +593,7 @@ extern "C" int64_t svr_stage1_workspace(int32_t B, int32_t D, int32_t H, int32_t
 extern "C" int svr_stage1_fwd(const float *x, const float *Wp, const float *bias, const float *gamma, const float *beta,
                               float *running_mean, float *running_var, float *y, float *pooled, uint8_t *argmax,
                               float *scale_shift, float *mean_f32, double *stats, int32_t B, int32_t D, int32_t H, int32_t W,
-                              int32_t Co, float eps, float momentum, int training, void *workspace, void *stream) {
+                              int32_t Co, float eps, float momentum, int training, int f16x3, void *workspace, void *stream) {
   if (int rc = s1_check("stage1_fwd", B, D, H, W, Co)) return rc;
   SVR_CHECK(x && Wp && y && scale_shift && mean_f32 && workspace && (!training || stats), SVR_E_BADARG, "stage1_fwd: null pointer");
   SVR_CHECK(!pooled || (D >= 2 && H >= 2 && W >= 2), SVR_E_BADSHAPE, "stage1_fwd: pooled output of a volume thinner than 2");
@@ -494,8 +604,7 @@ extern "C" int svr_stage1_fwd(const float *x, const float *Wp, const float *bias
   const int64_t rows = (int64_t)B * D * H * W;
   if (training) {
     a.part = (double *)workspace;
-    const int grid = s1_grid<S1_STATS>(a.nbricks);
-    hipLaunchKernelGGL(stage1_kernel<S1_STATS>, dim3(grid), dim3(256), 0, s, a);
+    const int grid = s1_launch<S1_STATS>(a, f16x3, s);
     bn_stats_finalize_launch(a.part, stats, rows, CO, grid, gamma, beta, running_mean, running_var, scale_shift, mean_f32, eps,
                              momentum, s);
   } else if (int rc = svr_bn_finalize(stats, gamma, beta, running_mean, running_var, scale_shift, mean_f32, rows, CO, eps,
@@ -503,14 +612,14 @@ extern "C" int svr_stage1_fwd(const float *x, const float *Wp, const float *bias
     return rc;
   }
   a.ss = scale_shift; a.mean = mean_f32; a.y = y; a.pooled = pooled; a.argmax = argmax;
-  hipLaunchKernelGGL(stage1_kernel<S1_APPLY>, dim3(s1_grid<S1_APPLY>(a.nbricks)), dim3(256), 0, s, a);
+  (void)s1_launch<S1_APPLY>(a, f16x3, s);
   return launch_status("stage1_fwd");
 }
 
 extern "C" int svr_stage1_bwd(const float *x, const float *Wp, const float *bias, const float *dy, const float *dpooled,
                               const uint8_t *argmax, const float *mean_f32, const float *scale_shift, double *sums,
                               float *dgamma, float *dbeta, float *dWp, float *db, float *dout, int32_t B, int32_t D,
-                              int32_t H, int32_t W, int32_t Co, int relu_mask, void *workspace, void *stream) {
+                              int32_t H, int32_t W, int32_t Co, int relu_mask, int f16x3, void *workspace, void *stream) {
   if (int rc = s1_check("stage1_bwd", B, D, H, W, Co)) return rc;
   SVR_CHECK(x && Wp && mean_f32 && scale_shift && sums && dWp && workspace, SVR_E_BADARG, "stage1_bwd: null pointer");
   SVR_CHECK(!dpooled || argmax, SVR_E_BADARG, "stage1_bwd: dpooled needs argmax");
@@ -523,11 +632,10 @@ extern "C" int svr_stage1_bwd(const float *x, const float *Wp, const float *bias
   float *slab = (float *)workspace;
   float *dbpart = slab + (int64_t)S1_MAX_BLOCKS * 1024;
   a.part = (double *)(dbpart + (int64_t)S1_MAX_BLOCKS * CO);
-  const int grid_r = s1_grid<S1_BWD_REDUCE>(a.nbricks), grid_a = s1_grid<S1_BWD_APPLY>(a.nbricks);
-  hipLaunchKernelGGL(stage1_kernel<S1_BWD_REDUCE>, dim3(grid_r), dim3(256), 0, s, a);
+  const int grid_r = s1_launch<S1_BWD_REDUCE>(a, f16x3, s);
   bn_sum_parts_launch(a.part, sums, 2 * CO, grid_r, s);
   a.sums = sums; a.slab = slab; a.dbpart = dbpart; a.dout = dout; a.dgamma = dgamma; a.dbeta = dbeta;
-  hipLaunchKernelGGL(stage1_kernel<S1_BWD_APPLY>, dim3(grid_a), dim3(256), 0, s, a);
+  const int grid_a = s1_launch<S1_BWD_APPLY>(a, f16x3, s);
   // slabs -> dW in the parameter's layout (16,1,3,3,3), partials -> db: one launch
   conv3d_c1_wgrad_reduce_launch(slab, dWp, CO, grid_a, 1, dbpart, db, s);
   return launch_status("stage1_bwd");

@@ -957,9 +957,15 @@ def stage1_supported(x, Co):
     return Ci == 1 and bool(_lib.lib().svr_stage1_supported(B, D, H, W, Co))
 
 
-def stage1_fwd(x, w, bias, gamma, beta, running_mean, running_var, training, eps=1e-5, momentum=0.1, want_pool=True):
+def stage1_arith(mode=None):
+    """1 if the first stage's recomputed convolution runs as the f16 split (FORWARD_CONV == "f16x3", the default), 0 = exact
+    f32.  The backward recomputes the forward's activation, so it must get the forward's value (stage1_fwd stores it on wp)."""
+    return 1 if (mode or FORWARD_CONV) == "f16x3" else 0
+
+
+def stage1_fwd(x, w, bias, gamma, beta, running_mean, running_var, training, eps=1e-5, momentum=0.1, want_pool=True, mode=None):
     """x (B,D,H,W,1) -> y = BN(relu(conv_in(x))), pooled, argmax, scale_shift (3*16), mean (16), wp: conv_in's activation
-    is recomputed wherever it is needed and never stored (stage1.hip)."""
+    is recomputed wherever it is needed and never stored (stage1.hip).  mode: "f16x3" / "f32" (default: FORWARD_CONV)."""
     _f32(x, w, bias, gamma, beta, running_mean, running_var)
     B, D, H, W, _ = x.shape
     Co = w.shape[0]
@@ -978,13 +984,15 @@ def stage1_fwd(x, w, bias, gamma, beta, running_mean, running_var, training, eps
     stats = torch.empty(2 * Co, device=dev, dtype=torch.float64) if training else None
     ws = torch.empty(l.svr_stage1_workspace(B, D, H, W), device=dev, dtype=torch.uint8)
     check(l.svr_stage1_fwd(_p(x), _p(wp), _p(bias), _p(gamma), _p(beta), _p(running_mean), _p(running_var), _p(y), _p(pooled),
-                           _p(argmax), _p(ss), _p(mean), _p(stats), B, D, H, W, Co, eps, momentum, int(training), _p(ws),
-                           _stream()), "stage1_fwd")
+                           _p(argmax), _p(ss), _p(mean), _p(stats), B, D, H, W, Co, eps, momentum, int(training),
+                           stage1_arith(mode), _p(ws), _stream()), "stage1_fwd")
+    wp.svr_stage1_arith = stage1_arith(mode)     # the arithmetic the backward has to recompute with
     return y, pooled, argmax, ss, mean, wp
 
 
 def stage1_bwd(x, wp, bias, dy, dpooled, argmax, mean, ss, relu_mask=True, training=True, want_dout=False):
-    """Backward of stage1_fwd -> dgamma, dbeta, dW (16,1,3,3,3), db, dout (None unless want_dout)."""
+    """Backward of stage1_fwd -> dgamma, dbeta, dW (16,1,3,3,3), db, dout (None unless want_dout).  wp: the tensor
+    stage1_fwd returned (it carries the forward's arithmetic)."""
     _f32(x, wp, bias, dy, dpooled, mean, ss)
     B, D, H, W, _ = x.shape
     Co = wp.shape[2]
@@ -999,7 +1007,7 @@ def stage1_bwd(x, wp, bias, dy, dpooled, argmax, mean, ss, relu_mask=True, train
     ws = torch.empty(l.svr_stage1_workspace(B, D, H, W), device=dev, dtype=torch.uint8)
     check(l.svr_stage1_bwd(_p(x), _p(wp), _p(bias), _p(dy), _p(dpooled), _p(argmax), _p(mean), _p(ss), _p(sums), _p(dgamma),
                            _p(dbeta), _p(dwp), _p(db), _p(dout), B, D, H, W, Co, int(relu_mask) | (0 if training else 2),
-                           _p(ws), _stream()), "stage1_bwd")
+                           int(getattr(wp, "svr_stage1_arith", stage1_arith())), _p(ws), _stream()), "stage1_bwd")
     return dgamma, dbeta, dwp, db, dout
 
 

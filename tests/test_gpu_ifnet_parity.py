@@ -445,9 +445,10 @@ def test_deterministic_mode_step_is_bit_reproducible_and_atomic_free():
 def test_round3_switches_do_not_change_the_step():
     """Every round-3 restructuring of the training step has a switch; the step with ALL of them off (separate conv_in /
     BatchNorm kernels, a statistics pass per stage, no arena, sort and weight preparation on the main stream, one join behind
-    the fork) gives the same logits to f32 summation-order rounding -- stage 1 sums its 27 taps in another order, which the
-    four stages behind it amplify: observed 3e-6, gate 1e-5 = the gate each of the two runs is held to against the reference
-    itself -- and the same gradients to the mask-flip / atomic-order noise every other A/B of this file allows."""
+    the fork) gives the same logits to f32-level rounding -- stage 1 sums its 27 taps in another order and (since the
+    recomputed convolution runs as the f16 split, stage1.hip) with the split's 3e-7 per product instead of exact f32 MFMAs,
+    which the four stages behind it and this test's weight gain of 3 amplify: observed 1.2e-5, gate 2e-5 = a fifth of
+    north_star's 1e-4 -- and the same gradients to the mask-flip / atomic-order noise every other A/B of this file allows."""
     from svr_amd.model import ifnet as ifn
     from svr_amd.trainer import bce_with_logits_sum_mean
     g = torch.Generator().manual_seed(77)
@@ -476,7 +477,7 @@ def test_round3_switches_do_not_change_the_step():
     finally:
         for n, v in saved.items():
             setattr(ifn, n, v)
-    assert G.rel_err(z1.cpu().numpy(), z0.cpu().numpy()) < 1e-5
+    assert G.rel_err(z1.cpu().numpy(), z0.cpu().numpy()) < 2e-5
     for n in b0:
         assert G.rel_err(b1[n].cpu().numpy(), b0[n].cpu().numpy()) < 1e-5, n
     top = max(float(v.norm()) for v in g0.values())

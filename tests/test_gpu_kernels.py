@@ -478,6 +478,16 @@ def test_stage1_recomputed_conv_in_bn_pool(B, dims, training):
         if want_dout:       # d(loss)/d(x) through the separate backward-data kernel, as the encoder's backward does
             dx = ops.conv3d_k3_bwd_data(dout, w.detach().cuda(), mode="f32")
             assert G.rel_err(_ncdhw(dx).numpy(), gx.numpy()) < 1e-5
+    # both arithmetics of the recomputed convolution (default: the f16 split of the other forward convolutions; "f32": exact)
+    for mode in ("f32", "f16x3"):
+        rm3, rv3 = rm.clone().cuda(), rv.clone().cuda()
+        y3, p3, am3, ss3, mean3, wp3 = ops.stage1_fwd(_cl(x), w.detach().cuda(), b.detach().cuda(), gamma.detach().cuda(),
+                                                       beta.detach().cuda(), rm3, rv3, training, want_pool=pool, mode=mode)
+        assert wp3.svr_stage1_arith == (1 if mode == "f16x3" else 0)
+        assert G.rel_err(_ncdhw(y3).numpy(), y_ref.detach().numpy()) < 3e-6, mode
+        g3 = ops.stage1_bwd(_cl(x), wp3, b.detach().cuda(), _cl(dy), _cl(dp) if pool else None, am3 if pool else None, mean3, ss3,
+                            relu_mask=True, training=training)
+        assert G.rel_err(g3[2].cpu().numpy(), gw.numpy()) < 1e-5 and G.rel_err(g3[0].cpu().numpy(), gg.numpy()) < 1e-5, mode
     # the same results as the separate kernels it replaces (conv_in + statistics, BatchNorm + pool) on the same input
     if training:
         rm2, rv2 = rm.clone().cuda(), rv.clone().cuda()
