@@ -12,6 +12,7 @@
 // gemm_f16x3.hip, f32-level accuracy for |x| < 65504 at three products); bf16x6 (three planes, six products, any
 // f32 range) stays selectable.  Both forwards are held to the exact-f32 kernel's gate.
 #include "common.h"
+#include <cstdlib>
 #include "f16x3.h"
 
 using namespace svr;
@@ -401,6 +402,288 @@ __global__ __launch_bounds__(256) void conv3d_brick_x3_kernel(const float *__res
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// PERSISTENT form of the brick kernel for 32 output columns (TNB = 1), round 3.  Measurement builds of the kernel above
+// (tools/exp/conv_variants.sh, SVR_CONV_EXP = 2 / 3 / 5) showed that at 64^3 the matrix instructions are completely hidden
+// (no MFMAs: same time), that the halo tile's global loads cost 19-23 % and that half of that is the WAIT for them: a
+// workgroup that stages a chunk computes nothing, and with two workgroups per CU the other one then has each SIMD to itself,
+// one wave that stalls on every LDS fragment read.  Here a workgroup walks bricks (grid = the resident workgroups) and the
+// NEXT work item's halo tile -- the next 16 / 32-channel chunk of the brick or the first chunk of the next brick -- is
+// fetched into registers before the current item's MFMA steps and split into LDS behind them; the weight pipeline (two
+// register sets, two steps ahead) runs straight through the item boundaries: an item is TEN barrier steps (taps 3 3 3 3 3 3
+// 3 2 2 2), an even number, so the two register sets keep their roles from one item to the next.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int CK, bool F16, int VT>
+__global__ __launch_bounds__(256, 2) void conv3d_brick_p_kernel(const float *__restrict__ in, const uint16_t *__restrict__ P0,
+                                                             int64_t plane_stride, const float *__restrict__ bias,
+                                                             float *__restrict__ out, const float *__restrict__ mask,
+                                                             ConvShape s, int nbz, int nby, int nbx, int nbricks, int mode,
+                                                             const uint32_t *__restrict__ amax, double *__restrict__ spart) {
+  constexpr int NP = 2, NC = 32, TG = 3, STEPS = 10;
+  constexpr int BZ = BRZ * VT, HV = (BZ + 2) * HLY * HLX;
+  constexpr int SL = CK / 8, XW = SL * 4, HR = (BZ + 2) * HLY * HP, KS = CK / 16;
+  constexpr int PIECES = TG * NP * NC * (CK / 8), WPT = (PIECES + 255) / 256;
+  constexpr int HIT = (HV * (CK / 4) + 255) / 256;
+  __shared__ __attribute__((aligned(16))) uint32_t sh[NP][HR * XW];
+  __shared__ __attribute__((aligned(16))) uint32_t sw[2][TG][NP][NC * XW];
+  static_assert(sizeof(sh) >= 256 * 2 * sizeof(float), "halo buffer too small for the statistics reduction");
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int n0 = blockIdx.y * NC;
+  const int hrow = ((wave + 1) * HLY + tile_vy(l31) + 1) * HP + tile_vx(l31) + 1;
+  const int nch = s.Ci / CK;
+  const int nmy = (nbricks - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;   // bricks of this workgroup (>= 1: grid <= bricks)
+  const int nitems = nmy * nch;
+
+  f32x16 acc[VT];
+#pragma unroll
+  for (int v = 0; v < VT; ++v)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[v][r] = 0.f;
+
+  struct Item { int b, z0, y0, x0, k0, brick; };
+  auto decode = [&](int it) {
+    Item I;
+    const int bi = it / nch;
+    I.k0 = (it - bi * nch) * CK;
+    I.brick = (int)blockIdx.x + bi * (int)gridDim.x;
+    int q = I.brick;
+    I.x0 = (q % nbx) * BRX; q /= nbx;
+    I.y0 = (q % nby) * BRY; q /= nby;
+    I.z0 = (q % nbz) * BZ;
+    I.b = q / nbz;
+    return I;
+  };
+
+  // ---- weights: as in the kernel above; step st of an item covers taps tap0(st) .. + 2 (the last three steps: + 1)
+  uint2 wregA[WPT][2], wregB[WPT][2];
+  auto wload = [&](uint2 (&wreg)[WPT][2], int k0, int st) {
+    const int tap0 = st < 7 ? 3 * st : 21 + 2 * (st - 7);
+#pragma unroll
+    for (int i = 0; i < WPT; ++i) {
+      const int idx = t + 256 * i;
+      const int part = idx % (CK / 8), row = (idx / (CK / 8)) % NC, pl = (idx / (CK / 8 * NC)) % NP, tg = idx / (CK / 8 * NC * NP);
+      const bool ok = idx < PIECES && n0 + row < s.Co;
+      const uint16_t *base = P0 + (ok ? pl : 0) * plane_stride;
+      const int tap = min(tap0 + (ok ? tg : 0), 26);   // (the third slot of a two-tap step re-reads tap 26: stored, never used)
+      const uint2 *p = reinterpret_cast<const uint2 *>(base + ((size_t)tap * s.Co + (ok ? n0 + row : 0)) * s.Ci + k0 + part * 8);
+      wreg[i][0] = p[0];
+      wreg[i][1] = p[1];
+    }
+  };
+  auto wstore = [&](const uint2 (&wreg)[WPT][2], int buf) {
+#pragma unroll
+    for (int i = 0; i < WPT; ++i) {
+      const int idx = t + 256 * i;
+      if (idx < PIECES) {
+        const int part = idx % (CK / 8), row = (idx / (CK / 8)) % NC, pl = (idx / (CK / 8 * NC)) % NP, tg = idx / (CK / 8 * NC * NP);
+        *reinterpret_cast<uint4 *>(&sw[buf][tg][pl][slot_dw<SL>(row, part)]) = make_uint4(wreg[i][0].x, wreg[i][0].y, wreg[i][1].x, wreg[i][1].y);
+      }
+    }
+  };
+
+  // ---- halo tile of an item: global -> registers (unconditional, clamped coordinates), later registers -> split -> LDS
+  float4 hreg[HIT];
+  uint32_t hok = 0;
+  // (piece i alone: the item loop issues one piece per step BEHIND that step's weight loads -- the vector-memory counter is in
+  // order, so a wait for a younger weight load also waits for every older halo load: a piece has two steps to arrive)
+  auto halo_load = [&](const Item &I, int i0, int i1) {
+    const float *inb = in + (int64_t)I.b * s.D * s.H * s.W * s.Ci;
+    if (i0 == 0) hok = 0;
+#pragma unroll
+    for (int i = i0; i < i1; ++i) {
+      const int idx = min(t + 256 * i, HV * (CK / 4) - 1);
+      const int hv = idx / (CK / 4), c4 = (idx % (CK / 4)) * 4;
+      const int hx = hv % HLX, hy = (hv / HLX) % HLY, hz = hv / (HLX * HLY);
+      const int gz = I.z0 + hz - 1, gy = I.y0 + hy - 1, gx = I.x0 + hx - 1;
+      if (gz >= 0 && gz < s.D && gy >= 0 && gy < s.H && gx >= 0 && gx < s.W) hok |= 1u << i;
+      const int cz = min(max(gz, 0), s.D - 1), cy = min(max(gy, 0), s.H - 1), cx = min(max(gx, 0), s.W - 1);
+      hreg[i] = *reinterpret_cast<const float4 *>(inb + (((int64_t)cz * s.H + cy) * s.W + cx) * s.Ci + I.k0 + c4);
+    }
+  };
+  auto halo_store = [&]() {
+#pragma unroll
+    for (int i = 0; i < HIT; ++i) {
+      const int idx = t + 256 * i;
+      if (idx >= HV * (CK / 4)) break;
+      const int hv = idx / (CK / 4), c4 = (idx % (CK / 4)) * 4;
+      const int hd = slot_dw<SL>((hv / HLX) * HP + hv % HLX, c4 / 8) + (c4 % 8) / 2;
+      const bool ok = (hok >> i) & 1u;
+      const float4 v = make_float4(ok ? hreg[i].x : 0.f, ok ? hreg[i].y : 0.f, ok ? hreg[i].z : 0.f, ok ? hreg[i].w : 0.f);
+      uint32_t h0, m0, h1, m1;
+      if constexpr (F16) {
+        split_x(v.x, v.y, h0, m0);
+        split_x(v.z, v.w, h1, m1);
+      } else {
+        split2(v.x, v.y, h0, m0);
+        split2(v.z, v.w, h1, m1);
+      }
+      *reinterpret_cast<uint2 *>(&sh[0][hd]) = make_uint2(h0, h1);
+      *reinterpret_cast<uint2 *>(&sh[1][hd]) = make_uint2(m0, m1);
+    }
+  };
+
+  // ---- epilogue of a finished brick (the kernel above's, for TNB = 1); the accumulators start the next brick at zero
+  auto epilogue = [&](const Item &I) {
+    float ssum = 0.f, ssq = 0.f;
+    const int n = n0 + l31, nc = min(n, s.Co - 1);
+    const float bv = (mode == SVR_EPI_BIAS || mode == SVR_EPI_BIAS_RELU) ? bias[nc] : 0.f;
+    const float inv = F16 ? w_scale(amax[0], true) : 1.f;
+#pragma unroll
+    for (int v = 0; v < VT; ++v) {
+      const int gz = I.z0 + wave + BRZ * v;
+      float mk[16];
+      if (mode == SVR_EPI_MASK) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int i = (r & 3) + 8 * (r >> 2) + 4 * lh;
+          const int cy = min(I.y0 + tile_vy(i), s.H - 1), cx = min(I.x0 + tile_vx(i), s.W - 1), cz = min(gz, s.D - 1);
+          mk[r] = mask[((((int64_t)I.b * s.D + cz) * s.H + cy) * s.W + cx) * s.Co + nc];
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int i = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int gy = I.y0 + tile_vy(i), gx = I.x0 + tile_vx(i);
+        if (n < s.Co && gz < s.D && gy < s.H && gx < s.W) {
+          const int64_t o = ((((int64_t)I.b * s.D + gz) * s.H + gy) * s.W + gx) * s.Co + n;
+          float val = (F16 ? acc[v][r] * inv : acc[v][r]) + bv;
+          if (mode == SVR_EPI_BIAS_RELU) val = fmaxf(val, 0.f);
+          if (mode == SVR_EPI_MASK) val = mk[r] > 0.f ? val : 0.f;
+          out[o] = val;
+          ssum += val;
+          ssq = fmaf(val, val, ssq);
+        }
+        acc[v][r] = 0.f;
+      }
+    }
+    if (spart) {  // (uniform) per-brick partial sums, row = brick id: the same rows as the one-brick-per-workgroup kernel writes
+      float *red = reinterpret_cast<float *>(&sh[0][0]);   // the halo tile is free between an item's last step and the next store
+      red[t * 2] = ssum;
+      red[t * 2 + 1] = ssq;
+      __syncthreads();
+      if (t < 2 * NC) {
+        const int which = t / NC, c31 = t % NC;
+        double a2 = 0.0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w)
+#pragma unroll
+          for (int h = 0; h < 2; ++h) a2 += (double)red[(w * 64 + h * 32 + c31) * 2 + which];
+        if (n0 + c31 < s.Co) spart[((int64_t)I.brick * 2 + which) * s.Co + n0 + c31] = a2;
+      }
+      __syncthreads();
+    }
+  };
+
+  Item cur = decode(0);
+  halo_load(cur, 0, HIT);
+  wload(wregA, cur.k0, 0);
+  wload(wregB, cur.k0, 1);
+  halo_store();
+  wstore(wregA, 0);
+  __syncthreads();
+  for (int it = 0; it < nitems; ++it) {
+    const Item nxt = decode(it + 1 < nitems ? it + 1 : it);   // (clamped: the last item fetches itself again, never stored)
+    // the 27 x VT swizzled fragment addresses are loop invariant; hoisted out of the item loop they cost 54 VGPRs and the
+    // kernel its second workgroup per CU.  Opaque per item, each is computed where it is used (4 VALU) and dies there.
+    int hrow_i = hrow;
+    asm volatile("" : "+v"(hrow_i));
+    // step st: MFMAs on LDS buffer st & 1; `nx` holds step st + 1 (in flight since st - 1), `fr` is refilled with st + 2
+    auto step = [&](int st, uint2 (&nx)[WPT][2], uint2 (&fr)[WPT][2]) {
+      const int buf = st & 1, tap0 = st < 7 ? 3 * st : 21 + 2 * (st - 7), nt = st < 7 ? 3 : 2;
+      if (st + 2 < STEPS) wload(fr, cur.k0, st + 2);
+      else wload(fr, nxt.k0, st + 2 - STEPS);
+      halo_load(nxt, (st * HIT) / STEPS, ((st + 1) * HIT) / STEPS);   // this step's share of the next item's halo tile
+#pragma unroll
+      for (int tg = 0; tg < TG; ++tg) {
+        if (tg >= nt) break;
+        const int tap = tap0 + tg;
+        const int arow = hrow_i + ((tap / 9 - 1) * HLY + ((tap / 3) % 3 - 1)) * HP + (tap % 3 - 1);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          const int sub = ks * 2 + lh;
+          const int woff = slot_dw<SL>(l31, sub);
+          if constexpr (F16) {
+            f16x8 xh[VT], xl[VT];
+#pragma unroll
+            for (int v = 0; v < VT; ++v) {
+              const int aoff = slot_dw<SL>(arow + v * BRZ * HLY * HP, sub);
+              xh[v] = read_frag_h(&sh[0][aoff]);
+              xl[v] = read_frag_h(&sh[1][aoff]);
+            }
+            const f16x8 wh = read_frag_h(&sw[buf][tg][0][woff]);
+            const f16x8 wl = read_frag_h(&sw[buf][tg][1][woff]);
+            const f16x8 wq = scale_2m11(wh);
+#pragma unroll
+            for (int v = 0; v < VT; ++v) {
+              acc[v] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xl[v], wq, acc[v], 0, 0, 0);
+              acc[v] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh[v], wl, acc[v], 0, 0, 0);
+              acc[v] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh[v], wh, acc[v], 0, 0, 0);
+            }
+          } else {
+            bf16x8 ah[VT], am[VT];
+#pragma unroll
+            for (int v = 0; v < VT; ++v) {
+              const int aoff = slot_dw<SL>(arow + v * BRZ * HLY * HP, sub);
+              ah[v] = read_frag(&sh[0][aoff]);
+              am[v] = read_frag(&sh[1][aoff]);
+            }
+            const bf16x8 bh = read_frag(&sw[buf][tg][0][woff]);
+            const bf16x8 bm = read_frag(&sw[buf][tg][1][woff]);
+#pragma unroll
+            for (int v = 0; v < VT; ++v) {
+              acc[v] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[v], bh, acc[v], 0, 0, 0);
+              acc[v] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[v], bm, acc[v], 0, 0, 0);
+              acc[v] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[v], bh, acc[v], 0, 0, 0);
+            }
+          }
+        }
+      }
+      wstore(nx, buf ^ 1);
+      __syncthreads();
+    };
+#pragma unroll
+    for (int st = 0; st < STEPS; st += 2) {
+      step(st, wregB, wregA);
+      step(st + 1, wregA, wregB);
+    }
+    if (cur.k0 + CK >= s.Ci) epilogue(cur);   // (uniform) the brick's last chunk
+    halo_store();                              // the next item's tile, fetched before this item's steps
+    __syncthreads();
+    cur = nxt;
+  }
+}
+
+// SVR_CONV_PERSISTENT=0: the one-brick-per-workgroup kernel everywhere (A/B switch, read once)
+bool persistent_bricks() {
+  static const bool on = !(getenv("SVR_CONV_PERSISTENT") && getenv("SVR_CONV_PERSISTENT")[0] == '0');
+  return on;
+}
+// resident workgroups of an instantiation (CUs x occupancy; cached per kernel: immutable after the first call)
+template <int CK, bool F16, int VT>
+int brick_p_resident() {
+  static int resident = 0;
+  if (resident == 0) {
+    int dev = 0, cus = 256, per_cu = 2;
+    if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, conv3d_brick_p_kernel<CK, F16, VT>, 256, 0) != hipSuccess || per_cu < 1) per_cu = 2;
+    (void)hipGetLastError();
+    resident = cus * per_cu;
+  }
+  return resident;
+}
+template <int CK, bool F16, int VT>
+void launch_brick_p(const float *in, const uint16_t *P0, int64_t plane_stride, const float *bias, float *out, const float *mask,
+                    ConvShape sh, int nbz, int nby, int nbx, int ycols, int mode, const uint32_t *amax, double *spart, hipStream_t s) {
+  const int64_t bricks = (int64_t)sh.B * nbz * nby * nbx;
+  int gx = brick_p_resident<CK, F16, VT>() / ycols;
+  if (gx < 1) gx = 1;
+  if (gx > bricks) gx = (int)bricks;
+  hipLaunchKernelGGL((conv3d_brick_p_kernel<CK, F16, VT>), dim3((unsigned)gx, (unsigned)ycols), dim3(256), 0, s, in, P0, plane_stride, bias, out,
+                     mask, sh, nbz, nby, nbx, (int)bricks, mode, amax, spart);
+}
+
 }  // namespace
 
 extern "C" int64_t svr_conv3d_bwd_data_bf16x3_workspace(int32_t Ci, int32_t Co) { return 2LL * 27 * Ci * Co * (int64_t)sizeof(uint16_t) + 256; }
@@ -433,6 +716,9 @@ extern "C" int svr_conv3d_k3_bwd_data_bf16x3(const float *dout, const float *W, 
   const int nbz2 = (int)cdiv(D, 2 * BRZ);
   if (tn == 1 && Co % 16 == 0 && (int64_t)B * nbz2 * nby * nbx * cdiv(Ci, 32) >= 512) {
     // 32 output columns: two z-slices per wave (8x4x8 bricks, 16-channel chunks)
+    if (persistent_bricks())
+      launch_brick_p<16, false, 2>(dout, hi, (int64_t)27 * Ci * Co, nullptr, din, mask, sh, nbz2, nby, nbx, (int)cdiv(Ci, 32), epilogue, nullptr, nullptr, s);
+    else
     hipLaunchKernelGGL((conv3d_brick_x3_kernel<16, 1, 2, false, 2>), dim3((unsigned)((int64_t)B * nbz2 * nby * nbx), (unsigned)cdiv(Ci, 32)),
                        dim3(256), 0, s, dout, hi, (int64_t)27 * Ci * Co, (const float *)nullptr, din, mask, sh, nbz2, nby, nbx, epilogue);
   } else if (Co % 32 == 0) {
@@ -538,6 +824,9 @@ int fwd_f16x3(const float *in, const float *W, const float *bias, float *out, in
   while (tn > 1 && (int64_t)bricks * cdiv(Co, tn * 32) < 512) tn /= 2;   // see svr_conv3d_k3_bwd_data_bf16x3
   const int nbz2 = (int)cdiv(D, 2 * BRZ);
   if (tn == 1 && (int64_t)B * nbz2 * nby * nbx * cdiv(Co, 32) >= 512) {  // two z-slices per wave (8x4x8 bricks, 16-channel chunks)
+    if (persistent_bricks())
+      launch_brick_p<16, true, 2>(in, p0, ps, bias, out, nullptr, sh, nbz2, nby, nbx, (int)cdiv(Co, 32), epilogue, amax, spart, s);
+    else
     hipLaunchKernelGGL((conv3d_brick_x3_kernel<16, 1, 2, true, 2>), dim3((unsigned)((int64_t)B * nbz2 * nby * nbx), (unsigned)cdiv(Co, 32)),
                        dim3(256), 0, s, in, p0, ps, bias, out, (const float *)nullptr, sh, nbz2, nby, nbx, epilogue, amax, spart);
   } else if (Ci % 32 == 0) {

@@ -65,11 +65,24 @@ constexpr int FPLANE = FTM * FLW;      // dwords per plane and k-step
 constexpr int FKSTEP = 2 * FPLANE + 8;   // hi + lo; + 8 dwords: the four k-steps of one producer store (64-column slabs) land on different banks
 constexpr int FSLAB_K = 4;             // k-steps per slab buffer
 constexpr int FSLAB = FSLAB_K * FKSTEP;
-constexpr int FC_MAX_SLABS = 44;
+constexpr int FC_MAX_SLABS = 56;
+// LDS staging of the coarse levels (round 3).  Counters (tools/pmc_counters.sh): the texture addresser is busy 69 % of the
+// kernel's time, the matrix pipe 29 %, LDS 24 % -- the 8 corner loads per (point, displacement, 4 channels) are what bounds
+// it, and 56 of the 81 KB a point reads belong to the two 128-channel levels, where a Morton tile of 64 points touches a box
+// of ~30 (8^3) / ~200 (16^3) voxels 7 x 8 x 64 times.  A level with D, H, W <= 16 and C % 64 == 0 is therefore visited one
+// 64-channel half at a time: a STAGE slab (no k-steps) copies the tile's bounding box x 64 channels into LDS (at most
+// FC_STAGE_VOX voxels: 40 KB; one coalesced float4 per lane), the seven displacement slabs behind it take their corners
+// from there with ds_read_b128 (16 lanes = one voxel's 256 bytes: all 64 banks, conflict free) -- same values, same order
+// of operations, bit-identical features.  The box of every (tile, level) comes from fc0_boxes_kernel (one wave per tile, in
+// front of the launch); a tile whose box is larger, or that straddles two samples, keeps the global loads (box.nvox = 0).
+constexpr int FC_STAGE_VOX = 160;
+constexpr int FC_STAGE_DW = FC_STAGE_VOX * 64;   // dwords of the staging region (64 channels per voxel)
+constexpr int FC_NSTAGE = 2;                     // at most two staged levels
+struct FcBox { int nvox, b, z0, y0, x0, by, bx, pad; };   // per (tile, staged level): 32 bytes, scalar loads
 #ifndef FC_DEPTH
 #define FC_DEPTH 1
 #endif
-constexpr int FC_LDS_BYTES = 2 * FSLAB * 4;
+constexpr int FC_LDS_BYTES = 2 * FSLAB * 4 + FC_STAGE_DW * 4;   // two slab buffers + the staging region
 
 struct FcLevel {
   const float *vol;
@@ -81,11 +94,14 @@ struct FcSlab {  // 32-bit fields: scalar loads.  (Sub-dword fields were fetched
   int level, j0, nj, lp;  // lp: lanes per point (columns / 4); 0 marks the C == 1 slab (7 columns + 9 zeros)
   int k0, nk;             // first k-step and number of k-steps
   int c0, keep;           // first channel; keep: also store the values to the feature matrix
+  int stage, pad;         // -1, or the staged-level index of a level whose corners come from the LDS staging region;
+                          // lp == -1 marks the STAGE slab itself (nk == 0)
 };
 struct FcArgs {
   FcLevel L[SVR_MAX_LEVELS];
   FcSlab S[FC_MAX_SLABS];
   int n_slabs, KF;  // KF: fused reduction length (multiple of 16)
+  int n_stage, stage_level[FC_NSTAGE];
 };
 
 // fused K order -> column of W's (= the feature row's) layout, -1 for the padding of the C == 1 slab
@@ -153,10 +169,12 @@ __device__ __forceinline__ f16x8 lds_frag(const uint32_t *plane, int row, int lh
 //     (uniform base + 32-bit offset), sum_k v_k * w_k in ATen's corner order.  A corner outside the volume contributes
 //     v * 0 with v read from a clamped, i.e. existing, voxel: the sum is bit-identical to skipping it (ATen,
 //     gather.hip) for finite volumes.
-template <int LP, int NJ, bool BF>
+#define LDS_AS __attribute__((address_space(3)))
+template <int LP, int NJ, bool BF, bool STAGED = false>
 __device__ __forceinline__ void produce_slab(const FcLevel L, const FcSlab S, uint32_t *__restrict__ buf,
                                              const float *__restrict__ points, int64_t m0, int64_t M, int N, float disp,
-                                             int ac, float *__restrict__ feat, int row_stride, int pw, int lane) {
+                                             int ac, float *__restrict__ feat, int row_stride, int pw, int lane,
+                                             const uint32_t *stage = nullptr, const FcBox box = FcBox{}) {
   constexpr int PPW0 = 64 / LP, PPW = PPW0 < RPW ? PPW0 : RPW, NP = RPW / PPW, LPI = LP / NJ, NC = LPI * 4, DEPTH = NP <= FC_DEPTH ? NP : (FC_DEPTH < 3 ? FC_DEPTH : 3);  // passes in flight (the fine levels miss the caches: all of a slab's passes)
   const int C = L.C;
   const GLOBAL_AS char *vol = (const GLOBAL_AS char *)L.vol;
@@ -184,10 +202,18 @@ __device__ __forceinline__ void produce_slab(const FcLevel L, const FcSlab S, ui
     wk[k] = __float_as_int((vx[k & 1] && vy[(k >> 1) & 1] && vz[k >> 2]) ? wt : 0.f);
   }
   constexpr uint32_t EB = BF ? 2u : 4u;   // bytes per stored channel value
+  if constexpr (STAGED) {   // byte offsets inside the staged box: [z][y][x][64 channels of this half]
+    (void)b;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ezy[i] = (((zc[i >> 1] - box.z0) * box.by + (yc[i & 1] - box.y0)) * box.bx) * 256;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) ex[a] = (xc[a] - box.x0) * 256;
+  } else {
 #pragma unroll
   for (int i = 0; i < 4; ++i) ezy[i] = (int)((uint32_t)(((b * L.D + zc[i >> 1]) * L.H + yc[i & 1]) * L.W * C) * EB);  // host: < 2^30 elements
 #pragma unroll
   for (int a = 0; a < 2; ++a) ex[a] = (xc[a] * C + S.c0) * (int)EB;
+  }
   // ---- phase 2
   const int g = lane / LP, q = lane % LP, jj = q / LPI, c4 = (q % LPI) * 4;
   const int src0 = (g * NJ + jj) << 2;
@@ -222,6 +248,10 @@ __device__ __forceinline__ void produce_slab(const FcLevel L, const FcSlab S, ui
       for (int k = 0; k < 8; ++k)
         I.v[k] = f32x4{__uint_as_float(raw[k].x << 16), __uint_as_float(raw[k].x & 0xffff0000u), __uint_as_float(raw[k].y << 16),
                        __uint_as_float(raw[k].y & 0xffff0000u)};
+    } else if constexpr (STAGED) {
+      const LDS_AS char *sb = (const LDS_AS char *)stage;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) I.v[k] = *reinterpret_cast<const LDS_AS f32x4 *>(sb + (zy[k >> 1] + x[k & 1]));
     } else {
 #pragma unroll
       for (int k = 0; k < 8; ++k) I.v[k] = *reinterpret_cast<const GLOBAL_AS f32x4 *>(vol + (zy[k >> 1] + x[k & 1]));
@@ -309,11 +339,49 @@ __device__ __forceinline__ void produce_c1(const FcLevel L, const FcSlab S, uint
   }
 }
 
+// STAGE slab: the tile's bounding box of level L, channels [c0, c0 + 64), into the staging region: one float4 per lane and
+// round (16 lanes = one voxel), all loads of the thread issued first.  tp = producer thread (0 .. 255).
+__device__ __forceinline__ void stage_box(const FcLevel L, int c0, const FcBox box, uint32_t *__restrict__ stage, int tp) {
+  if (box.nvox == 0) return;   // (uniform) the tile keeps its global loads
+  const GLOBAL_AS char *vol = (const GLOBAL_AS char *)L.vol;
+  constexpr int R = FC_STAGE_VOX * 16 / 256;
+  const int n16 = box.nvox * 16, byx = box.by * box.bx;
+  const float ibyx = 1.f / (float)byx, ibx = 1.f / (float)box.bx;
+  f32x4 reg[R];
+#pragma unroll
+  for (int i = 0; i < R; ++i) {
+    const int idx = min(tp + 256 * i, n16 - 1), v = idx >> 4, q = idx & 15;
+    const int vz = (int)(((float)v + 0.5f) * ibyx), r = v - vz * byx;   // exact for v, byx <= 160
+    const int vy = (int)(((float)r + 0.5f) * ibx), vx = r - vy * box.bx;
+    const uint32_t off = (uint32_t)((((box.b * L.D + box.z0 + vz) * L.H + box.y0 + vy) * L.W + box.x0 + vx) * L.C + c0 + q * 4) * 4u;
+    reg[i] = *reinterpret_cast<const GLOBAL_AS f32x4 *>(vol + off);
+  }
+#pragma unroll
+  for (int i = 0; i < R; ++i) {
+    const int idx = tp + 256 * i;
+    if (idx < n16) *reinterpret_cast<f32x4 *>(stage + idx * 4) = reg[i];   // [voxel][64 channels]: idx * 4 dwords
+  }
+}
+
 template <bool BF>
 __device__ __forceinline__ void produce(const FcArgs &A, int s, uint32_t *buf, const float *points, int64_t m0, int64_t M,
-                                        int N, float disp, int ac, float *feat, int row_stride, int pw, int lane, int dbg) {
+                                        int N, float disp, int ac, float *feat, int row_stride, int pw, int lane, int dbg,
+                                        uint32_t *stage, const FcBox *__restrict__ boxes) {
   const FcSlab S = A.S[s];
   const FcLevel L = A.L[S.level];
+  if constexpr (!BF) {
+    if (S.stage >= 0) {   // (uniform) a staged level: the STAGE slab itself, or one of its displacement slabs
+      const FcBox box = boxes[S.stage];
+      if (S.lp < 0) {
+        stage_box(L, S.c0, box, stage, pw * 64 + lane);
+        return;
+      }
+      if (box.nvox > 0) {
+        produce_slab<16, 1, BF, true>(L, S, buf, points, m0, M, N, disp, ac, feat, row_stride, pw, lane, stage, box);
+        return;
+      }
+    }
+  }
 #ifdef SVR_FC0_MEASURE
   if ((dbg >> (8 + S.level)) & 1) return;
 #else
@@ -358,8 +426,8 @@ __global__ __launch_bounds__(512, FTM == 64 ? 4 : 2) void gather_fc0_kernel(cons
                                                             const uint32_t *__restrict__ amax, const float *__restrict__ bias,
                                                             float *__restrict__ Y, int64_t ldy, float *__restrict__ feat,
                                                             int row_stride, int pad_start, int64_t M, int N, float disp, int ac,
-                                                            int relu, int dbg_arg) {
-  extern __shared__ uint32_t lds[];
+                                                            int relu, int dbg_arg, const FcBox *__restrict__ boxes) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   const int dbg = FC_DBG(dbg_arg);
   const FcArgs &A = *Ap;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -374,7 +442,13 @@ __global__ __launch_bounds__(512, FTM == 64 ? 4 : 2) void gather_fc0_kernel(cons
     // slab s + 1 is produced into the buffer the consumers are not reading, then the barrier hands both over (ONE call site:
     // with a second, peeled call for slab 0 the compiler inlined all five slab shapes twice and spilled 268 B / lane)
     for (int s = -1; s < S; ++s) {
-      if (s + 1 < S && !(dbg & 1)) produce<BF>(A, s + 1, lds + ((s + 1) & 1) * FSLAB, points, m0, M, N, disp, ac, feat, row_stride, pw, lane, dbg);
+      // (the lane index is made opaque per slab: with seven slab shapes the lane-derived constants of ALL of them were hoisted
+      // in front of this loop and 12 of them spilled; recomputed per slab they cost a few dozen VALU instructions)
+      int lane_s = lane;
+      asm volatile("" : "+v"(lane_s));
+      if (s + 1 < S && !(dbg & 1))
+        produce<BF>(A, s + 1, lds + ((s + 1) & 1) * FSLAB, points, m0, M, N, disp, ac, feat, row_stride, pw, lane_s, dbg, lds + 2 * FSLAB,
+                    boxes + (int64_t)blockIdx.x * FC_NSTAGE);
       slab_barrier();
     }
     return;
@@ -409,6 +483,15 @@ __global__ __launch_bounds__(512, FTM == 64 ? 4 : 2) void gather_fc0_kernel(cons
   }
   slab_barrier();  // slab 0 is in LDS
   int s = 0, kin = 0, ksl = A.S[0].nk, kidx = 0;
+  // a slab without k-steps (a STAGE slab) is one more hand-over and nothing else
+  auto skip_empty = [&]() {
+    while (s < S && ksl == 0) {
+      slab_barrier();
+      ++s;
+      ksl = s < S ? A.S[s].nk : 0;
+    }
+  };
+  skip_empty();
   // `mma_on`: an always-true scalar the compiler cannot see through.  With the k-step body unconditional the register
   // allocator spills 260 B / lane of the accumulators (one basic block for the whole unrolled loop: the launch takes 11.7
   // instead of 2.6 ms); behind a uniform branch -- which is how the kernel was developed, the branch used to be a
@@ -461,6 +544,7 @@ __global__ __launch_bounds__(512, FTM == 64 ? 4 : 2) void gather_fc0_kernel(cons
       ++s;
       kin = 0;
       ksl = s < S ? A.S[s].nk : 0;
+      skip_empty();
     }
   };
   while (kidx < nk) {
@@ -499,10 +583,64 @@ __global__ __launch_bounds__(512, FTM == 64 ? 4 : 2) void gather_fc0_kernel(cons
     }
 }
 
-// slab table of a descriptor; false if a level's channel count has no slab shape
-bool build_slabs(const svr_gather_desc *d, uint32_t keep_mask, FcArgs &A, const int32_t *keep_cols = nullptr) {
+// Bounding box of the clamped corner coordinates (the ones produce_slab reads) of a tile's 64 points x 7 displacements at
+// every staged level: one wave per tile.  nvox = 0: more than FC_STAGE_VOX voxels, or the tile straddles two samples.
+__global__ __launch_bounds__(64) void fc0_boxes_kernel(const FcArgs *__restrict__ Ap, const float *__restrict__ points, int64_t M,
+                                                       int N, float disp, int ac, FcBox *__restrict__ boxes) {
+  static_assert(FTM == 64, "one lane per row of the tile");
+  const FcArgs &A = *Ap;
+  const int lane = threadIdx.x;
+  const int64_t pn = min((int64_t)blockIdx.x * FTM + lane, M - 1);
+  const int b = (int)(pn / N);
+  for (int si = 0; si < A.n_stage; ++si) {
+    const FcLevel L = A.L[A.stage_level[si]];
+    int lo[3] = {1 << 30, 1 << 30, 1 << 30}, hi[3] = {-1, -1, -1};
+    for (int j = 0; j < 7; ++j) {
+      const Corner c = sample_corner(points + pn * 3, j, disp, L.D, L.H, L.W, ac);
+      const Weights w = corner_weights(c);
+      const int i0[3] = {w.z0, w.y0, w.x0}, n[3] = {L.D, L.H, L.W};
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        lo[a] = min(lo[a], min(max(i0[a], 0), n[a] - 1));
+        hi[a] = max(hi[a], min(max(i0[a] + 1, 0), n[a] - 1));
+      }
+    }
+    int bl = b, bh = b;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        lo[a] = min(lo[a], __shfl_xor(lo[a], o));
+        hi[a] = max(hi[a], __shfl_xor(hi[a], o));
+      }
+      bl = min(bl, __shfl_xor(bl, o));
+      bh = max(bh, __shfl_xor(bh, o));
+    }
+    if (lane == 0) {
+      FcBox x;
+      x.b = b; x.z0 = lo[0]; x.y0 = lo[1]; x.x0 = lo[2];
+      x.by = hi[1] - lo[1] + 1; x.bx = hi[2] - lo[2] + 1;
+      const int nv = (hi[0] - lo[0] + 1) * x.by * x.bx;
+      x.nvox = (bl == bh && nv <= FC_STAGE_VOX) ? nv : 0;
+      x.pad = 0;
+      boxes[(int64_t)blockIdx.x * FC_NSTAGE + si] = x;
+    }
+  }
+}
+
+// SVR_FC0_STAGE=0: no LDS staging of the coarse levels (A/B switch, read once; prepare and run must agree, so it is
+// process-wide)
+bool fc0_staging() {
+  static const bool on = !(getenv("SVR_FC0_STAGE") && getenv("SVR_FC0_STAGE")[0] == '0');
+  return on;
+}
+
+// slab table of a descriptor; false if a level's channel count has no slab shape.  stage: coarse levels through LDS
+bool build_slabs(const svr_gather_desc *d, uint32_t keep_mask, FcArgs &A, const int32_t *keep_cols = nullptr, bool stage = false) {
   int ns = 0, k = 0;
-  auto add = [&](int level, int j0, int nj, int lp, int c0, int cols) {
+  A.n_stage = 0;
+  for (int i = 0; i < FC_NSTAGE; ++i) A.stage_level[i] = 0;
+  auto add = [&](int level, int j0, int nj, int lp, int c0, int cols, int st = -1) {
     if (ns >= FC_MAX_SLABS) return false;
     FcSlab &S = A.S[ns++];
     S.level = level;
@@ -513,6 +651,8 @@ bool build_slabs(const svr_gather_desc *d, uint32_t keep_mask, FcArgs &A, const 
     S.nk = cols / FK;
     S.c0 = c0;
     S.keep = (int)((keep_mask >> level) & 1);
+    S.stage = st;
+    S.pad = 0;
     k += cols / FK;
     return true;
   };
@@ -533,8 +673,18 @@ bool build_slabs(const svr_gather_desc *d, uint32_t keep_mask, FcArgs &A, const 
         for (int j = 0; j < 6 && ok; j += 2) ok = add(l, j, 2, 16, 0, 64);
         ok = ok && add(l, 6, 1, 8, 0, 32);
       } else if (C >= 64 && C % 64 == 0) {
-        for (int j = 0; j < 7 && ok; ++j)
-          for (int c0 = 0; c0 < C && ok; c0 += 64) ok = add(l, j, 1, 16, c0, 64);
+        if (stage && FTM == 64 && lv.D <= 16 && lv.H <= 16 && lv.W <= 16 && A.n_stage < FC_NSTAGE) {
+          // staged level: one 64-channel half at a time -- the STAGE slab, then its seven displacement slabs
+          const int st = A.n_stage++;
+          A.stage_level[st] = l;
+          for (int c0 = 0; c0 < C && ok; c0 += 64) {
+            ok = add(l, 0, 0, -1, c0, 0, st);
+            for (int j = 0; j < 7 && ok; ++j) ok = add(l, j, 1, 16, c0, 64, st);
+          }
+        } else {
+          for (int j = 0; j < 7 && ok; ++j)
+            for (int c0 = 0; c0 < C && ok; c0 += 64) ok = add(l, j, 1, 16, c0, 64);
+        }
       } else {
         return false;
       }
@@ -575,7 +725,9 @@ extern "C" int32_t svr_gather_fc0_supported(const svr_gather_desc *d) {
 extern "C" int64_t svr_gather_fc0_workspace(const svr_gather_desc *d, int32_t n_out) {
   FcArgs A;
   if (!d || !build_slabs(d, 0, A)) return 0;
-  return 2 * (int64_t)n_out * A.KF * (int64_t)sizeof(uint16_t) + 1024 + (int64_t)sizeof(FcArgs);
+  const int64_t tiles = cdiv((int64_t)d->B * d->N, FTM);
+  return 2 * (int64_t)n_out * A.KF * (int64_t)sizeof(uint16_t) + 1024 + (int64_t)sizeof(FcArgs) + 256 +
+         tiles * FC_NSTAGE * (int64_t)sizeof(FcBox);
 }
 
 namespace {
@@ -584,6 +736,7 @@ struct FcWorkspace {
   uint32_t *amax;
   uint16_t *p0;
   FcArgs *Ad;
+  FcBox *boxes;   // [tiles][FC_NSTAGE]
 };
 FcWorkspace carve(void *workspace, int32_t n_out, int KF) {
   FcWorkspace w;
@@ -591,6 +744,7 @@ FcWorkspace carve(void *workspace, int32_t n_out, int KF) {
   w.p0 = (uint16_t *)(w.amax + 64);
   uint16_t *p1 = w.p0 + (int64_t)n_out * KF;
   w.Ad = (FcArgs *)(((uintptr_t)(p1 + (int64_t)n_out * KF) + 255) & ~(uintptr_t)255);
+  w.boxes = (FcBox *)(((uintptr_t)(w.Ad + 1) + 255) & ~(uintptr_t)255);
   return w;
 }
 
@@ -626,7 +780,7 @@ extern "C" int svr_gather_fc0_prepare(const svr_gather_desc *d, const float *W, 
   SVR_CHECK(n_out == FTN, SVR_E_UNSUPPORTED, "gather_fc0_prepare: %d output columns (the kernel is built for %d)", n_out, FTN);
   if (ldf <= 0) ldf = d->row_stride;
   FcArgs A;
-  SVR_CHECK(build_slabs(d, keep_levels, A, keep_cols), SVR_E_UNSUPPORTED,
+  SVR_CHECK(build_slabs(d, keep_levels, A, keep_cols, fc0_staging()), SVR_E_UNSUPPORTED,
             "gather_fc0_prepare: a level's channel count has no slab shape (1, 16, 32, 64 k)");
   int64_t kend;
   if ((rc = check_keep(d, A, feat, ldf, keep_levels, &kend)) != SVR_OK) return rc;
@@ -658,7 +812,7 @@ extern "C" int svr_gather_fc0_run(const svr_gather_desc *d, const float *points,
   if (ldf <= 0) ldf = d->row_stride;
   FcArgs A;  // (the slab table is rebuilt on the host only for its sizes and the argument checks; the kernel reads the
              // copy svr_gather_fc0_prepare stored in the workspace)
-  SVR_CHECK(build_slabs(d, keep_levels, A, keep_cols), SVR_E_UNSUPPORTED,
+  SVR_CHECK(build_slabs(d, keep_levels, A, keep_cols, fc0_staging()), SVR_E_UNSUPPORTED,
             "gather_fc0_run: a level's channel count has no slab shape (1, 16, 32, 64 k)");
   int64_t kend;
   if ((rc = check_keep(d, A, feat, ldf, keep_levels, &kend)) != SVR_OK) return rc;
@@ -678,9 +832,12 @@ extern "C" int svr_gather_fc0_run(const svr_gather_desc *d, const float *points,
 #else
   const int dbg = 0;
 #endif
+  if (A.n_stage > 0)   // the tiles' bounding boxes at the staged levels (the points change from call to call)
+    hipLaunchKernelGGL(fc0_boxes_kernel, dim3((unsigned)cdiv(M, FTM)), dim3(64), 0, (hipStream_t)stream, ws.Ad, points, M, d->N,
+                       d->displacement, d->align_corners, ws.boxes);
   hipLaunchKernelGGL(gather_fc0_kernel<false>, dim3((unsigned)cdiv(M, FTM)), dim3(512), FC_LDS_BYTES, (hipStream_t)stream, ws.Ad, points,
                      ws.p0, ws.amax, eb, Y, ldy, feat, (int)ldf, keep_levels ? (int)pad_start : -1, M, d->N, d->displacement,
-                     d->align_corners, relu, dbg);
+                     d->align_corners, relu, dbg, ws.boxes);
   return launch_status("gather_fc0_run");
 }
 
@@ -735,6 +892,6 @@ extern "C" int svr_gather_fc0_bf16_run(const svr_gather_desc *d, const float *po
   const int relu = epilogue == SVR_EPI_BIAS_RELU ? 1 : 0;
   hipLaunchKernelGGL(gather_fc0_kernel<true>, dim3((unsigned)cdiv(M, FTM)), dim3(512), FC_LDS_BYTES, (hipStream_t)stream, ws.Ad, points,
                      ws.p0, ws.amax, eb, reinterpret_cast<float *>(Y), ldy, (float *)nullptr, 0, -1, M, d->N, d->displacement,
-                     d->align_corners, relu, 0);
+                     d->align_corners, relu, 0, (const FcBox *)nullptr);
   return launch_status("gather_fc0_bf16_run");
 }

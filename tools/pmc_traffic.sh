@@ -32,7 +32,8 @@ for f in glob.glob(f"{R}/gpurun_out/pmc_traffic_*/**/*counter_collection.csv", r
         n = r["Kernel_Name"]
         for key in ("gather_fc0_kernel", "gather_bwd_proj_kernel", "gather_fwd_fused_kernel", "gather_bwd_fused_kernel", "gather_bwd_pull_kernel<16", "gather_bwd_pull_kernel<32",
                     "gather_bwd_pull_kernel<64", "stage1_kernel<0>", "stage1_kernel<1>", "stage1_kernel<2>", "stage1_kernel<3>"):
-            if key in n:
+            # (stage1_kernel<MODE, H3>: the key keeps the mode only)
+            if key in n or (key.startswith("stage1_kernel<") and key[:-1] + "," in n):
                 agg[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
                 rows[r["Counter_Name"]].append(r)
 for cname, rr in rows.items():                      # the gather rows of each pass, for profiles/
