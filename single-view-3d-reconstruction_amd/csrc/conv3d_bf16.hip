@@ -425,6 +425,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_brick_p_kernel(const float *__r
   constexpr int SL = CK / 8, XW = SL * 4, HR = (BZ + 2) * HLY * HP, KS = CK / 16;
   constexpr int PIECES = TG * NP * NC * (CK / 8), WPT = (PIECES + 255) / 256;
   constexpr int HIT = (HV * (CK / 4) + 255) / 256;
+  static_assert(CK == 16, "the piece -> (tap, plane, row, part) split below is written out for 16-channel chunks");
   __shared__ __attribute__((aligned(16))) uint32_t sh[NP][HR * XW];
   __shared__ __attribute__((aligned(16))) uint32_t sw[2][TG][NP][NC * XW];
   static_assert(sizeof(sh) >= 256 * 2 * sizeof(float), "halo buffer too small for the statistics reduction");
@@ -436,6 +437,13 @@ __global__ __launch_bounds__(256, 2) void conv3d_brick_p_kernel(const float *__r
   const int nmy = (nbricks - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;   // bricks of this workgroup (>= 1: grid <= bricks)
   const int nitems = nmy * nch;
 
+  // ADDRESS ARITHMETIC (round 3, SQ counters: this kernel issued 1 520 vector-ALU instructions per item and wave next to 162
+  // MFMAs -- 44 % + 38 % of the SIMDs' time, and the two add up; a fifth of them were 32 / 64-bit integer multiplies of the
+  // flat index arithmetic).  Everything below is 32-bit: wave-uniform bases (SGPRs) + per-lane offsets inside ONE sample
+  // (host: D H W <= 2^24 voxels and D H W max(Ci, Co) < 2^30 elements, so v_mad_u32_u24 is exact and byte offsets fit),
+  // and what only depends on the thread is computed once, in front of the item loop.
+  const uint32_t HW = (uint32_t)(s.H * s.W);
+
   f32x16 acc[VT];
 #pragma unroll
   for (int v = 0; v < VT; ++v)
@@ -443,7 +451,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_brick_p_kernel(const float *__r
     for (int r = 0; r < 16; ++r) acc[v][r] = 0.f;
 
   struct Item { int b, z0, y0, x0, k0, brick; };
-  auto decode = [&](int it) {
+  auto decode = [&](int it) {   // (wave-uniform: scalar unit)
     Item I;
     const int bi = it / nch;
     I.k0 = (it - bi * nch) * CK;
@@ -456,59 +464,77 @@ __global__ __launch_bounds__(256, 2) void conv3d_brick_p_kernel(const float *__r
     return I;
   };
 
-  // ---- weights: as in the kernel above; step st of an item covers taps tap0(st) .. + 2 (the last three steps: + 1)
-  uint2 wregA[WPT][2], wregB[WPT][2];
-  auto wload = [&](uint2 (&wreg)[WPT][2], int k0, int st) {
+  // ---- weights: piece 0 of a thread = (tap tg0 of the step, plane, row, 8-channel part), piece 1 (threads < 128) = the
+  // step's third tap; step st of an item covers taps tap0(st) .. + 2 (the last three steps: + 1, no piece 1)
+  const int p0part = t & 1, p0row = (t >> 1) & 31, p0pl = (t >> 6) & 1, p0tg = t >> 7;
+  const bool rowok = n0 + p0row < s.Co;
+  const uint32_t wtap = (uint32_t)(s.Co * s.Ci) * 2u;                             // bytes per tap of one plane
+  const uint32_t wrow = (uint32_t)((rowok ? n0 + p0row : 0) * s.Ci + p0part * 8) * 2u;
+  const uint32_t wof0 = (uint32_t)p0pl * (uint32_t)plane_stride * 2u + (uint32_t)p0tg * wtap + wrow;   // + (tap0 Co Ci + k0) * 2
+  const uint32_t wof1 = (uint32_t)((t >> 6) & 1) * (uint32_t)plane_stride * 2u + 2u * wtap + wrow;      // piece 1: tg = 2, plane = (t >> 6) & 1
+  const int wst0 = (int)(&sw[0][p0tg][p0pl][slot_dw<SL>(p0row, p0part)] - &sw[0][0][0][0]);
+  const int wst1 = (int)(&sw[0][2][(t >> 6) & 1][slot_dw<SL>(p0row, p0part)] - &sw[0][0][0][0]);
+  constexpr int WBUF = TG * NP * NC * XW;   // dwords per weight buffer
+  static_assert(PIECES == 384 && WPT == 2, "pieces 0 (256 threads) and 1 (128 threads)");
+  // (scalars, not arrays: a two-element array with a conditionally written element was demoted to LDS by the compiler)
+  struct WReg { uint4 p0, p1; };
+  WReg wregA, wregB;
+  wregA.p1 = wregB.p1 = make_uint4(0u, 0u, 0u, 0u);
+  const char *Pb = reinterpret_cast<const char *>(P0);
+  auto wload = [&](WReg &wreg, int k0, int st) {
     const int tap0 = st < 7 ? 3 * st : 21 + 2 * (st - 7);
-#pragma unroll
-    for (int i = 0; i < WPT; ++i) {
-      const int idx = t + 256 * i;
-      const int part = idx % (CK / 8), row = (idx / (CK / 8)) % NC, pl = (idx / (CK / 8 * NC)) % NP, tg = idx / (CK / 8 * NC * NP);
-      const bool ok = idx < PIECES && n0 + row < s.Co;
-      const uint16_t *base = P0 + (ok ? pl : 0) * plane_stride;
-      const int tap = min(tap0 + (ok ? tg : 0), 26);   // (the third slot of a two-tap step re-reads tap 26: stored, never used)
-      const uint2 *p = reinterpret_cast<const uint2 *>(base + ((size_t)tap * s.Co + (ok ? n0 + row : 0)) * s.Ci + k0 + part * 8);
-      wreg[i][0] = p[0];
-      wreg[i][1] = p[1];
-    }
+    const uint32_t sb = (uint32_t)tap0 * wtap + (uint32_t)k0 * 2u;   // (uniform)
+    wreg.p0 = *reinterpret_cast<const uint4 *>(Pb + (wof0 + sb));
+    if (st < 7) wreg.p1 = *reinterpret_cast<const uint4 *>(Pb + (wof1 + sb));   // (compile time: the two-tap steps have no third tap)
   };
-  auto wstore = [&](const uint2 (&wreg)[WPT][2], int buf) {
-#pragma unroll
-    for (int i = 0; i < WPT; ++i) {
-      const int idx = t + 256 * i;
-      if (idx < PIECES) {
-        const int part = idx % (CK / 8), row = (idx / (CK / 8)) % NC, pl = (idx / (CK / 8 * NC)) % NP, tg = idx / (CK / 8 * NC * NP);
-        *reinterpret_cast<uint4 *>(&sw[buf][tg][pl][slot_dw<SL>(row, part)]) = make_uint4(wreg[i][0].x, wreg[i][0].y, wreg[i][1].x, wreg[i][1].y);
-      }
-    }
+  auto wstore = [&](const WReg &wreg, int buf, int st_of_data) {
+    uint32_t *base = &sw[0][0][0][0] + buf * WBUF;
+    *reinterpret_cast<uint4 *>(base + wst0) = wreg.p0;
+    if (st_of_data < 7 && t < 128) *reinterpret_cast<uint4 *>(base + wst1) = wreg.p1;
   };
 
-  // ---- halo tile of an item: global -> registers (unconditional, clamped coordinates), later registers -> split -> LDS
+  // ---- halo tile of an item: global -> registers (unconditional, clamped coordinates), later registers -> split -> LDS.
+  // Per piece the thread's halo voxel (hz, hy, hx) and its LDS offset are constants: packed once (8 + 8 + 8 + 8 bits would
+  // not hold the LDS offset: two packed registers per piece would cost 20 VGPRs; the LDS offset is recomputed, 6 VALU)
+  constexpr int C4 = CK / 4;
+  const int c4 = (t % C4) * 4;   // (256 % C4 == 0: the same channel quad in every piece)
   float4 hreg[HIT];
   uint32_t hok = 0;
-  // (piece i alone: the item loop issues one piece per step BEHIND that step's weight loads -- the vector-memory counter is in
-  // order, so a wait for a younger weight load also waits for every older halo load: a piece has two steps to arrive)
+  auto halo_vox = [&](int i, int &hz, int &hy, int &hx) {   // compile-time i: constants folded per piece, t-dependent part small
+    const int idx = min(t + 256 * i, HV * C4 - 1);
+    const int hv = idx / C4;
+    hx = hv % HLX;
+    const int q = hv / HLX;
+    hy = q % HLY;
+    hz = q / HLY;
+  };
+  // (hz, hy, hx) of every piece, packed: 5 + 3 + 4 bits
+  int hpk[HIT];
+#pragma unroll
+  for (int i = 0; i < HIT; ++i) {
+    int hz, hy, hx;
+    halo_vox(i, hz, hy, hx);
+    hpk[i] = hz | (hy << 5) | (hx << 8);
+  }
   auto halo_load = [&](const Item &I, int i0, int i1) {
-    const float *inb = in + (int64_t)I.b * s.D * s.H * s.W * s.Ci;
+    const char *inb = reinterpret_cast<const char *>(in + (int64_t)I.b * s.D * s.H * s.W * s.Ci);   // (uniform)
     if (i0 == 0) hok = 0;
 #pragma unroll
     for (int i = i0; i < i1; ++i) {
-      const int idx = min(t + 256 * i, HV * (CK / 4) - 1);
-      const int hv = idx / (CK / 4), c4 = (idx % (CK / 4)) * 4;
-      const int hx = hv % HLX, hy = (hv / HLX) % HLY, hz = hv / (HLX * HLY);
-      const int gz = I.z0 + hz - 1, gy = I.y0 + hy - 1, gx = I.x0 + hx - 1;
-      if (gz >= 0 && gz < s.D && gy >= 0 && gy < s.H && gx >= 0 && gx < s.W) hok |= 1u << i;
-      const int cz = min(max(gz, 0), s.D - 1), cy = min(max(gy, 0), s.H - 1), cx = min(max(gx, 0), s.W - 1);
-      hreg[i] = *reinterpret_cast<const float4 *>(inb + (((int64_t)cz * s.H + cy) * s.W + cx) * s.Ci + I.k0 + c4);
+      const int gz = I.z0 - 1 + (hpk[i] & 31), gy = I.y0 - 1 + ((hpk[i] >> 5) & 7), gx = I.x0 - 1 + (hpk[i] >> 8);
+      if ((unsigned)gz < (unsigned)s.D && (unsigned)gy < (unsigned)s.H && (unsigned)gx < (unsigned)s.W) hok |= 1u << i;
+      const uint32_t cz = (uint32_t)min(max(gz, 0), s.D - 1), cy = (uint32_t)min(max(gy, 0), s.H - 1), cx = (uint32_t)min(max(gx, 0), s.W - 1);
+      const uint32_t vox = __umul24(__umul24(cz, (uint32_t)s.H) + cy, (uint32_t)s.W) + cx;
+      const uint32_t off = (__umul24(vox, (uint32_t)s.Ci) + (uint32_t)(I.k0 + c4)) * 4u;
+      hreg[i] = *reinterpret_cast<const float4 *>(inb + off);
     }
   };
   auto halo_store = [&]() {
 #pragma unroll
     for (int i = 0; i < HIT; ++i) {
-      const int idx = t + 256 * i;
-      if (idx >= HV * (CK / 4)) break;
-      const int hv = idx / (CK / 4), c4 = (idx % (CK / 4)) * 4;
-      const int hd = slot_dw<SL>((hv / HLX) * HP + hv % HLX, c4 / 8) + (c4 % 8) / 2;
+      if (t + 256 * i >= HV * C4) break;
+      const int row = ((hpk[i] & 31) * HLY + ((hpk[i] >> 5) & 7)) * HP + (hpk[i] >> 8);
+      const int hd = slot_dw<SL>(row, c4 / 8) + (c4 % 8) / 2;
       const bool ok = (hok >> i) & 1u;
       const float4 v = make_float4(ok ? hreg[i].x : 0.f, ok ? hreg[i].y : 0.f, ok ? hreg[i].z : 0.f, ok ? hreg[i].w : 0.f);
       uint32_t h0, m0, h1, m1;
@@ -524,34 +550,45 @@ __global__ __launch_bounds__(256, 2) void conv3d_brick_p_kernel(const float *__r
     }
   };
 
-  // ---- epilogue of a finished brick (the kernel above's, for TNB = 1); the accumulators start the next brick at zero
+  // ---- epilogue of a finished brick (the kernel above's, for TNB = 1); the accumulators start the next brick at zero.
+  // Element offset of result r = (uniform voxel base + lane part) * Co + n: the lane part (vy W + vx) of the 16 results is
+  // one of two compile-time tables (lh), the voxel base is scalar
   auto epilogue = [&](const Item &I) {
     float ssum = 0.f, ssq = 0.f;
     const int n = n0 + l31, nc = min(n, s.Co - 1);
     const float bv = (mode == SVR_EPI_BIAS || mode == SVR_EPI_BIAS_RELU) ? bias[nc] : 0.f;
     const float inv = F16 ? w_scale(amax[0], true) : 1.f;
+    const bool interior = I.z0 + BZ <= s.D && I.y0 + BRY <= s.H && I.x0 + BRX <= s.W && n0 + NC <= s.Co;   // (uniform)
+    char *outb = reinterpret_cast<char *>(out + (int64_t)I.b * s.D * s.H * s.W * s.Co);
+    const char *maskb = reinterpret_cast<const char *>(mask + (mode == SVR_EPI_MASK ? (int64_t)I.b * s.D * s.H * s.W * s.Co : 0));
 #pragma unroll
     for (int v = 0; v < VT; ++v) {
       const int gz = I.z0 + wave + BRZ * v;
+      const uint32_t vbase = __umul24((uint32_t)min(gz, s.D - 1), HW) + __umul24((uint32_t)I.y0, (uint32_t)s.W) + (uint32_t)I.x0;   // (uniform)
+      uint32_t off[16];
+      bool okr[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int i0 = (r & 3) + 8 * (r >> 2);                 // MFMA row of lanes 0 .. 31; lanes 32 .. 63: + 4
+        const int vy = lh ? tile_vy(i0 + 4) : tile_vy(i0), vx = lh ? tile_vx(i0 + 4) : tile_vx(i0);   // two constants, one select each
+        const int gy = I.y0 + vy, gx = I.x0 + vx;
+        okr[r] = interior || (n < s.Co && gz < s.D && gy < s.H && gx < s.W);
+        // (a voxel outside the volume gets the offset of a clamped one: never stored, its mask value never used)
+        const uint32_t lv = __umul24((uint32_t)min(vy, s.H - 1 - I.y0), (uint32_t)s.W) + (uint32_t)min(vx, s.W - 1 - I.x0);
+        off[r] = (__umul24(vbase + lv, (uint32_t)s.Co) + (uint32_t)nc) * 4u;
+      }
       float mk[16];
       if (mode == SVR_EPI_MASK) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int i = (r & 3) + 8 * (r >> 2) + 4 * lh;
-          const int cy = min(I.y0 + tile_vy(i), s.H - 1), cx = min(I.x0 + tile_vx(i), s.W - 1), cz = min(gz, s.D - 1);
-          mk[r] = mask[((((int64_t)I.b * s.D + cz) * s.H + cy) * s.W + cx) * s.Co + nc];
-        }
+        for (int r = 0; r < 16; ++r) mk[r] = *reinterpret_cast<const float *>(maskb + off[r]);
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int i = (r & 3) + 8 * (r >> 2) + 4 * lh;
-        const int gy = I.y0 + tile_vy(i), gx = I.x0 + tile_vx(i);
-        if (n < s.Co && gz < s.D && gy < s.H && gx < s.W) {
-          const int64_t o = ((((int64_t)I.b * s.D + gz) * s.H + gy) * s.W + gx) * s.Co + n;
+        if (okr[r]) {
           float val = (F16 ? acc[v][r] * inv : acc[v][r]) + bv;
           if (mode == SVR_EPI_BIAS_RELU) val = fmaxf(val, 0.f);
           if (mode == SVR_EPI_MASK) val = mk[r] > 0.f ? val : 0.f;
-          out[o] = val;
+          *reinterpret_cast<float *>(outb + off[r]) = val;
           ssum += val;
           ssq = fmaf(val, val, ssq);
         }
@@ -576,21 +613,28 @@ __global__ __launch_bounds__(256, 2) void conv3d_brick_p_kernel(const float *__r
     }
   };
 
+  // W fragment offset of this lane inside a tap's plane (rows = output columns)
+  int woff[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) woff[ks] = slot_dw<SL>(l31, ks * 2 + lh);
+
   Item cur = decode(0);
   halo_load(cur, 0, HIT);
   wload(wregA, cur.k0, 0);
   wload(wregB, cur.k0, 1);
   halo_store();
-  wstore(wregA, 0);
+  wstore(wregA, 0, 0);
   __syncthreads();
   for (int it = 0; it < nitems; ++it) {
     const Item nxt = decode(it + 1 < nitems ? it + 1 : it);   // (clamped: the last item fetches itself again, never stored)
-    // the 27 x VT swizzled fragment addresses are loop invariant; hoisted out of the item loop they cost 54 VGPRs and the
-    // kernel its second workgroup per CU.  Opaque per item, each is computed where it is used (4 VALU) and dies there.
+    // the 27 swizzled fragment addresses are loop invariant; hoisted out of the item loop they cost 27 VGPRs and the kernel
+    // its second workgroup per CU.  Opaque per item, each is computed where it is used (4 VALU) and dies there; the second
+    // z-slice of the wave sits BRZ HLY HP = 288 rows further -- a multiple of 16, so the swizzle bit is the same and its
+    // address is an immediate offset
     int hrow_i = hrow;
     asm volatile("" : "+v"(hrow_i));
     // step st: MFMAs on LDS buffer st & 1; `nx` holds step st + 1 (in flight since st - 1), `fr` is refilled with st + 2
-    auto step = [&](int st, uint2 (&nx)[WPT][2], uint2 (&fr)[WPT][2]) {
+    auto step = [&](int st, WReg &nx, WReg &fr) {
       const int buf = st & 1, tap0 = st < 7 ? 3 * st : 21 + 2 * (st - 7), nt = st < 7 ? 3 : 2;
       if (st + 2 < STEPS) wload(fr, cur.k0, st + 2);
       else wload(fr, nxt.k0, st + 2 - STEPS);
@@ -603,17 +647,18 @@ __global__ __launch_bounds__(256, 2) void conv3d_brick_p_kernel(const float *__r
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
           const int sub = ks * 2 + lh;
-          const int woff = slot_dw<SL>(l31, sub);
+          const int aoff = slot_dw<SL>(arow, sub);
+          static_assert((BRZ * HLY * HP) % 16 == 0, "second z-slice: same swizzle");
+          constexpr int VSTEP = BRZ * HLY * HP * XW;   // dwords between the wave's z-slices
           if constexpr (F16) {
             f16x8 xh[VT], xl[VT];
 #pragma unroll
             for (int v = 0; v < VT; ++v) {
-              const int aoff = slot_dw<SL>(arow + v * BRZ * HLY * HP, sub);
-              xh[v] = read_frag_h(&sh[0][aoff]);
-              xl[v] = read_frag_h(&sh[1][aoff]);
+              xh[v] = read_frag_h(&sh[0][aoff + v * VSTEP]);
+              xl[v] = read_frag_h(&sh[1][aoff + v * VSTEP]);
             }
-            const f16x8 wh = read_frag_h(&sw[buf][tg][0][woff]);
-            const f16x8 wl = read_frag_h(&sw[buf][tg][1][woff]);
+            const f16x8 wh = read_frag_h(&sw[buf][tg][0][woff[ks]]);
+            const f16x8 wl = read_frag_h(&sw[buf][tg][1][woff[ks]]);
             const f16x8 wq = scale_2m11(wh);
 #pragma unroll
             for (int v = 0; v < VT; ++v) {
@@ -625,12 +670,11 @@ __global__ __launch_bounds__(256, 2) void conv3d_brick_p_kernel(const float *__r
             bf16x8 ah[VT], am[VT];
 #pragma unroll
             for (int v = 0; v < VT; ++v) {
-              const int aoff = slot_dw<SL>(arow + v * BRZ * HLY * HP, sub);
-              ah[v] = read_frag(&sh[0][aoff]);
-              am[v] = read_frag(&sh[1][aoff]);
+              ah[v] = read_frag(&sh[0][aoff + v * VSTEP]);
+              am[v] = read_frag(&sh[1][aoff + v * VSTEP]);
             }
-            const bf16x8 bh = read_frag(&sw[buf][tg][0][woff]);
-            const bf16x8 bm = read_frag(&sw[buf][tg][1][woff]);
+            const bf16x8 bh = read_frag(&sw[buf][tg][0][woff[ks]]);
+            const bf16x8 bm = read_frag(&sw[buf][tg][1][woff[ks]]);
 #pragma unroll
             for (int v = 0; v < VT; ++v) {
               acc[v] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[v], bh, acc[v], 0, 0, 0);
@@ -640,7 +684,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_brick_p_kernel(const float *__r
           }
         }
       }
-      wstore(nx, buf ^ 1);
+      wstore(nx, buf ^ 1, (st + 1) % STEPS);
       __syncthreads();
     };
 #pragma unroll
@@ -649,16 +693,18 @@ __global__ __launch_bounds__(256, 2) void conv3d_brick_p_kernel(const float *__r
       step(st + 1, wregA, wregB);
     }
     if (cur.k0 + CK >= s.Ci) epilogue(cur);   // (uniform) the brick's last chunk
-    halo_store();                              // the next item's tile, fetched before this item's steps
+    halo_store();                              // the next item's tile, fetched during this item's steps
     __syncthreads();
     cur = nxt;
   }
 }
 
 // SVR_CONV_PERSISTENT=0: the one-brick-per-workgroup kernel everywhere (A/B switch, read once)
-bool persistent_bricks() {
+bool persistent_bricks(const ConvShape &sh) {
   static const bool on = !(getenv("SVR_CONV_PERSISTENT") && getenv("SVR_CONV_PERSISTENT")[0] == '0');
-  return on;
+  // the kernel's 24-bit voxel index multiplies and 32-bit byte offsets inside one sample
+  const int64_t vox = (int64_t)sh.D * sh.H * sh.W, cmax = sh.Ci > sh.Co ? sh.Ci : sh.Co;
+  return on && vox <= (1LL << 24) && vox * cmax < (1LL << 30);
 }
 // resident workgroups of an instantiation (CUs x occupancy; cached per kernel: immutable after the first call)
 template <int CK, bool F16, int VT>
@@ -716,7 +762,7 @@ extern "C" int svr_conv3d_k3_bwd_data_bf16x3(const float *dout, const float *W, 
   const int nbz2 = (int)cdiv(D, 2 * BRZ);
   if (tn == 1 && Co % 16 == 0 && (int64_t)B * nbz2 * nby * nbx * cdiv(Ci, 32) >= 512) {
     // 32 output columns: two z-slices per wave (8x4x8 bricks, 16-channel chunks)
-    if (persistent_bricks())
+    if (persistent_bricks(sh))
       launch_brick_p<16, false, 2>(dout, hi, (int64_t)27 * Ci * Co, nullptr, din, mask, sh, nbz2, nby, nbx, (int)cdiv(Ci, 32), epilogue, nullptr, nullptr, s);
     else
     hipLaunchKernelGGL((conv3d_brick_x3_kernel<16, 1, 2, false, 2>), dim3((unsigned)((int64_t)B * nbz2 * nby * nbx), (unsigned)cdiv(Ci, 32)),
@@ -824,7 +870,7 @@ int fwd_f16x3(const float *in, const float *W, const float *bias, float *out, in
   while (tn > 1 && (int64_t)bricks * cdiv(Co, tn * 32) < 512) tn /= 2;   // see svr_conv3d_k3_bwd_data_bf16x3
   const int nbz2 = (int)cdiv(D, 2 * BRZ);
   if (tn == 1 && (int64_t)B * nbz2 * nby * nbx * cdiv(Co, 32) >= 512) {  // two z-slices per wave (8x4x8 bricks, 16-channel chunks)
-    if (persistent_bricks())
+    if (persistent_bricks(sh))
       launch_brick_p<16, true, 2>(in, p0, ps, bias, out, nullptr, sh, nbz2, nby, nbx, (int)cdiv(Co, 32), epilogue, amax, spart, s);
     else
     hipLaunchKernelGGL((conv3d_brick_x3_kernel<16, 1, 2, true, 2>), dim3((unsigned)((int64_t)B * nbz2 * nby * nbx), (unsigned)cdiv(Co, 32)),
