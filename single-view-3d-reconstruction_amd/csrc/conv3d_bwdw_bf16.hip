@@ -128,7 +128,7 @@ __global__ __launch_bounds__(NT) void conv3d_bwd_weight_x3_kernel(const float *_
   const int grp = wave & 3, half = wave >> 2;
   const int pair = blockIdx.y;
   const int ci0 = (pair / co_tiles) * 32, co0 = (pair % co_tiles) * 32;
-  const int64_t bricks = (int64_t)s.B * nbz * nby * nbx;
+  const int bricks = s.B * nbz * nby * nbx;   // (host: < 2^31)
 
   // the next brick travels in two phases: phase 0 = input items 0, 1 of this thread, phase 1 = input item 2 + its dout item
   float4 ia[2][2], da[2];
@@ -138,14 +138,16 @@ __global__ __launch_bounds__(NT) void conv3d_bwd_weight_x3_kernel(const float *_
   const bool want_db = dbpart != nullptr && ci0 == 0;
   float4 dbs = make_float4(0.f, 0.f, 0.f, 0.f);
 
-  auto load = [&](int64_t brick, int ph) {
-    int64_t q = brick;
-    const int bx = (int)(q % nbx); q /= nbx;
-    const int by = (int)(q % nby); q /= nby;
-    const int bz = (int)(q % nbz);
-    const int64_t b = q / nbz;
+  // (32-bit brick arithmetic: the 64-bit divisions of the first version were ~1 000 scalar instructions per brick and wave,
+  // eight waves of them per CU against ~10 000 cycles per brick)
+  auto load = [&](int brick, int ph) {
+    int q = brick;
+    const int bx = q % nbx; q /= nbx;
+    const int by = q % nby; q /= nby;
+    const int bz = q % nbz;
+    const int b = q / nbz;
     const int z0 = bz * BRZ, y0 = by * BRY, x0 = bx * BRX;
-    const float *inb = in + b * (int64_t)s.D * s.H * s.W * s.Ci;
+    const float *inb = in + (int64_t)b * s.D * s.H * s.W * s.Ci;
 #pragma unroll
     for (int j = 0; j < (ph == 0 ? 2 : 1); ++j) {
       const int idx = min(t + NT * (ph * 2 + j), IN_ITEMS - 1);
@@ -155,29 +157,32 @@ __global__ __launch_bounds__(NT) void conv3d_bwd_weight_x3_kernel(const float *_
       // end of the branch, which serialises the whole prefetch); out-of-range voxels are zeroed in store()
       const bool rowok = gz >= 0 && gz < s.D && gy >= 0 && gy < s.H && ci0 + cg * 4 < s.Ci;
       const int cz = min(max(gz, 0), s.D - 1), cy = min(max(gy, 0), s.H - 1), cc = min(ci0 + cg * 4, s.Ci - 4);
-      const float *p = inb + ((int64_t)cz * s.H + cy) * s.W * s.Ci + cc;
+      // (uniform base + 32-bit byte offsets, 24-bit multiplies: the host checks the ranges)
+      const uint32_t ro = __umul24(__umul24(__umul24((uint32_t)cz, (uint32_t)s.H) + (uint32_t)cy, (uint32_t)s.W), (uint32_t)s.Ci) + (uint32_t)cc;
+      const char *p = reinterpret_cast<const char *>(inb);
 #if defined(SVR_WG_EXP) && SVR_WG_EXP == 2   // measurement build: no global loads of the next brick
       ia[j][0] = make_float4((float)idx, 1.f, (float)brick, 3.f);
       ia[j][1] = make_float4((float)(uintptr_t)p, 1.f, 2.f, 3.f);
 #else
-      ia[j][0] = *reinterpret_cast<const float4 *>(p + (int64_t)min(max(gx, 0), s.W - 1) * s.Ci);
-      ia[j][1] = *reinterpret_cast<const float4 *>(p + (int64_t)min(max(gx + 1, 0), s.W - 1) * s.Ci);
+      ia[j][0] = *reinterpret_cast<const float4 *>(p + (ro + __umul24((uint32_t)min(max(gx, 0), s.W - 1), (uint32_t)s.Ci)) * 4u);
+      ia[j][1] = *reinterpret_cast<const float4 *>(p + (ro + __umul24((uint32_t)min(max(gx + 1, 0), s.W - 1), (uint32_t)s.Ci)) * 4u);
 #endif
       iok[j] = (rowok && gx >= 0 && gx < s.W ? 1 : 0) | (rowok && gx + 1 >= 0 && gx + 1 < s.W ? 2 : 0);
     }
     if (ph == 1) {
-      const float *dob = dout + b * (int64_t)s.D * s.H * s.W * s.Co;
+      const float *dob = dout + (int64_t)b * s.D * s.H * s.W * s.Co;
       const int row = t >> 5, pr = (t & 31) >> 3, cg = t & 7;
       const int gz = z0 + (row >> 2), gy = y0 + (row & 3), gx = x0 + 2 * pr;
       const bool rowok = gz < s.D && gy < s.H && co0 + cg * 4 < s.Co;
       const int cz = min(gz, s.D - 1), cy = min(gy, s.H - 1), cc = min(co0 + cg * 4, s.Co - 4);
-      const float *p = dob + ((int64_t)cz * s.H + cy) * s.W * s.Co + cc;
+      const uint32_t ro = __umul24(__umul24(__umul24((uint32_t)cz, (uint32_t)s.H) + (uint32_t)cy, (uint32_t)s.W), (uint32_t)s.Co) + (uint32_t)cc;
+      const char *p = reinterpret_cast<const char *>(dob);
 #if defined(SVR_WG_EXP) && SVR_WG_EXP == 2
       da[0] = make_float4((float)t, 1.f, (float)brick, 3.f);
       da[1] = make_float4((float)(uintptr_t)p, 1.f, 2.f, 3.f);
 #else
-      da[0] = *reinterpret_cast<const float4 *>(p + (int64_t)min(gx, s.W - 1) * s.Co);
-      da[1] = *reinterpret_cast<const float4 *>(p + (int64_t)min(gx + 1, s.W - 1) * s.Co);
+      da[0] = *reinterpret_cast<const float4 *>(p + (ro + __umul24((uint32_t)min(gx, s.W - 1), (uint32_t)s.Co)) * 4u);
+      da[1] = *reinterpret_cast<const float4 *>(p + (ro + __umul24((uint32_t)min(gx + 1, s.W - 1), (uint32_t)s.Co)) * 4u);
 #endif
       dok = (rowok && gx < s.W ? 1 : 0) | (rowok && gx + 1 < s.W ? 2 : 0);
     }
@@ -228,7 +233,7 @@ __global__ __launch_bounds__(NT) void conv3d_bwd_weight_x3_kernel(const float *_
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
-  int64_t brick = blockIdx.x;
+  int brick = (int)blockIdx.x;
   if (brick < bricks) {
     load(brick, 0);
     store(lds, 0);
@@ -237,8 +242,8 @@ __global__ __launch_bounds__(NT) void conv3d_bwd_weight_x3_kernel(const float *_
   }
   __syncthreads();
   int cur = 0;
-  for (; brick < bricks; brick += gridDim.x) {
-    const int64_t next = brick + gridDim.x;
+  for (; brick < bricks; brick += (int)gridDim.x) {
+    const int next = brick + (int)gridDim.x;
     const bool more = next < bricks;
     if (more) load(next, 0);
     const uint32_t *ibuf = lds + cur * BUF, *dbuf = ibuf + 2 * IN_PLANE;
@@ -347,6 +352,10 @@ int bwd_weight_x3(const float *in, const float *dout, float *dWp, float *db, int
   SVR_CHECK(Ci >= 4 && Ci % 4 == 0 && Co % 4 == 0 && Co >= 4, SVR_E_UNSUPPORTED,
             "conv3d_bwd_weight_bf16x3: need Ci, Co %% 4 == 0 (Ci=%d Co=%d)", Ci, Co);
   SVR_CHECK((((uintptr_t)in | (uintptr_t)dout) & 15) == 0, SVR_E_ALIGN, "conv3d_bwd_weight_bf16x3: 16-byte alignment");
+  // the kernel's 24-bit row multiplies and 32-bit byte offsets inside one sample, 32-bit brick ids
+  SVR_CHECK((int64_t)D * H * W <= (1LL << 24) && (int64_t)D * H * W * (Ci > Co ? Ci : Co) < (1LL << 30) &&
+                (int64_t)B * cdiv(D, BRZ) * cdiv(H, BRY) * cdiv(W, BRX) < (1LL << 31),
+            SVR_E_UNSUPPORTED, "conv3d_bwd_weight_bf16x3: volume %dx%dx%dx%d too large for 32-bit offsets", B, D, H, W);
   hipStream_t s = (hipStream_t)stream;
   ConvShape sh{B, D, H, W, Ci, Co};
   const int cit = (int)cdiv(Ci, 32), cot = (int)cdiv(Co, 32);

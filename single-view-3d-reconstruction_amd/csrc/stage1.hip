@@ -182,7 +182,7 @@ __global__ __launch_bounds__(256) void stage1_kernel(const S1Args a) {
   // H3: taps 8 kq .. 8 kq + 7 of this lane (28 .. 31 do not exist: weight 0, operand read from tap 26), weight fragments
   int toffH[8];
   f16x8 wh, wl, wq;
-  float winv = 1.f;
+  float winv = 1.f, w_scale_up = 1.f;
   if constexpr (H3) {
     float *redf = reinterpret_cast<float *>(redd);
     float m = fabsf(a.Wp[t]);                                      // 27 x 16 = 432 weights
@@ -197,6 +197,7 @@ __global__ __launch_bounds__(256) void stage1_kernel(const S1Args a) {
     __syncthreads();   // (redd is used again at the end)
     const float wsc = w_scale(amax, false);
     winv = w_scale(amax, true);
+    w_scale_up = wsc;
     bv *= wsc;         // the bias rides in the accumulator, which carries the weights' scale
     uint32_t hp[4], lp[4];
 #pragma unroll
@@ -235,6 +236,15 @@ __global__ __launch_bounds__(256) void stage1_kernel(const S1Args a) {
     const double n = (double)a.B * D * H * W;
     m1 = (float)(a.sums[l15] / n);
     m2 = (float)(a.sums[CO + l15] / n);
+  }
+  // H3: the accumulator carries the weights' scale 2^s.  Instead of scaling every result back (4 VALU per tile), the
+  // constants that meet it are scaled once -- exact, powers of two: relu(acc 2^-s) sc + sh = relu(acc) (sc 2^-s) + sh,
+  // (relu(acc) 2^-s - mu) is = (relu(acc) - mu 2^s) (is 2^-s); the statistics are scaled where they are written.  `av` below is
+  // the activation times 2^s in the H3 passes.
+  if constexpr (H3) {
+    if (MODE == S1_APPLY) sc *= winv;   // (in the backward passes sc multiplies the gradient, not the activation)
+    is *= winv;
+    mu *= w_scale_up;
   }
   // dW operands (BWD_APPLY): A rows = taps 16 h + l15, k = voxel 4 kq + r
   int toffW[2];
@@ -379,7 +389,6 @@ __global__ __launch_bounds__(256) void stage1_kernel(const S1Args a) {
         acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(xl.v, wq, acc, 0, 0, 0);   // lo(x) hi(w)
         acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh.v, wl, acc, 0, 0, 0);   // hi(x) lo(w)
         acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh.v, wh, acc, 0, 0, 0);   // hi(x) hi(w)
-        acc = acc * winv;
       } else {
 #pragma unroll
         for (int m = 0; m < 7; ++m) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[m], bw[m], acc, 0, 0, 0);
@@ -394,11 +403,19 @@ __global__ __launch_bounds__(256) void stage1_kernel(const S1Args a) {
 #endif
 
       if (MODE == S1_STATS) {
+        if (gc.interior) {   // (uniform) every result counts: no masks
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float v = s1_and(av[r], s1_okmask(gc, tt, r));
-          f1 += v;
-          f2 = fmaf(v, v, f2);
+          for (int r = 0; r < 4; ++r) {
+            f1 += av[r];
+            f2 = fmaf(av[r], av[r], f2);
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float v = s1_and(av[r], s1_okmask(gc, tt, r));
+            f1 += v;
+            f2 = fmaf(v, v, f2);
+          }
         }
       } else if (MODE == S1_APPLY) {
         float yv[4];
@@ -504,6 +521,8 @@ __global__ __launch_bounds__(256) void stage1_kernel(const S1Args a) {
       const int ch = t % CO, which = t / CO;
       double s = 0.0;
       for (int k = 0; k < 16; ++k) s += redd[(k * 16 + ch) * 2 + which];   // the 16 lane groups (4 waves x 4 kq) of a channel
+      // STATS in the H3 arithmetic summed a 2^s and (a 2^s)^2: scaled back here, exactly (BWD_REDUCE sums gradients: no scale)
+      if (H3 && MODE == S1_STATS) s *= which ? (double)winv * (double)winv : (double)winv;
       a.part[(int64_t)blockIdx.x * 2 * CO + which * CO + ch] = s;
     }
   }

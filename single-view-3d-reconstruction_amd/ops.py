@@ -874,6 +874,10 @@ def conv3d_k3_bwd_weight(x, dout, want_bias=True, mode=None, param_layout=False)
     B, D, H, W, Ci = x.shape
     Co = dout.shape[4]
     l = _lib.lib()
+    # the split-precision kernel's 32-bit offsets inside one sample (conv3d_bwdw_bf16.hip); larger volumes take the f32 kernel
+    fits = D * H * W <= (1 << 24) and D * H * W * max(Ci, Co) < (1 << 30)
+    if not fits and (mode or BACKWARD_CONV_WEIGHT) == "bf16x3":
+        mode = "f32"
     if (mode or BACKWARD_CONV_WEIGHT) == "bf16x3" and Ci % 4 == 0 and Co % 4 == 0 and param_layout:
         ws = torch.empty(l.svr_conv3d_k3_bwd_weight_bf16x3_workspace(B, D, H, W, Ci, Co), device=x.device, dtype=torch.uint8)
         dw = torch.empty(Co, Ci, 3, 3, 3, device=x.device, dtype=torch.float32)
