@@ -445,7 +445,7 @@ __global__ __launch_bounds__(512, FTM == 64 ? 4 : 2) void gather_fc0_kernel(cons
       // (the lane index is made opaque per slab: with seven slab shapes the lane-derived constants of ALL of them were hoisted
       // in front of this loop and 12 of them spilled; recomputed per slab they cost a few dozen VALU instructions)
       int lane_s = lane;
-      asm volatile("" : "+v"(lane_s));
+      if constexpr (!BF) asm volatile("" : "+v"(lane_s));   // (the bf16 variant has no staged shapes and no spills)
       if (s + 1 < S && !(dbg & 1))
         produce<BF>(A, s + 1, lds + ((s + 1) & 1) * FSLAB, points, m0, M, N, disp, ac, feat, row_stride, pw, lane_s, dbg, lds + 2 * FSLAB,
                     boxes + (int64_t)blockIdx.x * FC_NSTAGE);
