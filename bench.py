@@ -46,6 +46,13 @@ MFMA_F16_PEAK_TFLOPS = 2500.0                # dense f16 / bf16 MFMA peak (spec)
 MLP_FLOP_PER_POINT = 1585152                 # forward FLOP per query point of fc_0..fc_out (f32-equivalent)
 DIAG_STEPS = 2                               # untimed single-stream steps behind the timed region (per-kernel times)
 SETUP_STEPS = 2                              # untimed steps before the W warm-up steps (allocator pools, scatter-form decision)
+# the same step under other backward arithmetic, measured behind the timed region: key -> (ops.BACKWARD_* mode, note)
+ALT_BACKWARD = {
+    "backward_exact_f32": ("f32", "the same step with every backward GEMM / convolution on the exact-f32 MFMA kernels "
+                                  "(ops.BACKWARD_* = 'f32') instead of the bf16x3 split"),
+    "backward_f32_level": ("bf16x6", "the same step with every backward GEMM / convolution as the 6-product bf16 split "
+                                     "(three bf16 terms per operand, f32-level accuracy at any range; ops.BACKWARD_* = 'bf16x6')"),
+}
 SPLIT_PRODUCTS = 3                           # f16x3 / bf16x3: three MFMA products per f32-equivalent product
 
 
@@ -108,6 +115,7 @@ def cpu_baseline(D, N, reps=3):
             "value_median": N / statistics.median(tot),
             "fwd_only": {"value": N / min(fwd), "value_median": N / statistics.median(fwd), "unit": "query-points/s"},
             "cpu_model": _cpu_model(),
+            "sample_short": f"1 sample (B=1, {D}^3, {N} pts), 1 warm-up + {reps} reps, best; torch CPU ops, {threads} threads",
             "sample": f"1 sample of the workload (B=1, {D}^3 grid, {N} points; x B = one GPU batch), 1 warm-up + {reps} timed "
                       f"repetitions: fwd+bwd {', '.join(f'{t:.2f}' for t in tot)} s, fwd {', '.join(f'{t:.2f}' for t in fwd)} s; "
                       f"value = best, value_median = median; torch {torch.__version__} CPU ops with {threads} threads "
@@ -210,7 +218,11 @@ def main():
     ap.add_argument("--no-fwd-only", action="store_true")
     ap.add_argument("--no-query", action="store_true", help="skip the query-path (f32 / bf16 storage / lattice) measurement")
     ap.add_argument("--no-diag", action="store_true", help="skip the untimed single-stream steps behind the timed region")
-    ap.add_argument("--no-f32-backward", action="store_true", help="skip the extra steps with the exact-f32 backward kernels")
+    ap.add_argument("--no-f32-backward", action="store_true",
+                    help="skip the extra steps with the exact-f32 / f32-level (bf16x6) backward kernels")
+    ap.add_argument("--detail", default=os.path.join(ROOT, "bench_detail.json"),
+                    help="where the full record goes (per-kernel roofline table, per-step lists, per-rank dicts, query path); "
+                         "stdout carries only the compact line")
     ap.add_argument("--alloc-trace", action="store_true",
                     help="record the caching allocator's history over the timed region and report the call sites of every hipMalloc")
     ap.add_argument("--backward", choices=["production", "f32"], default="production",
@@ -247,6 +259,8 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if dist.get_world_size() != a.gpus:
+            sys.exit(f"bench.py: process group has {dist.get_world_size()} ranks, --gpus {a.gpus}")
     dev = torch.device("cuda", local_rank)
 
     trainer = ImplicitRefinementTrainer()
@@ -343,21 +357,24 @@ def main():
                 setattr(mod, name, orig)
     # what the step costs WITHOUT the bf16x3 split in the backward: a few extra steps behind the timed
     # region with the backward GEMMs / convolutions on the exact-f32 MFMA kernels (rank 0's clock; never the headline)
-    f32_bwd_ms = None
+    alt_ms = {}
     if not a.no_diag and not a.no_f32_backward and a.backward == "production":
         prev = (ops.BACKWARD_GEMM, ops.BACKWARD_CONV, ops.BACKWARD_CONV_WEIGHT)
-        ops.BACKWARD_GEMM = ops.BACKWARD_CONV = ops.BACKWARD_CONV_WEIGHT = "f32"
-        try:
-            for _ in range(2):
-                dp.step(batch)
-            sync()
-            t1 = time.perf_counter()
-            for _ in range(5):
-                dp.step(batch)
-            sync()
-            f32_bwd_ms = (time.perf_counter() - t1) / 5 * 1e3
-        finally:
-            ops.BACKWARD_GEMM, ops.BACKWARD_CONV, ops.BACKWARD_CONV_WEIGHT = prev
+        for key, (mode, _) in ALT_BACKWARD.items():
+            if mode not in getattr(ops, "BACKWARD_MODES", ("bf16x3", "f32")) or mode in prev:
+                continue
+            ops.BACKWARD_GEMM = ops.BACKWARD_CONV = ops.BACKWARD_CONV_WEIGHT = mode
+            try:
+                for _ in range(2):
+                    dp.step(batch)
+                sync()
+                t1 = time.perf_counter()
+                for _ in range(5):
+                    dp.step(batch)
+                sync()
+                alt_ms[key] = (time.perf_counter() - t1) / 5 * 1e3
+            finally:
+                ops.BACKWARD_GEMM, ops.BACKWARD_CONV, ops.BACKWARD_CONV_WEIGHT = prev
     loss = float(loss_t)
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
     if launched:
@@ -466,17 +483,85 @@ def main():
 
     if rank == 0:
         res = report(a, world, dt, loss, step_ms, host_ms, kt, kd, ranks, forms, fwd_ms, query, arena, grown0)
-        if f32_bwd_ms is not None:
-            res["backward_exact_f32"] = {"ms_per_step": f32_bwd_ms, "value": world * a.batch * a.points / (f32_bwd_ms * 1e-3),
-                                         "unit": "query-points/s",
-                                         "note": "the same step with every backward GEMM / convolution on the exact-f32 MFMA kernels "
-                                                 "(ops.BACKWARD_* = 'f32') instead of the bf16x3 split: 5 steps behind the timed region"}
+        res["rccl"] = {"world_size": world, "launched_by_torchrun": launched, "backend": "nccl (RCCL)" if launched else None,
+                       "device_count": torch.cuda.device_count(),
+                       "devices": {str(r["rank"]): r["device"] for r in ranks}}
+        for key, ms in alt_ms.items():
+            res[key] = {"ms_per_step": ms, "value": world * a.batch * a.points / (ms * 1e-3), "unit": "query-points/s",
+                        "note": ALT_BACKWARD[key][1] + ": 5 steps behind the timed region"}
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(a.grid, a.points)
-        print(json.dumps(res), flush=True)
+        emit(res, a.detail)
     if launched:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def _sig(v, n=5):
+    """Floats of the compact line: n significant digits."""
+    if isinstance(v, float):
+        return float(f"{v:.{n}g}")
+    return v
+
+
+def compact(res):
+    """The ONE line the driver parses (the 21 KB line of round 3 left BENCH_r03.parsed null): the contract's
+    keys + a short roofline / cpu_baseline / backward-arithmetic / allocator / RCCL summary, <= 3 KB at any world size.
+    Everything else (per-kernel table, per-step lists, per-rank dicts, query path) is bench_detail.json."""
+    r, st, cfg = res["roofline"], res.get("step_ms") or {}, res["config"]
+    out = {k: res[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                               "scaling", "vs_baseline", "dtype", "data")}
+    out["step_ms"] = {k: st.get(k) for k in ("min", "median", "max")}
+    out["config"] = {"workload": cfg["workload_short"], "global_batch": cfg["global_batch"], "parallelism": cfg["parallelism"],
+                     "points": cfg["points"], "arithmetic": cfg["arithmetic_short"]}
+    out["roofline"] = {"kernel": r["kernel_short"], "bound": r["bound"], "unit": r["unit"], "peak": r["peak"],
+                       "achieved": r["achieved"], "frac": r["frac"], "traffic": r["traffic"],
+                       "traffic_source": "stored PMC (profiles/gather_traffic.json; FETCH x2 uncalibrated for gathers: upper bound)"
+                                         if r["traffic"] else None,
+                       "compulsory_bytes": r["compulsory_bytes_per_launch"], "algorithmic_bytes": r["algorithmic_bytes_per_launch"],
+                       "ms_per_launch": r["ms_per_launch"], "mfma_frac": r.get("mfma_frac_of_f16_peak")}
+    c = res.get("cpu_baseline")
+    if c:
+        out["cpu_baseline"] = {"value": c["value"], "value_median": c["value_median"], "unit": c["unit"], "cores": c["cores"],
+                               "kind": c["kind"], "cpu_model": c["cpu_model"], "fwd_only_value": c["fwd_only"]["value"],
+                               "sample": c["sample_short"]}
+    for key in ALT_BACKWARD:
+        if key in res:
+            out[key] = {"ms_per_step": res[key]["ms_per_step"]}
+    if res.get("fwd_only"):
+        out["fwd_only_ms"] = res["fwd_only"]["ms_per_step"]
+    out["hipMalloc_calls_in_timed_region"] = res["allocator"]["hipMalloc_calls_in_timed_region"]
+    rc = res.get("rccl") or {}
+    out["rccl"] = {"world_size": rc.get("world_size"), "torchrun": rc.get("launched_by_torchrun"),
+                   "device_count": rc.get("device_count")}
+    if res["n_gpus"] > 1:
+        out["rccl"]["rank_ms_per_step"] = [_sig(x["wall_ms_per_step"], 4) for x in res.get("ranks", [])]
+    ar = res.get("all_reduce_ms")
+    if ar:
+        out["rccl"]["all_reduce_ms_median"] = ar["median"]
+    out["detail"] = "bench_detail.json"
+
+    def rnd(o):
+        if isinstance(o, dict):
+            return {k: rnd(v) for k, v in o.items()}
+        if isinstance(o, list):
+            return [rnd(v) for v in o]
+        return _sig(o)
+    return rnd(out)
+
+
+def emit(res, detail_path):
+    """bench_detail.json (+ the same object on stderr) first, then the compact line as the LAST and ONLY JSON line on stdout."""
+    line = json.dumps(compact(res), separators=(",", ":"))
+    assert len(line) < 3072, f"compact bench line grew to {len(line)} bytes"
+    full = json.dumps(res)
+    try:
+        with open(detail_path, "w") as f:
+            f.write(full + "\n")
+    except OSError as e:
+        print(f"bench.py: cannot write {detail_path}: {e}", file=sys.stderr)
+    print("bench_detail " + full, file=sys.stderr, flush=True)
+    print(line, flush=True)
 
 
 def _ifn_mod():
@@ -487,8 +572,22 @@ def _ifn_mod():
 def _backward_arithmetic():
     from svr_amd import ops
     modes = {ops.BACKWARD_GEMM, ops.BACKWARD_CONV, ops.BACKWARD_CONV_WEIGHT}
-    names = {"bf16x3": "bf16x3 split (~1.5e-5 per product)", "f16x3s": "scaled 3-product f16 split (f32-level)", "f32": "exact f32 MFMA"}
+    names = {"bf16x3": "bf16x3 split (~1.5e-5 per product)", "bf16x6": "bf16x6 split (f32-level)",
+             "f16x3s": "scaled 3-product f16 split (f32-level)", "f32": "exact f32 MFMA"}
     return " / ".join(names.get(m, m) for m in sorted(modes))
+
+
+def _arithmetic():
+    """The step's arithmetic, read from the switches the kernels are selected by (ops.FORWARD_* / BACKWARD_* /
+    stage1_arith): (long form for bench_detail.json, short form for the compact line)."""
+    from svr_amd import ops
+    s1 = "f16x3 (recomputed, |x| < 65504)" if ops.stage1_arith() else "exact f32 (recomputed)"
+    long = (f"f32 storage everywhere; forward GEMMs: {ops.FORWARD_GEMM}, forward convs: {ops.FORWARD_CONV} (3-product f16 split "
+            f"on the f16 MFMA: f32-level, ~3e-7 of f64); conv_in (stage 1): {s1}; backward dX/dW GEMMs, conv backward-data and "
+            f"conv weight gradients: {_backward_arithmetic()}; BN, gather/scatter, loss: exact f32")
+    short = (f"f32 storage; fwd gemm {ops.FORWARD_GEMM}, fwd conv {ops.FORWARD_CONV}, conv_in {'f16x3' if ops.stage1_arith() else 'f32'}; "
+             f"bwd gemm {ops.BACKWARD_GEMM}, bwd conv {ops.BACKWARD_CONV}, wgrad {ops.BACKWARD_CONV_WEIGHT}; BN/gather/scatter f32")
+    return long, short
 
 
 def _traffic(a):
@@ -532,6 +631,7 @@ def report(a, world, dt, loss, step_ms, host_ms, kt, kd, ranks, forms, fwd_ms, q
     proj_hbm, proj_atomic, tsrc = t.get("proj_hbm_bytes_per_launch"), t.get("proj_atomic_bytes_per_launch"), t.get("source")
     hbm_rate = traffic / (gather_ms * 1e-3) / 1e9 if (traffic and gather_ms > 0) else None
     roofline = {
+        "kernel_short": "gather_fc0_kernel (fused 6-level trilinear gather -> fc_0)" if fused else "gather_fwd_fused_kernel (6 levels)",
         "kernel": ("gather_fc0_kernel (svr_gather_fc0_run: all 6 levels gathered slab by slab into LDS and multiplied into "
                    "fc_0's 64 x 256 tile, one launch; the W split / slab table launches of svr_gather_fc0_prepare are outside "
                    "the bracket)") if fused else
@@ -568,11 +668,11 @@ def report(a, world, dt, loss, step_ms, host_ms, kt, kd, ranks, forms, fwd_ms, q
         "config": {"workload": f"BASELINE configs[2] per GPU: {a.grid}^3 grid, {a.points} query points, batch "
                                f"{a.batch}/GPU, full 3D conv encoder + 6-level trilinear gather + occupancy MLP, "
                                "fwd+bwd+grad all-reduce+Adam",
+                   "workload_short": f"configs[2] per GPU: {a.grid}^3 grid, {a.points} pts, batch {a.batch}/GPU, encoder + gather + MLP, "
+                                     "fwd+bwd+allreduce+Adam",
                    "global_batch": world * a.batch, "parallelism": f"dp{world}", "loss": loss, "points": a.dist,
                    "deterministic_scatter": bool(_ifn_mod().DETERMINISTIC),
-                   "arithmetic": "f32 storage everywhere; forward GEMMs/convs: 3-product f16 split on the f16 MFMA "
-                                 "(f32-level, ~3e-7 of f64); backward dX/dW GEMMs, conv backward-data and conv weight "
-                                 f"gradients: {_backward_arithmetic()}; conv_in, BN, gather/scatter: exact f32"},
+                   "arithmetic": _arithmetic()[0], "arithmetic_short": _arithmetic()[1]},
         # every timed step on its own (HIP events at the step boundaries on the main stream; no host synchronisation inside
         # the region): a transient shows as max >> median, uniform contention as a shifted median
         "step_ms": st, "step_ms_list": [round(v, 3) for v in step_ms],
@@ -591,9 +691,7 @@ def report(a, world, dt, loss, step_ms, host_ms, kt, kd, ranks, forms, fwd_ms, q
         "all_reduce_ms": ranks[0]["all_reduce_ms"],
         "roofline": roofline,
     }
-    if world > 1:
-        res["ranks"] = ranks
-        res["rccl"] = {"world_size": world, "backend": "nccl (RCCL)", "devices": {str(r["rank"]): r["device"] for r in ranks}}
+    res["ranks"] = ranks
     if fwd_ms is not None:
         res["fwd_only"] = {"value": npts / (fwd_ms * 1e-3), "unit": "query-points/s", "ms_per_step": fwd_ms,
                            "note": "rank 0, forward + loss under no_grad, training-mode BatchNorm"}

@@ -68,6 +68,26 @@ class StepArena:
     def nbytes(self):
         return sum(t.numel() * t.element_size() for t in self._bufs.values())
 
+    def owns(self, t):
+        """Does tensor `t` live in one of the arena's buffers?  (Arena memory never returns to an allocator pool, so a
+        tensor it owns needs no record_stream bookkeeping when another stream reads it; any other tensor does.)"""
+        p = t.data_ptr()
+        for b in self._bufs.values():
+            q = b.data_ptr()
+            if q <= p < q + b.numel() * b.element_size():
+                return True
+        return False
+
+    def release(self):
+        """Free every buffer (after draining the device: queued work on any stream may still read them).  The next
+        training step allocates them again.  Refused while a forward pass holds the lease."""
+        if self._leased:
+            raise RuntimeError("StepArena.release: a forward pass whose backward is pending still holds the arena")
+        if self._bufs:
+            for dev in {t.device for t in self._bufs.values() if t.is_cuda}:
+                torch.cuda.synchronize(dev)
+            self._bufs.clear()
+
 
 def alloc(arena, name, shape, dtype, device):
     """torch.empty from the arena when there is one, from the caching allocator otherwise."""

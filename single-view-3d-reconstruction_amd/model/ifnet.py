@@ -119,8 +119,11 @@ def _level_orders_async(pts, D, H, W, n_levels, align, layout=None, disp=None, p
     main = torch.cuda.current_stream()
     side = _get_side_stream(pts.device)
     side.wait_stream(main)          # pts may have just been produced on the main stream
-    if arena is None:
-        pts.record_stream(side)     # ... and must not return to the main stream's pool while the side stream reads it
+    if arena is None or not arena.owns(pts):
+        # ... and must not return to the main stream's pool while the side stream reads it.  (Skipped only for points that
+        # LIVE in the arena -- the Morton-sorted copy; with spatial_sort off or N == 1 pts is the caller's tensor even
+        # under a lease, and a graph dropped without a backward would hand its block out again on main.)
+        pts.record_stream(side)
     launched = False
     form = "pull" if DETERMINISTIC else SCATTER_FORM
     fits32 = layout is not None and N > 0 and 7 * B * N < 2 ** 31 and B * N * layout.row_stride < 2 ** 31
@@ -675,6 +678,39 @@ class _PermuteColumnsFn(torch.autograd.Function):
 class _ExtractorBase(nn.Module):
     """Shared host logic of the two extractor variants."""
 
+    # Per-process scratch state that is neither parameter nor buffer: the step arena (multi-GB device buffers, allocated by
+    # the first training steps and kept for the module's lifetime -- release_step_buffers() frees them) and the prepared
+    # weight planes (hold a torch.cuda.Event, which can be neither pickled nor deep-copied).  copy.deepcopy(model),
+    # pickle / torch.save(model) get fresh, empty ones, like the reference nn.Module that has neither.
+    _SCRATCH = ("_arena", "_prepared", "_points_ready")
+
+    def __getstate__(self):
+        st = dict(self.__dict__)
+        for k in self._SCRATCH:
+            st.pop(k, None)
+        return st
+
+    def __setstate__(self, st):
+        self.__dict__.update(st)
+        self._arena = StepArena()
+        self._prepared = ops.PreparedWeights()
+        self._points_ready = None
+
+    def __deepcopy__(self, memo):
+        import copy
+        new = self.__class__.__new__(self.__class__)
+        memo[id(self)] = new
+        new.__setstate__(copy.deepcopy(self.__getstate__(), memo))
+        # (_stages / _param_list hold references to submodules / parameters: copied through the same memo, so they point at
+        # the copy's own conv / bn modules)
+        return new
+
+    def release_step_buffers(self):
+        """Hand the step arena's device memory (4.4 GB at configs[2]) and the prepared weight planes back: call between
+        training and a memory-hungry inference phase.  The next training step allocates them again (a few hipMalloc)."""
+        self._arena.release()
+        self._prepared = ops.PreparedWeights()
+
     def _finish_init(self, net_res):
         a = _ARCH[net_res]
         self._stages = [([getattr(self, c) for c in convs], getattr(self, bn)) for convs, bn in a["stages"]]
@@ -869,6 +905,8 @@ class IFNet(nn.Module):
                                                                                 self.fc_0.out_channels):
             prepared = ops.gather_fc0_bf16_prepare(levels, ext._layout, ext._disp, ext._align, self._fc0_internal())
         if prepared is not None:      # fused gather -> fc_0 on bf16 storage: the bf16 feature rows never reach HBM
+            if any(a.data_ptr() != b.data_ptr() or a.shape != b.shape for a, b in zip(prepared["vols"], levels)):
+                raise RuntimeError("IFNet.query: `prepared` was made for another pyramid than `levels` (prepare_query again)")
             h = ops.gather_fc0_bf16_run(prepared, points, self.fc_0.bias, relu=True)
         else:
             rows = ops.gather_fwd_bf16(levels, points, ext._layout, ext._disp, ext._align)
@@ -909,6 +947,10 @@ class IFNet(nn.Module):
             return self._query_bf16(levels, points, row_map, prepared)
         ext = self.ifnet_feature_extractor
         if prepared is not None:
+            # the prepared descriptor holds ITS pyramid (slab table, volume pointers): a different `levels` would be ignored
+            if len(prepared.vols) != len(levels) or any(a.data_ptr() != b.data_ptr() or a.shape != b.shape
+                                                        for a, b in zip(prepared.vols, levels)):
+                raise RuntimeError("IFNet.query: `prepared` was made for another pyramid than `levels` (prepare_query again)")
             h, _ = ops.gather_fc0_run(prepared, points, self.fc_0.bias)
         elif FUSE_FC0 and ops.gather_fc0_supported(levels, points, ext._layout, ext._disp, ext._align, self.fc_0.out_channels):
             h, _ = ops.gather_fc0_fwd(levels, points, ext._layout, ext._disp, ext._align, self._fc0_internal(), self.fc_0.bias)

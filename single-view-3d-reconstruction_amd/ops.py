@@ -320,8 +320,11 @@ class Fc0Prepared:
     """fc_0's weights split into the fused kernel's f16 planes + the slab table of one pyramid (svr_gather_fc0_prepare):
     reusable for any number of gather_fc0_run calls on the same volumes / layout / weights."""
 
-    def __init__(self, vols, layout, displacement, align_corners, n_out, ws, keep_levels, keep_layout):
+    def __init__(self, vols, layout, displacement, align_corners, n_out, ws, keep_levels, keep_layout, B=None, N=None):
         self.vols, self.layout, self.displacement, self.align_corners = list(vols), layout, displacement, align_corners
+        # the point set the workspace was sized for (one FcBox record per 64-point tile and staged level): a larger query
+        # would write past it on the device, so gather_fc0_run refuses it
+        self.B, self.N = B, N
         self.n_out, self.ws, self.keep_levels, self.keep_layout = n_out, ws, tuple(keep_levels), keep_layout
         self.mask = 0
         for lv in self.keep_levels:
@@ -347,7 +350,7 @@ def gather_fc0_prepare(vols, layout, displacement, align_corners, w, B, N, keep_
     if ws_bytes <= 0:
         raise RuntimeError("gather_fc0: unsupported level shapes (see svr_gather_fc0_supported)")
     ws = _alloc(arena, "fc0_ws", (ws_bytes,), torch.uint8, w.device)
-    prep = Fc0Prepared(vols, layout, displacement, align_corners, n_out, ws, keep_levels, keep_layout)
+    prep = Fc0Prepared(vols, layout, displacement, align_corners, n_out, ws, keep_levels, keep_layout, B, N)
     # (the kept matrix itself is only needed by run; prepare validates its geometry against a dummy aligned address)
     check(l.svr_gather_fc0_prepare(C.byref(d), C.c_void_p(w.data_ptr()), w.stride(0), n_out, C.c_void_p(256) if prep.mask else None,
                                    prep.stride if prep.mask else 0, prep.kc, prep.mask, _p(ws), _stream()), "gather_fc0_prepare")
@@ -358,6 +361,9 @@ def gather_fc0_run(prep, points, bias, relu=True, rows_out=None):
     """The fused gather -> fc_0 kernel alone, on a prepared pyramid: -> (h0 (B*N, n_out), kept rows or None)."""
     B, N, _ = points.shape
     _f32(points, bias)
+    if prep.B is not None and (B != prep.B or N > prep.N):
+        raise RuntimeError(f"gather_fc0: points ({B}, {N}, 3) exceed the prepared capacity (B = {prep.B}, N <= {prep.N}): "
+                           "prepare again for the larger point set")
     d = make_gather_desc(prep.vols, None, prep.layout, B, N, prep.displacement, prep.align_corners)
     out = torch.empty(B * N, prep.n_out, device=points.device, dtype=torch.float32)
     rows, ldf = None, 0

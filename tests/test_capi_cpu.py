@@ -139,3 +139,33 @@ def test_hand_written_kernels_do_not_spill():
     assert not bad, bad
     fc0 = [v for k, v in own.items() if "gather_fc0_kernel" in k][0]
     assert fc0["scratch"] == 0 and fc0["vgprs"] <= 128 and fc0["occupancy"] >= 4, fc0
+
+
+def test_module_copies_and_pickles_after_a_step_left_scratch_state():
+    """a training step leaves a torch.cuda.Event in ext._prepared.ready and GBs in ext._arena; the reference
+    nn.Module can be deep-copied / pickled, so this one must be too -- the copy gets fresh, empty scratch state."""
+    import copy
+    import io
+    import pickle
+
+    import torch
+    from svr_amd.arena import StepArena
+    from svr_amd.model import IFNet
+    m = IFNet(net_res=128)
+    ext = m.ifnet_feature_extractor
+    ext._prepared.ready = torch.cuda.Event()          # what _prepare_weights_async leaves behind
+    ext._points_ready = torch.cuda.Event()
+    ext._arena._bufs["x"] = torch.zeros(4)
+    for clone in (copy.deepcopy(m), pickle.loads(pickle.dumps(m))):
+        e2 = clone.ifnet_feature_extractor
+        assert isinstance(e2._arena, StepArena) and e2._arena is not ext._arena and e2._arena.nbytes() == 0
+        assert e2._prepared is not ext._prepared and e2._prepared.ready is None
+        # _stages / _param_list of the copy point at the copy's own modules
+        assert e2._stages[0][0][0] is e2.conv_in and e2._param_list[0] is e2.conv_in.weight
+        assert e2._param_list[0] is not ext._param_list[0]
+        for (k, a), (k2, b) in zip(m.state_dict().items(), clone.state_dict().items()):
+            assert k == k2 and torch.equal(a, b)
+    buf = io.BytesIO()
+    torch.save(m, buf)
+    ext.release_step_buffers()
+    assert ext._arena.nbytes() == 0

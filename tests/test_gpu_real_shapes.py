@@ -207,3 +207,27 @@ def test_dense_lattice_inference_at_139x104x112():
     # the same through the unprepared per-chunk path and with another chunk size: identical values
     again = evaluate_network_on_grid(m, x.cuda(), DIMS, 1, points_batch_size=50000)
     assert np.array_equal(again, got)
+
+
+def test_prepared_query_refuses_what_it_was_not_prepared_for():
+    """the fused kernel's workspace holds one box record per 64-point tile of the PREPARED point set; a
+    larger chunk would write past it on the device.  gather_fc0_run / IFNet.query raise instead -- and a `prepared` handle
+    of another pyramid is refused rather than silently used."""
+    m, st = _model(train=False)
+    g = torch.Generator().manual_seed(37)
+    x = (torch.rand(1, 1, 32, 32, 32, generator=g) < 0.05).float().cuda()
+    levels = m.encode(x)
+    prep = m.prepare_query(levels, 1000)
+    assert prep is not None and (prep.B, prep.N) == (1, 1000)
+    pts = (torch.rand(1, 1000, 3, generator=g) - 0.5).cuda()
+    z = m.query(levels, pts, prepared=prep)
+    assert torch.equal(z[:, :300], m.query(levels, pts[:, :300].contiguous(), prepared=prep))     # smaller chunks are fine
+    assert torch.equal(z, m.query(levels, pts))                                                   # = the unprepared path
+    with pytest.raises(RuntimeError, match="prepared capacity"):
+        m.query(levels, (torch.rand(1, 1001, 3, generator=g) - 0.5).cuda(), prepared=prep)
+    with pytest.raises(RuntimeError, match="prepared capacity"):
+        m.query(levels, torch.cat([pts, pts]), prepared=prep)                                     # another batch size
+    other = m.encode((torch.rand(1, 1, 32, 32, 32, generator=g) < 0.05).float().cuda())
+    with pytest.raises(RuntimeError, match="another pyramid"):
+        m.query(other, pts, prepared=prep)
+    torch.cuda.synchronize()
