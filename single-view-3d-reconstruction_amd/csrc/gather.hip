@@ -1109,7 +1109,8 @@ extern "C" int svr_gather_trilinear_fwd(const svr_gather_desc *d, const float *p
   // Off by default: measured at config 3 it helps UNSORTED points (3.04 -> 2.57 ms) but costs Morton-sorted ones, the
   // production order (2.00 -> 2.20 ms: with round-robin placement the lines a neighbour XCD just fetched are Infinity
   // Cache hits, and eight XCDs streaming eight different samples open more DRAM pages).  SVR_GATHER_XCD=1 enables it.
-  A.xcd = getenv("SVR_GATHER_XCD") ? 1 : 0;
+  static const int xcd_order = getenv("SVR_GATHER_XCD") ? 1 : 0;   // read once per process, not per launch
+  A.xcd = xcd_order;
   A.pad_start = 0;
   for (int l = 0; l < d->n_levels; ++l) {
     int end = d->level[l].col + 7 * d->level[l].C;

@@ -82,6 +82,9 @@ struct FcBox { int nvox, b, z0, y0, x0, by, bx, pad; };   // per (tile, staged l
 #ifndef FC_DEPTH
 #define FC_DEPTH 1
 #endif
+#ifndef FC_FMA
+#define FC_FMA 0   // corner sum: 0 = ATen's rounding (bit-identical to F.grid_sample), 1 = one v_pk_fma_f32 per step
+#endif
 constexpr int FC_LDS_BYTES = 2 * FSLAB * 4 + FC_STAGE_DW * 4;   // two slab buffers + the staging region
 
 struct FcLevel {
@@ -94,8 +97,9 @@ struct FcSlab {  // 32-bit fields: scalar loads.  (Sub-dword fields were fetched
   int level, j0, nj, lp;  // lp: lanes per point (columns / 4); 0 marks the C == 1 slab (7 columns + 9 zeros)
   int k0, nk;             // first k-step and number of k-steps
   int c0, keep;           // first channel; keep: also store the values to the feature matrix
-  int stage, pad;         // -1, or the staged-level index of a level whose corners come from the LDS staging region;
-                          // lp == -1 marks the STAGE slab itself (nk == 0)
+  int stage, geo;         // stage: -1, or the staged-level index of a level whose corners come from the LDS staging region;
+                          // lp == -1 marks the STAGE slab itself (nk == 0).  geo: first displacement slab of its level --
+                          // the producers evaluate the level's sample geometry there (level_geometry) and keep it
 };
 struct FcArgs {
   FcLevel L[SVR_MAX_LEVELS];
@@ -158,65 +162,93 @@ __device__ __forceinline__ f16x8 lds_frag(const uint32_t *plane, int row, int lh
   return f.v;
 }
 
-// One slab of a level with C >= 16: LP lanes per point (LP * 4 columns), NJ displacements side by side.
-// Producer wave pw owns rows [32 pw, 32 pw + 32) of the tile.  The producers are bound by the instructions they issue
-// (one wave per SIMD, 4 cycles per wave64 VALU instruction), so the per-pass code is pared down to the loads, the
-// packed multiply / add chain, the f16 split and two LDS stores:
-//   phase 1 (once per slab): lane l evaluates item (row 32 pw + l / NJ, displacement j0 + l % NJ) completely -- the eight
-//     corner weights (wx*wy)*wz with 0 for corners outside the volume, and the byte offsets of the CLAMPED corner
-//     coordinates (four (z,y) row offsets + two x offsets), so phase 2 needs neither bounds tests nor address selects;
-//   phase 2: LP / 2 passes of 64 / LP rows; the owning lane's 14 values arrive by ds_bpermute, 8 float4 loads
-//     (uniform base + 32-bit offset), sum_k v_k * w_k in ATen's corner order.  A corner outside the volume contributes
-//     v * 0 with v read from a clamped, i.e. existing, voxel: the sum is bit-identical to skipping it (ATen,
-//     gather.hip) for finite volumes.
+// Levels with C >= 16.  The producers are bound by the instructions they issue (one wave per SIMD, 4 cycles per wave64
+// VALU instruction), so the code is split by how often each part has to run:
+//   level_geometry (ONCE per tile and level; round 4 -- rounds 2-3 redid it in every one of the level's 4-14 slabs, ~250
+//     instructions per slab and wave against ~100 per pass: 38-55 % of a slab's issue slots): producer wave pw owns rows
+//     [RPW pw, RPW pw + RPW) of the tile; its 7 RPW (row, displacement) items are evaluated completely, one per lane and
+//     round, in displacement-major order (item = j RPW + row; set = item / 64, lane = item % 64) and stay in registers
+//     for all slabs of the level: the eight corner weights (wx*wy)*wz with 0 for corners outside the volume, and the byte
+//     offsets of the CLAMPED corner coordinates (four (z,y) row offsets + two x offsets, without the slab's first
+//     channel), so a pass needs neither bounds tests nor address selects;
+//   produce_slab (per slab): LP lanes per point (LP * 4 columns), NJ displacements side by side; LP / 2 passes of
+//     64 / LP rows; the owning lane's 14 values arrive by ds_bpermute, 8 float4 loads (uniform base + 32-bit offset),
+//     sum_k v_k * w_k in ATen's corner order.  A corner outside the volume contributes v * 0 with v read from a clamped,
+//     i.e. existing, voxel: the sum is bit-identical to skipping it (ATen, gather.hip) for finite volumes.
+// Corner sum: FC_FMA = 0 rounds product and sum separately, in ATen's order -- the gathered values are bit-identical to
+// F.grid_sample / gather.hip (v_pk_mul_f32 + v_pk_add_f32: 34 instructions per pass); FC_FMA = 1 contracts each step into
+// one v_pk_fma_f32 (16 per pass; one rounding per step instead of two: <= 1 ulp of the f32 sum closer to the exact value).
+// Index arithmetic, weights and floor() are not contracted in either mode: corner indices stay bit-exact.
 #define LDS_AS __attribute__((address_space(3)))
+constexpr int GEO_N = 14;                     // per item: ezy[4], ex[2], wk[8]
+constexpr int GEO_IPS = 64 / RPW;             // displacements per register set (64 items)
+constexpr int GEO_SETS = (7 + GEO_IPS - 1) / GEO_IPS;
+struct Geo { int v[GEO_SETS][GEO_N]; };
+
+template <bool BF, bool STAGED>
+__device__ __forceinline__ void level_geometry(const FcLevel L, const float *__restrict__ points, int64_t m0, int64_t M, int N,
+                                               float disp, int ac, int pw, int lane, const FcBox box, Geo &G) {
+  constexpr uint32_t EB = BF ? 2u : 4u;   // bytes per stored channel value
+  const int C = L.C;
+#pragma unroll
+  for (int r = 0; r < GEO_SETS; ++r) {
+    const int item = r * 64 + lane, j = min(item / RPW, 6);
+    const int64_t pn = min(m0 + RPW * pw + item % RPW, M - 1);
+    const int b = (int)(pn / N);
+    const Corner c = sample_corner(points + pn * 3, j, disp, L.D, L.H, L.W, ac);
+    const Weights w = corner_weights(c);
+    int xc[2], yc[2], zc[2];
+    bool vx[2], vy[2], vz[2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      vx[a] = w.x0 + a >= 0 && w.x0 + a < L.W;
+      vy[a] = w.y0 + a >= 0 && w.y0 + a < L.H;
+      vz[a] = w.z0 + a >= 0 && w.z0 + a < L.D;
+      xc[a] = min(max(w.x0 + a, 0), L.W - 1);
+      yc[a] = min(max(w.y0 + a, 0), L.H - 1);
+      zc[a] = min(max(w.z0 + a, 0), L.D - 1);
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const float wt = (w.wx[k & 1] * w.wy[(k >> 1) & 1]) * w.wz[k >> 2];
+      G.v[r][6 + k] = __float_as_int((vx[k & 1] && vy[(k >> 1) & 1] && vz[k >> 2]) ? wt : 0.f);
+    }
+    if constexpr (STAGED) {   // byte offsets inside the staged box: [z][y][x][64 channels of this half]
+      (void)b;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) G.v[r][i] = (((zc[i >> 1] - box.z0) * box.by + (yc[i & 1] - box.y0)) * box.bx) * 256;
+#pragma unroll
+      for (int a = 0; a < 2; ++a) G.v[r][4 + a] = (xc[a] - box.x0) * 256;
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) G.v[r][i] = (int)((uint32_t)(((b * L.D + zc[i >> 1]) * L.H + yc[i & 1]) * L.W * C) * EB);  // host: < 2^30 elements
+#pragma unroll
+      for (int a = 0; a < 2; ++a) G.v[r][4 + a] = xc[a] * C * (int)EB;
+    }
+  }
+}
+
 template <int LP, int NJ, bool BF, bool STAGED = false>
-__device__ __forceinline__ void produce_slab(const FcLevel L, const FcSlab S, uint32_t *__restrict__ buf,
-                                             const float *__restrict__ points, int64_t m0, int64_t M, int N, float disp,
-                                             int ac, float *__restrict__ feat, int row_stride, int pw, int lane,
-                                             const uint32_t *stage = nullptr, const FcBox box = FcBox{}) {
+__device__ __forceinline__ void produce_slab(const FcLevel L, const FcSlab S, uint32_t *__restrict__ buf, int64_t m0, int64_t M,
+                                             float *__restrict__ feat, int row_stride, int pw, int lane, const Geo &G,
+                                             const uint32_t *stage = nullptr) {
   constexpr int PPW0 = 64 / LP, PPW = PPW0 < RPW ? PPW0 : RPW, NP = RPW / PPW, LPI = LP / NJ, NC = LPI * 4, DEPTH = NP <= FC_DEPTH ? NP : (FC_DEPTH < 3 ? FC_DEPTH : 3);  // passes in flight (the fine levels miss the caches: all of a slab's passes)
   const int C = L.C;
   const GLOBAL_AS char *vol = (const GLOBAL_AS char *)L.vol;
-  // ---- phase 1
-  const int irow = RPW * pw + min(lane / NJ, RPW - 1);
-  const int64_t pn = min(m0 + irow, M - 1);
-  const int b = (int)(pn / N);
-  const Corner c = sample_corner(points + pn * 3, S.j0 + lane % NJ, disp, L.D, L.H, L.W, ac);
-  const Weights w = corner_weights(c);
-  int xc[2], yc[2], zc[2];
-  bool vx[2], vy[2], vz[2];
-#pragma unroll
-  for (int a = 0; a < 2; ++a) {
-    vx[a] = w.x0 + a >= 0 && w.x0 + a < L.W;
-    vy[a] = w.y0 + a >= 0 && w.y0 + a < L.H;
-    vz[a] = w.z0 + a >= 0 && w.z0 + a < L.D;
-    xc[a] = min(max(w.x0 + a, 0), L.W - 1);
-    yc[a] = min(max(w.y0 + a, 0), L.H - 1);
-    zc[a] = min(max(w.z0 + a, 0), L.D - 1);
-  }
-  int wk[8], ezy[4], ex[2];
-#pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    const float wt = (w.wx[k & 1] * w.wy[(k >> 1) & 1]) * w.wz[k >> 2];
-    wk[k] = __float_as_int((vx[k & 1] && vy[(k >> 1) & 1] && vz[k >> 2]) ? wt : 0.f);
-  }
   constexpr uint32_t EB = BF ? 2u : 4u;   // bytes per stored channel value
-  if constexpr (STAGED) {   // byte offsets inside the staged box: [z][y][x][64 channels of this half]
-    (void)b;
+  // the register set that holds this slab's displacements (j0 is even for NJ == 2: both sit in one set)
+  int ge[GEO_N];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) ezy[i] = (((zc[i >> 1] - box.z0) * box.by + (yc[i & 1] - box.y0)) * box.bx) * 256;
+  for (int k = 0; k < GEO_N; ++k) ge[k] = G.v[0][k];
 #pragma unroll
-    for (int a = 0; a < 2; ++a) ex[a] = (xc[a] - box.x0) * 256;
-  } else {
+  for (int r = 1; r < GEO_SETS; ++r)
+    if (S.j0 / GEO_IPS == r) {   // (wave uniform)
 #pragma unroll
-  for (int i = 0; i < 4; ++i) ezy[i] = (int)((uint32_t)(((b * L.D + zc[i >> 1]) * L.H + yc[i & 1]) * L.W * C) * EB);  // host: < 2^30 elements
-#pragma unroll
-  for (int a = 0; a < 2; ++a) ex[a] = (xc[a] * C + S.c0) * (int)EB;
-  }
-  // ---- phase 2
+      for (int k = 0; k < GEO_N; ++k) ge[k] = G.v[r][k];
+    }
   const int g = lane / LP, q = lane % LP, jj = q / LPI, c4 = (q % LPI) * 4;
-  const int src0 = (g * NJ + jj) << 2;
+  const int src0 = (((S.j0 + jj) % GEO_IPS) * RPW + g) << 2;   // + it * PPW rows
+  const uint32_t xoff = STAGED ? (uint32_t)c4 * 4u : (uint32_t)(S.c0 + c4) * EB;
   const int col = jj * NC + c4;  // column inside the slab
   // row of pass `it` = RPW pw + g + it PPW: its swizzle bit (bit 3) is known at compile time when PPW <= 8 (g < PPW), else
   // (PPW = 16) it is bit 3 of g: at most one v_xor per pass
@@ -232,14 +264,14 @@ __device__ __forceinline__ void produce_slab(const FcLevel L, const FcSlab S, ui
     float w[8];
   };
   auto fetch = [&](Iter &I, int it) {
-    const int src = src0 + it * (PPW * NJ * 4);
+    const int src = src0 + it * (PPW * 4);
     uint32_t zy[4], x[2];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) zy[i] = (uint32_t)__builtin_amdgcn_ds_bpermute(src, ezy[i]);
+    for (int i = 0; i < 4; ++i) zy[i] = (uint32_t)__builtin_amdgcn_ds_bpermute(src, ge[i]);
 #pragma unroll
-    for (int a = 0; a < 2; ++a) x[a] = (uint32_t)__builtin_amdgcn_ds_bpermute(src, ex[a]) + (uint32_t)c4 * EB;
+    for (int a = 0; a < 2; ++a) x[a] = (uint32_t)__builtin_amdgcn_ds_bpermute(src, ge[4 + a]) + xoff;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) I.w[k] = __int_as_float(__builtin_amdgcn_ds_bpermute(src, wk[k]));
+    for (int k = 0; k < 8; ++k) I.w[k] = __int_as_float(__builtin_amdgcn_ds_bpermute(src, ge[6 + k]));
     if constexpr (BF) {   // four bf16 channels = one 8-byte load; widened to f32 exactly (bf16 = the upper half of an f32)
       u32x2_t raw[8];
 #pragma unroll
@@ -258,9 +290,21 @@ __device__ __forceinline__ void produce_slab(const FcLevel L, const FcSlab S, ui
     }
   };
   auto finish = [&](const Iter &I, int it) {
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    f32x4 acc;
+    if constexpr (FC_FMA != 0 && !BF) {   // one rounding per step (v_pk_fma_f32)
+      acc = I.v[0] * I.w[0];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) acc = acc + I.v[k] * I.w[k];
+      for (int k = 1; k < 8; ++k) {
+        const f32x2_t wk = {I.w[k], I.w[k]};
+        const f32x2_t lo = __builtin_elementwise_fma(wk, f32x2_t{I.v[k].x, I.v[k].y}, f32x2_t{acc.x, acc.y});
+        const f32x2_t hi = __builtin_elementwise_fma(wk, f32x2_t{I.v[k].z, I.v[k].w}, f32x2_t{acc.z, acc.w});
+        acc = f32x4{lo.x, lo.y, hi.x, hi.y};
+      }
+    } else {
+      acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int k = 0; k < 8; ++k) acc = acc + I.v[k] * I.w[k];
+    }
     uint32_t *d = buf + (dsto ^ (PPW == 16 ? 0 : (((it * PPW) >> 3) & 1) * 4)) + it * (PPW * FLW);
     if constexpr (BF) {   // the feature values in bf16 (one rounding), one plane
       *reinterpret_cast<uint2 *>(d) = make_uint2(pack_bf16_rne(acc.x, acc.y), pack_bf16_rne(acc.z, acc.w));
@@ -366,7 +410,7 @@ __device__ __forceinline__ void stage_box(const FcLevel L, int c0, const FcBox b
 template <bool BF>
 __device__ __forceinline__ void produce(const FcArgs &A, int s, uint32_t *buf, const float *points, int64_t m0, int64_t M,
                                         int N, float disp, int ac, float *feat, int row_stride, int pw, int lane, int dbg,
-                                        uint32_t *stage, const FcBox *__restrict__ boxes) {
+                                        uint32_t *stage, const FcBox *__restrict__ boxes, Geo &G) {
   const FcSlab S = A.S[s];
   const FcLevel L = A.L[S.level];
   if constexpr (!BF) {
@@ -377,7 +421,8 @@ __device__ __forceinline__ void produce(const FcArgs &A, int s, uint32_t *buf, c
         return;
       }
       if (box.nvox > 0) {
-        produce_slab<16, 1, BF, true>(L, S, buf, points, m0, M, N, disp, ac, feat, row_stride, pw, lane, stage, box);
+        if (S.geo) level_geometry<BF, true>(L, points, m0, M, N, disp, ac, pw, lane, box, G);
+        produce_slab<16, 1, BF, true>(L, S, buf, m0, M, feat, row_stride, pw, lane, G, stage);
         return;
       }
     }
@@ -391,12 +436,13 @@ __device__ __forceinline__ void produce(const FcArgs &A, int s, uint32_t *buf, c
     produce_c1<BF>(L, S, buf, points, m0, M, N, disp, ac, feat, row_stride, pw * 64 + lane);
     return;
   }
+  if (S.geo) level_geometry<BF, false>(L, points, m0, M, N, disp, ac, pw, lane, FcBox{}, G);
   switch (S.lp * 4 + S.nj) {
-    case 16 * 4 + 1: produce_slab<16, 1, BF>(L, S, buf, points, m0, M, N, disp, ac, feat, row_stride, pw, lane); break;
-    case 16 * 4 + 2: produce_slab<16, 2, BF>(L, S, buf, points, m0, M, N, disp, ac, feat, row_stride, pw, lane); break;
-    case 8 * 4 + 1: produce_slab<8, 1, BF>(L, S, buf, points, m0, M, N, disp, ac, feat, row_stride, pw, lane); break;
-    case 8 * 4 + 2: produce_slab<8, 2, BF>(L, S, buf, points, m0, M, N, disp, ac, feat, row_stride, pw, lane); break;
-    case 4 * 4 + 1: produce_slab<4, 1, BF>(L, S, buf, points, m0, M, N, disp, ac, feat, row_stride, pw, lane); break;
+    case 16 * 4 + 1: produce_slab<16, 1, BF>(L, S, buf, m0, M, feat, row_stride, pw, lane, G); break;
+    case 16 * 4 + 2: produce_slab<16, 2, BF>(L, S, buf, m0, M, feat, row_stride, pw, lane, G); break;
+    case 8 * 4 + 1: produce_slab<8, 1, BF>(L, S, buf, m0, M, feat, row_stride, pw, lane, G); break;
+    case 8 * 4 + 2: produce_slab<8, 2, BF>(L, S, buf, m0, M, feat, row_stride, pw, lane, G); break;
+    case 4 * 4 + 1: produce_slab<4, 1, BF>(L, S, buf, m0, M, feat, row_stride, pw, lane, G); break;
   }
 }
 
@@ -441,6 +487,7 @@ __global__ __launch_bounds__(512, FTM == 64 ? 4 : 2) void gather_fc0_kernel(cons
       for (int cc = pad_start; cc < row_stride; ++cc) feat[(m0 + (t - 256)) * row_stride + cc] = 0.f;
     // slab s + 1 is produced into the buffer the consumers are not reading, then the barrier hands both over (ONE call site:
     // with a second, peeled call for slab 0 the compiler inlined all five slab shapes twice and spilled 268 B / lane)
+    Geo G;   // the sample geometry of the level in work (level_geometry), alive across that level's slabs
     for (int s = -1; s < S; ++s) {
       // (the lane index is made opaque per slab: with seven slab shapes the lane-derived constants of ALL of them were hoisted
       // in front of this loop and 12 of them spilled; recomputed per slab they cost a few dozen VALU instructions)
@@ -448,7 +495,7 @@ __global__ __launch_bounds__(512, FTM == 64 ? 4 : 2) void gather_fc0_kernel(cons
       if constexpr (!BF) asm volatile("" : "+v"(lane_s));   // (the bf16 variant has no staged shapes and no spills)
       if (s + 1 < S && !(dbg & 1))
         produce<BF>(A, s + 1, lds + ((s + 1) & 1) * FSLAB, points, m0, M, N, disp, ac, feat, row_stride, pw, lane_s, dbg, lds + 2 * FSLAB,
-                    boxes + (int64_t)blockIdx.x * FC_NSTAGE);
+                    boxes + (int64_t)blockIdx.x * FC_NSTAGE, G);
       slab_barrier();
     }
     return;
@@ -640,6 +687,7 @@ bool build_slabs(const svr_gather_desc *d, uint32_t keep_mask, FcArgs &A, const 
   int ns = 0, k = 0;
   A.n_stage = 0;
   for (int i = 0; i < FC_NSTAGE; ++i) A.stage_level[i] = 0;
+  int geo_level = -1;   // level whose geometry slab has been flagged
   auto add = [&](int level, int j0, int nj, int lp, int c0, int cols, int st = -1) {
     if (ns >= FC_MAX_SLABS) return false;
     FcSlab &S = A.S[ns++];
@@ -652,7 +700,8 @@ bool build_slabs(const svr_gather_desc *d, uint32_t keep_mask, FcArgs &A, const 
     S.c0 = c0;
     S.keep = (int)((keep_mask >> level) & 1);
     S.stage = st;
-    S.pad = 0;
+    S.geo = (lp > 0 && level != geo_level) ? 1 : 0;   // first displacement slab of the level
+    if (S.geo) geo_level = level;
     k += cols / FK;
     return true;
   };

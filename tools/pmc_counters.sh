@@ -7,6 +7,20 @@ set -u
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 PAT=$1; shift
+budget_ok() {   # $1 = counter list of one pass: 8 SQ / 4 TCC / 2 GRBM slots (an oversubscribed pass is rocprofv3's "error code 38")
+  local sq=0 tcc=0 grbm=0 other=0 c
+  for c in $1; do
+    case $c in
+      FETCH_SIZE) tcc=$((tcc+3));; WRITE_SIZE) tcc=$((tcc+2));;
+      SQ_*) sq=$((sq+1));; TCC_*) tcc=$((tcc+1));; GRBM_*) grbm=$((grbm+1));; *) other=$((other+1));;
+    esac
+  done
+  if [ $sq -gt 8 ] || [ $tcc -gt 4 ] || [ $grbm -gt 2 ] || [ $other -gt 4 ]; then
+    echo "pmc_counters: pass '$1' exceeds the per-pass counter budget (SQ $sq/8, TCC $tcc/4, GRBM $grbm/2, other $other/4): split it"
+    return 1
+  fi
+}
+for G in "$@"; do budget_ok "$G" || exit 2; done
 n=0
 for G in "$@"; do
   n=$((n + 1))
