@@ -15,8 +15,11 @@ LIB = os.path.join(LIBDIR, "libsvr_hip.so")
 SOURCES = {
     "capi.cpp": [],
     "gather.hip": ["-ffp-contract=off"],
-    "gather_fc0.hip": ["-ffp-contract=off"] + [f"-D{k}={os.environ[e]}" for k, e in (("FC_TM", "SVR_FC_TM"), ("FC_DEPTH", "SVR_FC_DEPTH"))
-                                               if os.environ.get(e)],   # tile-shape experiments
+    "gather_fc0.hip": ["-ffp-contract=off"] + [f"-D{k}={os.environ[e]}" for k, e in (("FC_TM", "SVR_FC_TM"), ("FC_DEPTH", "SVR_FC_DEPTH"), ("FC_FMA", "SVR_FC_FMA"))
+                                               if os.environ.get(e)]    # tile-shape experiments
+                      + (["-DSVR_FC0_MEASURE"] if os.environ.get("SVR_FC0_MEASURE") else [])   # role switches (SVR_FC0_DBG)
+                      + ["-D" + d for d in os.environ.get("SVR_FC_DEFS", "").split()]   # experiments: SVR_FC_DEFS="FC_PRIO=1 FC_PK=0"
+                      + (["-fno-slp-vectorize"] if "FC_PK=0" in os.environ.get("SVR_FC_DEFS", "").split() else []),
     "sort.hip": [],
     "gemm.hip": [],
     "gemm_bf16x3.hip": [],

@@ -82,6 +82,12 @@ struct FcBox { int nvox, b, z0, y0, x0, by, bx, pad; };   // per (tile, staged l
 #ifndef FC_DEPTH
 #define FC_DEPTH 1
 #endif
+#ifndef FC_PRIO
+#define FC_PRIO 0  // s_setprio of the producer waves (the second-dispatched half of the workgroup loses VALU arbitration by age)
+#endif
+#ifndef FC_PK
+#define FC_PK 1    // corner sum / f16 split as packed f32 instructions (v_pk_mul/add/fma_f32) or as plain ones
+#endif
 #ifndef FC_FMA
 #define FC_FMA 0   // corner sum: 0 = ATen's rounding (bit-identical to F.grid_sample), 1 = one v_pk_fma_f32 per step
 #endif
@@ -185,17 +191,22 @@ constexpr int GEO_IPS = 64 / RPW;             // displacements per register set 
 constexpr int GEO_SETS = (7 + GEO_IPS - 1) / GEO_IPS;
 struct Geo { int v[GEO_SETS][GEO_N]; };
 
+// rowb: the lane's row of the tile (lane % RPW of the wave's rows, clamped to the last point) | its sample << 8 -- the same
+// for every level and round, computed once in front of the slab loop (a 64-bit pn / N per slab cost ~100 VALU)
 template <bool BF, bool STAGED>
-__device__ __forceinline__ void level_geometry(const FcLevel L, const float *__restrict__ points, int64_t m0, int64_t M, int N,
-                                               float disp, int ac, int pw, int lane, const FcBox box, Geo &G) {
+__device__ __forceinline__ void level_geometry(const FcLevel L, const float *__restrict__ pt0, int rowb, float disp, int ac, int lane,
+                                               const FcBox box, Geo &G) {
   constexpr uint32_t EB = BF ? 2u : 4u;   // bytes per stored channel value
   const int C = L.C;
 #pragma unroll
   for (int r = 0; r < GEO_SETS; ++r) {
     const int item = r * 64 + lane, j = min(item / RPW, 6);
-    const int64_t pn = min(m0 + RPW * pw + item % RPW, M - 1);
-    const int b = (int)(pn / N);
-    const Corner c = sample_corner(points + pn * 3, j, disp, L.D, L.H, L.W, ac);
+    const int row = rowb & 255, b = rowb >> 8;
+    // (uniform base + 32-bit lane offset: a per-lane 64-bit pointer would live -- spilled -- across the whole slab loop)
+    const GLOBAL_AS float *pg = (const GLOBAL_AS float *)pt0;
+    const uint32_t po = (uint32_t)row * 3u;
+    const float pt[3] = {pg[po], pg[po + 1u], pg[po + 2u]};
+    const Corner c = sample_corner(pt, j, disp, L.D, L.H, L.W, ac);
     const Weights w = corner_weights(c);
     int xc[2], yc[2], zc[2];
     bool vx[2], vy[2], vz[2];
@@ -260,9 +271,8 @@ __device__ __forceinline__ void produce_slab(const FcLevel L, const FcSlab S, ui
   const uint32_t fo0 = (uint32_t)((RPW * pw + g) * row_stride + L.kcol + (S.j0 + jj) * C + S.c0 + c4) * 4u;
   const int live = M - m0 < FTM ? (int)(M - m0) : FTM;
   struct Iter {
-    f32x4 v[8];
-    float w[8];
-  };
+    f32x4 v[8];   // (only the loaded values are in flight: the weights are fetched by finish(), so a second pass in flight
+  };              //  costs 32 registers, not 40)
   auto fetch = [&](Iter &I, int it) {
     const int src = src0 + it * (PPW * 4);
     uint32_t zy[4], x[2];
@@ -270,8 +280,6 @@ __device__ __forceinline__ void produce_slab(const FcLevel L, const FcSlab S, ui
     for (int i = 0; i < 4; ++i) zy[i] = (uint32_t)__builtin_amdgcn_ds_bpermute(src, ge[i]);
 #pragma unroll
     for (int a = 0; a < 2; ++a) x[a] = (uint32_t)__builtin_amdgcn_ds_bpermute(src, ge[4 + a]) + xoff;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) I.w[k] = __int_as_float(__builtin_amdgcn_ds_bpermute(src, ge[6 + k]));
     if constexpr (BF) {   // four bf16 channels = one 8-byte load; widened to f32 exactly (bf16 = the upper half of an f32)
       u32x2_t raw[8];
 #pragma unroll
@@ -290,12 +298,34 @@ __device__ __forceinline__ void produce_slab(const FcLevel L, const FcSlab S, ui
     }
   };
   auto finish = [&](const Iter &I, int it) {
+    float w[8];
+    {
+      const int src = src0 + it * (PPW * 4);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) w[k] = __int_as_float(__builtin_amdgcn_ds_bpermute(src, ge[6 + k]));
+    }
     f32x4 acc;
-    if constexpr (FC_FMA != 0 && !BF) {   // one rounding per step (v_pk_fma_f32)
-      acc = I.v[0] * I.w[0];
+    if constexpr (FC_PK == 0 && !BF) {   // plain f32 instructions: same values, same order
+      float a[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        if constexpr (FC_FMA != 0) {
+          a[c] = I.v[0][c] * w[0];
+#pragma unroll
+          for (int k = 1; k < 8; ++k) a[c] = __builtin_fmaf(I.v[k][c], w[k], a[c]);
+        } else {
+          a[c] = 0.f;
+#pragma unroll
+          for (int k = 0; k < 8; ++k) a[c] = a[c] + I.v[k][c] * w[k];
+        }
+        asm volatile("" : "+v"(a[c]));   // (keeps the SLP vectoriser from packing the four chains again)
+      }
+      acc = f32x4{a[0], a[1], a[2], a[3]};
+    } else if constexpr (FC_FMA != 0 && !BF) {   // one rounding per step (v_pk_fma_f32)
+      acc = I.v[0] * w[0];
 #pragma unroll
       for (int k = 1; k < 8; ++k) {
-        const f32x2_t wk = {I.w[k], I.w[k]};
+        const f32x2_t wk = {w[k], w[k]};
         const f32x2_t lo = __builtin_elementwise_fma(wk, f32x2_t{I.v[k].x, I.v[k].y}, f32x2_t{acc.x, acc.y});
         const f32x2_t hi = __builtin_elementwise_fma(wk, f32x2_t{I.v[k].z, I.v[k].w}, f32x2_t{acc.z, acc.w});
         acc = f32x4{lo.x, lo.y, hi.x, hi.y};
@@ -303,7 +333,7 @@ __device__ __forceinline__ void produce_slab(const FcLevel L, const FcSlab S, ui
     } else {
       acc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int k = 0; k < 8; ++k) acc = acc + I.v[k] * I.w[k];
+      for (int k = 0; k < 8; ++k) acc = acc + I.v[k] * w[k];
     }
     uint32_t *d = buf + (dsto ^ (PPW == 16 ? 0 : (((it * PPW) >> 3) & 1) * 4)) + it * (PPW * FLW);
     if constexpr (BF) {   // the feature values in bf16 (one rounding), one plane
@@ -311,8 +341,19 @@ __device__ __forceinline__ void produce_slab(const FcLevel L, const FcSlab S, ui
       return;
     }
     uint32_t h0, l0, h1, l1;
-    split_x(acc.x, acc.y, h0, l0);
-    split_x(acc.z, acc.w, h1, l1);
+    if constexpr (FC_PK == 0) {   // split_x with plain f32 instructions (same values)
+      h0 = pack_f16(acc.x, acc.y);
+      h1 = pack_f16(acc.z, acc.w);
+      const f32x2 u0 = unpack_f16(h0), u1 = unpack_f16(h1);
+      float r[4] = {(acc.x - u0.x) * 2048.f, (acc.y - u0.y) * 2048.f, (acc.z - u1.x) * 2048.f, (acc.w - u1.y) * 2048.f};
+#pragma unroll
+      for (int c = 0; c < 4; ++c) asm volatile("" : "+v"(r[c]));
+      l0 = pack_f16(r[0], r[1]);
+      l1 = pack_f16(r[2], r[3]);
+    } else {
+      split_x(acc.x, acc.y, h0, l0);
+      split_x(acc.z, acc.w, h1, l1);
+    }
     *reinterpret_cast<uint2 *>(d) = make_uint2(h0, h1);
     *reinterpret_cast<uint2 *>(d + FPLANE) = make_uint2(l0, l1);
     if (S.keep && (PPW0 <= RPW || g < RPW) && RPW * pw + it * PPW + g < live)
@@ -372,12 +413,14 @@ __device__ __forceinline__ void produce_c1(const FcLevel L, const FcSlab S, uint
       if (!BF) b16[(FPLANE + s0) * 2 + j] = __builtin_bit_cast(uint16_t, l);
       if (!BF && S.keep && m0 + row < M) feat[(m0 + row) * row_stride + L.kcol + j] = acc;
     } else {  // halves 7 .. 15 of the row: zeros
-      b16[s0 * 2 + 7] = 0;
-      if (!BF) b16[(FPLANE + s0) * 2 + 7] = 0;
+      uint32_t z = 0u;
+      asm volatile("" : "+v"(z));   // (a hoisted uint4 of zeros was kept -- spilled -- across the whole slab loop)
+      b16[s0 * 2 + 7] = (uint16_t)z;
+      if (!BF) b16[(FPLANE + s0) * 2 + 7] = (uint16_t)z;
 #pragma unroll
       for (int p = 0; p < 4; ++p) {
-        buf[s1 + p] = 0u;
-        if (!BF) buf[FPLANE + s1 + p] = 0u;
+        buf[s1 + p] = z;
+        if (!BF) buf[FPLANE + s1 + p] = z;
       }
     }
   }
@@ -410,7 +453,7 @@ __device__ __forceinline__ void stage_box(const FcLevel L, int c0, const FcBox b
 template <bool BF>
 __device__ __forceinline__ void produce(const FcArgs &A, int s, uint32_t *buf, const float *points, int64_t m0, int64_t M,
                                         int N, float disp, int ac, float *feat, int row_stride, int pw, int lane, int dbg,
-                                        uint32_t *stage, const FcBox *__restrict__ boxes, Geo &G) {
+                                        uint32_t *stage, const FcBox *__restrict__ boxes, Geo &G, int rowb) {
   const FcSlab S = A.S[s];
   const FcLevel L = A.L[S.level];
   if constexpr (!BF) {
@@ -421,7 +464,7 @@ __device__ __forceinline__ void produce(const FcArgs &A, int s, uint32_t *buf, c
         return;
       }
       if (box.nvox > 0) {
-        if (S.geo) level_geometry<BF, true>(L, points, m0, M, N, disp, ac, pw, lane, box, G);
+        if (S.geo) level_geometry<BF, true>(L, points + m0 * 3, rowb, disp, ac, lane, box, G);
         produce_slab<16, 1, BF, true>(L, S, buf, m0, M, feat, row_stride, pw, lane, G, stage);
         return;
       }
@@ -436,7 +479,7 @@ __device__ __forceinline__ void produce(const FcArgs &A, int s, uint32_t *buf, c
     produce_c1<BF>(L, S, buf, points, m0, M, N, disp, ac, feat, row_stride, pw * 64 + lane);
     return;
   }
-  if (S.geo) level_geometry<BF, false>(L, points, m0, M, N, disp, ac, pw, lane, FcBox{}, G);
+  if (S.geo) level_geometry<BF, false>(L, points + m0 * 3, rowb, disp, ac, lane, FcBox{}, G);
   switch (S.lp * 4 + S.nj) {
     case 16 * 4 + 1: produce_slab<16, 1, BF>(L, S, buf, m0, M, feat, row_stride, pw, lane, G); break;
     case 16 * 4 + 2: produce_slab<16, 2, BF>(L, S, buf, m0, M, feat, row_stride, pw, lane, G); break;
@@ -472,30 +515,44 @@ __global__ __launch_bounds__(512, FTM == 64 ? 4 : 2) void gather_fc0_kernel(cons
                                                             const uint32_t *__restrict__ amax, const float *__restrict__ bias,
                                                             float *__restrict__ Y, int64_t ldy, float *__restrict__ feat,
                                                             int row_stride, int pad_start, int64_t M, int N, float disp, int ac,
-                                                            int relu, int dbg_arg, const FcBox *__restrict__ boxes) {
+                                                            int relu, int dbg_arg, const FcBox *__restrict__ boxes, int xcd) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   const int dbg = FC_DBG(dbg_arg);
   const FcArgs &A = *Ap;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int64_t m0 = (int64_t)blockIdx.x * FTM;
+  // tile of this workgroup: the block id, or (xcd: grid padded to a multiple of 8) a tile order that is contiguous per XCD
+  const int64_t tile = xcd ? xcd_logical(blockIdx.x, gridDim.x) : (int64_t)blockIdx.x;
+  const int64_t m0 = tile * FTM;
+  if (m0 >= M) return;   // (whole workgroup, in front of the first barrier)
   const int S = A.n_slabs;
   if (dbg & 8) return;
   if (wave >= 4) {
     // ------------------------------------------------------------------ producers
-    const int pw = wave - 4;
+    const int pw = __builtin_amdgcn_readfirstlane(wave) - 4;   // (uniform: everything derived from it is scalar arithmetic)
+    if constexpr (FC_PRIO != 0) __builtin_amdgcn_s_setprio(FC_PRIO);
     if (pad_start >= 0 && t - 256 < FTM && m0 + (t - 256) < M)  // kept rows: the padding columns behind the last level are zeros
       for (int cc = pad_start; cc < row_stride; ++cc) feat[(m0 + (t - 256)) * row_stride + cc] = 0.f;
     // slab s + 1 is produced into the buffer the consumers are not reading, then the barrier hands both over (ONE call site:
     // with a second, peeled call for slab 0 the compiler inlined all five slab shapes twice and spilled 268 B / lane)
     Geo G;   // the sample geometry of the level in work (level_geometry), alive across that level's slabs
+    int rowb;
+    {
+      static_assert(FTM <= 256, "row in the low byte of rowb");
+      const int last = (int)min<int64_t>(M - 1 - m0, FTM - 1);
+      const int row = min(RPW * pw + lane % RPW, last);
+      const int b0 = (int)(m0 / N);                                // (uniform)
+      rowb = row | ((b0 + (int)((uint32_t)((int)(m0 - (int64_t)b0 * N) + row) / (uint32_t)N)) << 8);
+      asm volatile("" : "+v"(rowb));    // one register, not its recomputable pieces hoisted and spilled
+    }
     for (int s = -1; s < S; ++s) {
       // (the lane index is made opaque per slab: with seven slab shapes the lane-derived constants of ALL of them were hoisted
       // in front of this loop and 12 of them spilled; recomputed per slab they cost a few dozen VALU instructions)
       int lane_s = lane;
-      if constexpr (!BF) asm volatile("" : "+v"(lane_s));   // (the bf16 variant has no staged shapes and no spills)
+      int rowb_s = rowb;
+      asm volatile("" : "+v"(lane_s), "+v"(rowb_s));   // (rowb too: the point address derived from it was hoisted and spilled)
       if (s + 1 < S && !(dbg & 1))
         produce<BF>(A, s + 1, lds + ((s + 1) & 1) * FSLAB, points, m0, M, N, disp, ac, feat, row_stride, pw, lane_s, dbg, lds + 2 * FSLAB,
-                    boxes + (int64_t)blockIdx.x * FC_NSTAGE, G);
+                    boxes + tile * FC_NSTAGE, G, rowb_s);
       slab_barrier();
     }
     return;
@@ -884,9 +941,12 @@ extern "C" int svr_gather_fc0_run(const svr_gather_desc *d, const float *points,
   if (A.n_stage > 0)   // the tiles' bounding boxes at the staged levels (the points change from call to call)
     hipLaunchKernelGGL(fc0_boxes_kernel, dim3((unsigned)cdiv(M, FTM)), dim3(64), 0, (hipStream_t)stream, ws.Ad, points, M, d->N,
                        d->displacement, d->align_corners, ws.boxes);
-  hipLaunchKernelGGL(gather_fc0_kernel<false>, dim3((unsigned)cdiv(M, FTM)), dim3(512), FC_LDS_BYTES, (hipStream_t)stream, ws.Ad, points,
+  // SVR_FC0_XCD=1: tiles contiguous per XCD (Morton neighbours share an L2) instead of dealt round-robin over the eight
+  static const int xcd = (getenv("SVR_FC0_XCD") && getenv("SVR_FC0_XCD")[0] == '1') ? 1 : 0;
+  const unsigned grid = xcd ? xcd_grid(cdiv(M, FTM)) : (unsigned)cdiv(M, FTM);
+  hipLaunchKernelGGL(gather_fc0_kernel<false>, dim3(grid), dim3(512), FC_LDS_BYTES, (hipStream_t)stream, ws.Ad, points,
                      ws.p0, ws.amax, eb, Y, ldy, feat, (int)ldf, keep_levels ? (int)pad_start : -1, M, d->N, d->displacement,
-                     d->align_corners, relu, dbg, ws.boxes);
+                     d->align_corners, relu, dbg, ws.boxes, xcd);
   return launch_status("gather_fc0_run");
 }
 
@@ -941,6 +1001,6 @@ extern "C" int svr_gather_fc0_bf16_run(const svr_gather_desc *d, const float *po
   const int relu = epilogue == SVR_EPI_BIAS_RELU ? 1 : 0;
   hipLaunchKernelGGL(gather_fc0_kernel<true>, dim3((unsigned)cdiv(M, FTM)), dim3(512), FC_LDS_BYTES, (hipStream_t)stream, ws.Ad, points,
                      ws.p0, ws.amax, eb, reinterpret_cast<float *>(Y), ldy, (float *)nullptr, 0, -1, M, d->N, d->displacement,
-                     d->align_corners, relu, 0, (const FcBox *)nullptr);
+                     d->align_corners, relu, 0, (const FcBox *)nullptr, 0);
   return launch_status("gather_fc0_bf16_run");
 }

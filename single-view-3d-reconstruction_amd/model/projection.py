@@ -111,11 +111,20 @@ class project(nn.Module):
         return tuple(int(v) for v in self.vox_size)
 
     def _consts(self, scale_factor):
-        _, inv, t = _camera_to_grid(self.intrinsic.cpu(), scale_factor)
+        """The 12 kernel constants of one (intrinsic, scale_factor, dims): computed once and cached.  (They are a dozen tiny
+        CPU tensor ops -- torch.inverse, mm, min / max -- which cost 25 ms of HOST time per training step on a GPU box whose
+        128 intra-op threads share a 16-CPU quota, and stalled the eager config-5 step: profiles/r04_scene_host_profile.txt.)"""
         K = self.intrinsic
+        key = (float(scale_factor), self._dims(), K.data_ptr(), K._version)
+        hit = getattr(self, "_consts_cache", None)
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        _, inv, t = _camera_to_grid(K.cpu(), scale_factor)
         d = self._dims()
-        return [float(K[0, 0]), float(K[0, 2]), float(K[1, 2]), float(inv), float(t[0]), float(inv), float(t[1]),
-                float(inv), float(t[2]), float(d[0]), float(d[1]), float(d[2])]
+        c = [float(K[0, 0]), float(K[0, 2]), float(K[1, 2]), float(inv), float(t[0]), float(inv), float(t[1]),
+             float(inv), float(t[2]), float(d[0]), float(d[1]), float(d[2])]
+        self._consts_cache = (key, c)
+        return c
 
     # -- depth -> points -------------------------------------------------------------------
     def depthmap_to_gridspace(self, depthmap, scale_factor=1, normalize=False):

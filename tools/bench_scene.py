@@ -20,6 +20,10 @@ ap.add_argument("--steps", type=int, default=10)
 ap.add_argument("--warmup", type=int, default=8, help="the step arena and the scatter-form decision (fixed lag 3) settle in the first steps")
 ap.add_argument("--batch", type=int, default=4)
 ap.add_argument("--points", type=int, default=50000)
+ap.add_argument("--gc", default="default", choices=["default", "freeze", "off"],
+                help="Python's cyclic collector over the timed steps: untouched, gc.freeze() after the warm-up (the modules / "
+                     "graphs / caches alive by then leave the collector's generations), or disabled")
+ap.add_argument("--inflight", type=int, default=2, help="steps the host may run ahead of the GPU (0: unbounded)")
 ap.add_argument("--graph", action="store_true", help="capture the whole step into a HIP graph (svr_amd.graphs.GraphedStep)")
 ap.add_argument("--unet-backend", default="hip", choices=["hip", "stock"])
 ap.add_argument("--miopen-benchmark", action="store_true", help="torch.backends.cudnn.benchmark: let MIOpen time its solvers")
@@ -45,12 +49,20 @@ else:
 batch = {"rgb": rgb.cuda(), "depthmap_target": target.cuda(), "points": pts.cuda(), "occupancies": occ.cuda()}
 
 
+phase_ms = []      # host time of the eager step's phases (forward, backward, optimizer): where a slow step lost its time
+
+
 def step():
+    t = [time.perf_counter()]
     opt.zero_grad(set_to_none=True)
     loss = tr.training_step(batch, 0)["loss"]
+    t.append(time.perf_counter())
     loss.backward()
+    t.append(time.perf_counter())
     opt.step()
-    return loss
+    t.append(time.perf_counter())
+    phase_ms.append([round((b - a_) * 1e3, 2) for a_, b in zip(t, t[1:])])
+    return loss.detach()      # (not the graph: a kept loss tensor keeps its step's activations alive while the next step allocates)
 
 
 if a.graph:
@@ -62,12 +74,60 @@ if a.graph:
 for _ in range(a.warmup):
     step()
 torch.cuda.synchronize()
+import gc  # noqa: E402
+if a.gc == "freeze":
+    gc.collect()
+    gc.freeze()
+elif a.gc == "off":
+    gc.collect()
+    gc.disable()
+gc_events = []
+_gc_t = [0.0]
+
+
+def _gc_cb(phase, info):      # how long each collection of the timed region took, and of which generation
+    if phase == "start":
+        _gc_t[0] = time.perf_counter()
+    else:
+        gc_events.append((info["generation"], round((time.perf_counter() - _gc_t[0]) * 1e3, 2)))
+
+
+gc.callbacks.append(_gc_cb)
+# every timed step on its own: HIP events at the step boundaries, the host's enqueue time and the caching allocator's
+# hipMalloc count per step (the only kept round-3 artefact said 106.5 ms eager and nobody could tell why)
+dev = torch.device("cuda")
+marks = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]
+done = []
+host_ms, mallocs = [], []
+m_prev = torch.cuda.memory_stats(dev).get("num_device_alloc", 0)
 t0 = time.perf_counter()
-for _ in range(a.steps):
+marks[0].record()
+for i in range(a.steps):
+    if a.inflight and len(done) >= a.inflight:      # like DataParallelTrainer: at most `inflight` steps queued ahead of the GPU
+        done[-a.inflight].synchronize()
+    h0 = time.perf_counter()
     loss = step()
+    marks[i + 1].record()
+    done.append(marks[i + 1])
+    host_ms.append((time.perf_counter() - h0) * 1e3)
+    m = torch.cuda.memory_stats(dev).get("num_device_alloc", 0)
+    mallocs.append(m - m_prev)
+    m_prev = m
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / a.steps
+step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(a.steps)]
+srt = sorted(step_ms)
 print(json.dumps({"workload": f"BASELINE configs[4] per-GPU shard: UNet -> unproject -> project(128^3) -> IF-Net, batch {a.batch}, "
                               f"{a.points} points, fwd+bwd+Adam", "ms_per_step": dt * 1e3,
                   "query_points_per_s": a.batch * a.points / dt, "loss": float(loss), "unet_backend": a.unet_backend,
-                  "hip_graph": bool(a.graph)}))
+                  "hip_graph": bool(a.graph), "steps": a.steps, "warmup": a.warmup, "inflight": a.inflight,
+                  "step_ms": {"min": srt[0], "median": srt[len(srt) // 2], "max": srt[-1]},
+                  "step_ms_list": [round(v, 2) for v in step_ms],
+                  "host_enqueue_ms": {"median": sorted(host_ms)[len(host_ms) // 2], "max": max(host_ms)},
+                  "host_ms_list": [round(v, 1) for v in host_ms],
+                  "host_phase_ms_fwd_bwd_opt": phase_ms[-a.steps:] if not a.graph else None,
+                  "hipMalloc_calls_per_step": mallocs, "gc": a.gc,
+                  "gc_collections_ms": {"gen2": [t for g_, t in gc_events if g_ == 2],
+                                        "gen1_total": round(sum(t for g_, t in gc_events if g_ == 1), 2),
+                                        "gen0_total": round(sum(t for g_, t in gc_events if g_ == 0), 2)},
+                  "reserved_GB": torch.cuda.memory_stats(dev).get("reserved_bytes.all.current", 0) / 1e9}))

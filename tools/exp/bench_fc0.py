@@ -19,12 +19,23 @@ pts = torch.rand(B, N, 3, device="cuda") - 0.5
 if dist == "surface":
     v = torch.randn(B, N, 3, device="cuda")
     pts = (v / v.norm(dim=2, keepdim=True) * 0.35 + 0.01 * torch.randn(B, N, 3, device="cuda")).clamp(-0.5, 0.5)
+if dist == "tiny":      # all points inside a cube of edge 0.1: every level's working set is L2 resident (latency experiment)
+    pts = pts * 0.1
+if dist == "same":      # one point: every load hits the same lines (issue / LDS / barrier / MFMA floor of the kernel)
+    pts = torch.zeros_like(pts) + torch.tensor([0.1, 0.2, 0.3], device="cuda")
 _, pts = ops.morton_order(pts.contiguous(), want_sorted=True)
 layout = ops.FeatureLayout(chans)
 disp = float(np.float32(0.0722))
 w = torch.randn(256, layout.row_stride, device="cuda") / 30
 w[:, layout.width:] = 0
 bias = torch.randn(256, device="cuda")
+# DVFS experiments (MI355X_MICROARCH.md "DVFS give-back": matrix instructions on random operands lower the clock the chip
+# holds; on zeros they do not): zero weights / zero volumes keep every instruction and every address, only the operand bits change
+if "zerow" in sys.argv[2:]:
+    w.zero_()
+if "zerov" in sys.argv[2:]:
+    for v in vols:
+        v.zero_()
 
 
 def timeit(f, n=10):
