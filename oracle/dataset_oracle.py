@@ -8,10 +8,14 @@ TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).  Follows:
 * file formats written by ......... data_processing/process_sample.py:19-30 (np.savez_compressed(depth_grid, grid=float64
                                    grid); copy of the .df; np.savez(occupancy_<sigma>, points, occupancies, grid_coords))
 
-Parity: the real data/processed/overfit/00000/depth_grid.npz of the reference is kept as tests/golden/ref_depth_grid.npz
-(the only sample file the reference ships: target.df and the occupancy files are listed in .MISSING_LARGE_BLOBS); the
-.df / occupancy paths are exercised on synthetic files written with exactly process_sample.py's calls.  The reference
-modules themselves cannot be imported here (skimage, trimesh, pyexr are not installed): "parity unpinned" beyond that.
+Parity: PINNED by the reference itself.  oracle/gen_golden_dataset.py imports the reference's unmodified
+dataset/implicit_dataset.py and data_processing/volume_reader.py in the build container (visualisation-only packages as
+empty modules; skimage.measure.block_reduce -- only reachable with scale_factor != 1 -- as a function that raises) and
+stores what ImplicitDataset.__getitem__ / read_df returned in tests/golden/dataset_{real_grid,synthetic}.npz;
+tests/test_sample_io.py holds getitem / read_df below (and the product's mirror over the native readers) to those
+outputs bit for bit.  The sample files are regenerated from the fixture's seeds by make_sample (process_sample.py's own
+calls) around the reference's real depth_grid.npz (tests/golden/ref_depth_grid.npz: the only sample file the reference
+ships -- target.df and the occupancy files are in .MISSING_LARGE_BLOBS).  Unpinned: down_sample (skimage absent).
 """
 import struct
 from pathlib import Path

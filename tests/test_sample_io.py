@@ -130,3 +130,58 @@ def test_malformed_npz_returns_an_error_instead_of_crashing(tmp_path):
     with pytest.raises(RuntimeError):
         io.npz_load(bad, "a")
     assert np.array_equal(io.npz_load(plain, "a"), np.arange(6.0).reshape(2, 3))  # the library is still usable afterwards
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Pinned by the REFERENCE ITSELF: tests/golden/dataset_*.npz hold what the reference's unmodified
+# dataset/implicit_dataset.py (ImplicitDataset.__getitem__, :24-56) and data_processing/volume_reader.py (read_df, :36-45)
+# returned in the build container (oracle/gen_golden_dataset.py) on sample files that the seeds in the fixture regenerate
+# here with oracle.dataset_oracle.make_sample.  Held to them bit for bit: the oracle's restatement (getitem / read_df),
+# the product's ImplicitDataset mirror and its native .df / .npz readers.
+# ---------------------------------------------------------------------------------------------------------------------
+DATASET_CASES = [("dataset_real_grid", "00000", None), ("dataset_synthetic", "00001", (23, 17, 19))]
+
+
+def _check_against_fixture(z, s, df):
+    dims = tuple(int(v) for v in z["dims"])
+    assert tuple(s["input"].shape) == (1,) + dims and s["input"].dtype == torch.float32
+    bits = np.unpackbits(z["input_bits"])[: int(np.prod(dims))].reshape(dims)
+    assert np.array_equal(s["input"][0].numpy(), bits.astype(np.float32)) and float(s["input"].double().sum()) == float(z["input_sum"])
+    for k in ("points", "grid", "occupancies"):
+        assert s[k].dtype == torch.float32 and np.array_equal(s[k].numpy(), z[k]), k
+    t = s["target"]
+    assert tuple(t.shape) == tuple(int(v) for v in z["target_shape"]) and t.dtype == torch.float32
+    if z["target"].ndim == 4:
+        assert np.array_equal(t.numpy(), z["target"])
+    else:      # the 1.6 M-voxel field: the strided sample exactly + the reference's float64 moments (sum, sum of squares, index-weighted sum)
+        assert np.array_equal(t.numpy().reshape(-1)[::97], z["target"])
+        td = t.double().reshape(-1)
+        mom = np.array([td.sum().item(), (td ** 2).sum().item(), (td * torch.arange(td.numel(), dtype=torch.float64)).sum().item()])
+        assert np.allclose(mom, z["target_moments"], rtol=1e-12, atol=1e-9)
+    assert bool(z["read_df_equals_target"]) and np.array_equal(df, t.numpy()[0]) and df.dtype == np.float32
+
+
+@pytest.mark.parametrize("tag,item,dims", DATASET_CASES)
+def test_dataset_oracle_and_mirror_against_the_reference_loader(tmp_path, tag, item, dims):
+    import svr_amd  # noqa: F401
+    from svr_amd.data_processing.volume_reader import read_df
+    from svr_amd.dataset import ImplicitDataset
+    z = np.load(os.path.join(GOLD, tag + ".npz"))
+    n_pts, fseed, num_points, nseed, real = (int(v) for v in z["meta"])
+    assert real == (dims is None)
+    folder = tmp_path / "data" / "processed" / "overfit" / item
+    DO.make_sample(folder, dims=dims or (1, 1, 1), n_pts=n_pts, seed=fseed,
+                   grid_from=os.path.join(GOLD, "ref_depth_grid.npz") if real else None)
+    # (1) the oracle's restatement
+    np.random.seed(nseed)
+    _check_against_fixture(z, DO.getitem(folder, item, num_points),
+                           DO.read_df(str(folder / "target.df")) if not real else read_df(str(folder / "target.df")))
+    # (2) the product's mirror over the native readers (C++ + zlib behind the C ABI)
+    (tmp_path / "splits" / "overfit").mkdir(parents=True)
+    (tmp_path / "splits" / "overfit" / "train.txt").write_text(item + "\n")
+    ds = ImplicitDataset("train", tmp_path / "data", num_points, "overfit", splits_root=tmp_path / "splits")
+    assert len(ds) == 50
+    np.random.seed(nseed)
+    got = ds[0]
+    assert got["name"] == item
+    _check_against_fixture(z, got, read_df(str(folder / "target.df")))
