@@ -58,7 +58,17 @@ constexpr int FTM = FC_TM;             // points per workgroup.  64 (two workgro
                                        // 16 waves per CU hide the producers' load latency; one pass in flight per producer
                                        // wave) 2.58 ms at config 3 against 2.83 for 128 (one workgroup per CU, 255 VGPRs,
                                        // three passes in flight): W is read twice as often (every 64 points), still faster
-constexpr int RPW = FTM / 4;           // rows per producer wave
+#ifndef FC_NPW
+#define FC_NPW 4
+#endif
+constexpr int NPW = FC_NPW;            // producer waves per workgroup: 4 (512 threads, two workgroups per CU at 128 VGPRs) or
+                                       // 8 (768 threads = 3 waves per SIMD at 168 VGPRs, one workgroup per CU: round 4 -- the
+                                       // in-kernel timeline showed a producer pass to be one ~1 600-cycle dependency chain and
+                                       // a consumer k-step to be one ~1 500-cycle W-fragment load latency; what hides them is
+                                       // passes / loads in flight, i.e. registers per wave)
+constexpr int NPT = NPW * 64;          // producer threads
+constexpr int NTHR = 256 + NPT;        // threads per workgroup (4 consumer waves first)
+constexpr int RPW = FTM / NPW;         // rows per producer wave
 constexpr int FMT = FTM / 32;          // 32-row MFMA tiles per consumer wave
 constexpr int FTN = 256;               // output columns (fc_0's width)
 constexpr int FPLANE = FTM * FLW;      // dwords per plane and k-step
@@ -80,7 +90,7 @@ constexpr int FC_STAGE_DW = FC_STAGE_VOX * 64;   // dwords of the staging region
 constexpr int FC_NSTAGE = 2;                     // at most two staged levels
 struct FcBox { int nvox, b, z0, y0, x0, by, bx, pad; };   // per (tile, staged level): 32 bytes, scalar loads
 #ifndef FC_DEPTH
-#define FC_DEPTH 1
+#define FC_DEPTH (FC_NPW == 8 ? 2 : 1)
 #endif
 #ifndef FC_PRIO
 #define FC_PRIO 0  // s_setprio of the producer waves (the second-dispatched half of the workgroup loses VALU arbitration by age)
@@ -263,10 +273,13 @@ __device__ __forceinline__ void produce_slab(const FcLevel L, const FcSlab S, ui
   const int col = jj * NC + c4;  // column inside the slab
   // row of pass `it` = RPW pw + g + it PPW: its swizzle bit (bit 3) is known at compile time when PPW <= 8 (g < PPW), else
   // (PPW = 16) it is bit 3 of g: at most one v_xor per pass
-  static_assert(RPW % 16 == 0 && (PPW == 4 || PPW == 8 || PPW == 16), "swizzle bit of the producer rows");
+  static_assert((RPW == 8 || RPW % 16 == 0) && (PPW == 4 || PPW == 8 || PPW == 16), "swizzle bit of the producer rows");
   // (FKSTEP, FLW and the pass stride are multiples of 8 dwords: bit 2 of the dword offset IS the slot bit, `^ 4` toggles it)
   static_assert(FKSTEP % 8 == 0 && FLW == 8, "slot bit of the producer's destination");
-  const int dsto = ((col >> 4) * FKSTEP + (RPW * pw + g) * FLW + ((col & 15) >> 1)) ^ (PPW == 16 ? ((g >> 3) & 1) * 4 : 0);
+  // RPW == 8: all rows of the wave share bit 3 (= bit 0 of pw)
+  const int dsto = ((col >> 4) * FKSTEP + (RPW * pw + g) * FLW + ((col & 15) >> 1)) ^
+                   (RPW == 8 ? (pw & 1) * 4 : (PPW == 16 ? ((g >> 3) & 1) * 4 : 0));
+  const bool own = PPW0 <= RPW || g < RPW;   // (a lane group beyond the wave's rows -- LP = 4 at RPW = 8 -- stores nothing)
   GLOBAL_AS char *featt = (GLOBAL_AS char *)(feat + m0 * row_stride);
   const uint32_t fo0 = (uint32_t)((RPW * pw + g) * row_stride + L.kcol + (S.j0 + jj) * C + S.c0 + c4) * 4u;
   const int live = M - m0 < FTM ? (int)(M - m0) : FTM;
@@ -335,7 +348,8 @@ __device__ __forceinline__ void produce_slab(const FcLevel L, const FcSlab S, ui
 #pragma unroll
       for (int k = 0; k < 8; ++k) acc = acc + I.v[k] * w[k];
     }
-    uint32_t *d = buf + (dsto ^ (PPW == 16 ? 0 : (((it * PPW) >> 3) & 1) * 4)) + it * (PPW * FLW);
+    uint32_t *d = buf + (dsto ^ ((PPW == 16 || RPW == 8) ? 0 : (((it * PPW) >> 3) & 1) * 4)) + it * (PPW * FLW);
+    if (!own) return;
     if constexpr (BF) {   // the feature values in bf16 (one rounding), one plane
       *reinterpret_cast<uint2 *>(d) = make_uint2(pack_bf16_rne(acc.x, acc.y), pack_bf16_rne(acc.z, acc.w));
       return;
@@ -356,7 +370,7 @@ __device__ __forceinline__ void produce_slab(const FcLevel L, const FcSlab S, ui
     }
     *reinterpret_cast<uint2 *>(d) = make_uint2(h0, h1);
     *reinterpret_cast<uint2 *>(d + FPLANE) = make_uint2(l0, l1);
-    if (S.keep && (PPW0 <= RPW || g < RPW) && RPW * pw + it * PPW + g < live)
+    if (S.keep && RPW * pw + it * PPW + g < live)
       *reinterpret_cast<GLOBAL_AS f32x4 *>(featt + (fo0 + (uint32_t)(it * PPW * row_stride * 4))) = acc;
   };
   Iter I[DEPTH];
@@ -377,11 +391,12 @@ __device__ __forceinline__ void produce_c1(const FcLevel L, const FcSlab S, uint
                                            float *__restrict__ feat, int row_stride, int tp) {
   const GLOBAL_AS float *vol = (const GLOBAL_AS float *)L.vol;
   const GLOBAL_AS uint16_t *vol16 = (const GLOBAL_AS uint16_t *)L.vol;
-  constexpr int C1R = FTM * 8 / 256;  // rounds of 256 (row, displacement) items
+  constexpr int C1R = FTM * 8 / NPT;  // rounds of NPT (row, displacement) items
+  static_assert(C1R >= 1 && FTM * 8 % NPT == 0, "C == 1 level: whole rounds of producer threads");
   float u[C1R][8], wk[C1R][8];
 #pragma unroll
   for (int r = 0; r < C1R; ++r) {
-    const int item = r * 256 + tp, row = item >> 3, j = item & 7;
+    const int item = r * NPT + tp, row = item >> 3, j = item & 7;
     const int64_t pn = min(m0 + row, M - 1);
     const uint32_t vb = (uint32_t)(pn / N) * (uint32_t)(L.D * L.H * L.W);
     const Corner c = sample_corner(points + pn * 3, j < 7 ? j : 0, disp, L.D, L.H, L.W, ac);
@@ -399,7 +414,7 @@ __device__ __forceinline__ void produce_c1(const FcLevel L, const FcSlab S, uint
   uint16_t *b16 = reinterpret_cast<uint16_t *>(buf);
 #pragma unroll
   for (int r = 0; r < C1R; ++r) {
-    const int item = r * 256 + tp, row = item >> 3, j = item & 7;
+    const int item = r * NPT + tp, row = item >> 3, j = item & 7;
     float acc = 0.f;
 #pragma unroll
     for (int k = 0; k < 8; ++k) acc = acc + u[r][k] * wk[r][k];
@@ -431,13 +446,14 @@ __device__ __forceinline__ void produce_c1(const FcLevel L, const FcSlab S, uint
 __device__ __forceinline__ void stage_box(const FcLevel L, int c0, const FcBox box, uint32_t *__restrict__ stage, int tp) {
   if (box.nvox == 0) return;   // (uniform) the tile keeps its global loads
   const GLOBAL_AS char *vol = (const GLOBAL_AS char *)L.vol;
-  constexpr int R = FC_STAGE_VOX * 16 / 256;
+  constexpr int R = FC_STAGE_VOX * 16 / NPT;
+  static_assert(FC_STAGE_VOX * 16 % NPT == 0, "staging rounds");
   const int n16 = box.nvox * 16, byx = box.by * box.bx;
   const float ibyx = 1.f / (float)byx, ibx = 1.f / (float)box.bx;
   f32x4 reg[R];
 #pragma unroll
   for (int i = 0; i < R; ++i) {
-    const int idx = min(tp + 256 * i, n16 - 1), v = idx >> 4, q = idx & 15;
+    const int idx = min(tp + NPT * i, n16 - 1), v = idx >> 4, q = idx & 15;
     const int vz = (int)(((float)v + 0.5f) * ibyx), r = v - vz * byx;   // exact for v, byx <= 160
     const int vy = (int)(((float)r + 0.5f) * ibx), vx = r - vy * box.bx;
     const uint32_t off = (uint32_t)((((box.b * L.D + box.z0 + vz) * L.H + box.y0 + vy) * L.W + box.x0 + vx) * L.C + c0 + q * 4) * 4u;
@@ -445,7 +461,7 @@ __device__ __forceinline__ void stage_box(const FcLevel L, int c0, const FcBox b
   }
 #pragma unroll
   for (int i = 0; i < R; ++i) {
-    const int idx = tp + 256 * i;
+    const int idx = tp + NPT * i;
     if (idx < n16) *reinterpret_cast<f32x4 *>(stage + idx * 4) = reg[i];   // [voxel][64 channels]: idx * 4 dwords
   }
 }
@@ -506,11 +522,32 @@ __global__ void args_store_kernel(FcArgs A, FcArgs *__restrict__ dst) {
 // DESIGN.md section 5b quotes the numbers).
 #ifdef SVR_FC0_MEASURE
 #define FC_DBG(x) (x)
+// In-kernel timeline (measurement builds only; MI355X_MICROARCH.md "In-kernel stamps"): lane 0 of every wave of the tiles
+// [FC_ST_TILE0, FC_ST_TILE0 + FC_ST_TILES) appends (event id << 56 | slab << 48 | s_memtime) to its own row of a buffer that
+// nothing else reads (svr_gather_fc0_stamps sets the pointer; tools/exp/fc0_timeline.py reads it back).
+__device__ unsigned long long *fc_stamps = nullptr;
+constexpr int FC_ST_TILE0 = 3000, FC_ST_TILES = 8, FC_ST_N = 1024;
+#define FC_STAMP_INIT()                                                                                          \
+  unsigned long long *st_p = nullptr;                                                                            \
+  int st_i = 0;                                                                                                  \
+  if (fc_stamps && tile >= FC_ST_TILE0 && tile < FC_ST_TILE0 + FC_ST_TILES && lane == 0)                        \
+    st_p = fc_stamps + ((tile - FC_ST_TILE0) * 8 + wave) * FC_ST_N;
+#define FC_STAMP(id, slab)                                                                                       \
+  do {                                                                                                           \
+    if (st_p && st_i < FC_ST_N)                                                                                  \
+      st_p[st_i++] = ((unsigned long long)(id) << 56) | ((unsigned long long)((slab) & 255) << 48) |             \
+                     (__builtin_amdgcn_s_memtime() & 0xffffffffffffull);                                         \
+  } while (0)
 #else
 #define FC_DBG(x) 0
+#define FC_STAMP_INIT()
+#define FC_STAMP(id, slab)
 #endif
 template <bool BF>
-__global__ __launch_bounds__(512, FTM == 64 ? 4 : 2) void gather_fc0_kernel(const FcArgs *__restrict__ Ap, const float *__restrict__ points,
+#ifndef FC_MINWAVES
+#define FC_MINWAVES (FC_NPW == 8 ? 3 : (FTM == 64 ? 4 : 2))
+#endif
+__global__ __launch_bounds__(NTHR, FC_MINWAVES) void gather_fc0_kernel(const FcArgs *__restrict__ Ap, const float *__restrict__ points,
                                                             const uint16_t *__restrict__ W0,
                                                             const uint32_t *__restrict__ amax, const float *__restrict__ bias,
                                                             float *__restrict__ Y, int64_t ldy, float *__restrict__ feat,
@@ -526,6 +563,11 @@ __global__ __launch_bounds__(512, FTM == 64 ? 4 : 2) void gather_fc0_kernel(cons
   if (m0 >= M) return;   // (whole workgroup, in front of the first barrier)
   const int S = A.n_slabs;
   if (dbg & 8) return;
+  FC_STAMP_INIT();
+  FC_STAMP(0, 0);
+#ifdef FC_NO_PRODUCER
+  if (wave >= 4) return;
+#endif
   if (wave >= 4) {
     // ------------------------------------------------------------------ producers
     const int pw = __builtin_amdgcn_readfirstlane(wave) - 4;   // (uniform: everything derived from it is scalar arithmetic)
@@ -550,13 +592,19 @@ __global__ __launch_bounds__(512, FTM == 64 ? 4 : 2) void gather_fc0_kernel(cons
       int lane_s = lane;
       int rowb_s = rowb;
       asm volatile("" : "+v"(lane_s), "+v"(rowb_s));   // (rowb too: the point address derived from it was hoisted and spilled)
+      FC_STAMP(1, s + 1);
       if (s + 1 < S && !(dbg & 1))
         produce<BF>(A, s + 1, lds + ((s + 1) & 1) * FSLAB, points, m0, M, N, disp, ac, feat, row_stride, pw, lane_s, dbg, lds + 2 * FSLAB,
                     boxes + tile * FC_NSTAGE, G, rowb_s);
+      FC_STAMP(2, s + 1);
       slab_barrier();
+      FC_STAMP(3, s + 1);
     }
     return;
   }
+#ifdef FC_NO_CONSUMER   // (register-count experiments: what do the producers need on their own?)
+  return;
+#endif
   // -------------------------------------------------------------------- consumers: wave wc -> columns [64 wc, 64 wc + 64)
   const int wc = wave, l31 = lane & 31, lh = lane >> 5;
   const int KF = A.KF, nk = KF / FK;
@@ -579,7 +627,7 @@ __global__ __launch_bounds__(512, FTM == 64 ? 4 : 2) void gather_fc0_kernel(cons
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  constexpr int BDIST = FTM == 64 ? 1 : 3;  // k-steps the W loads run ahead (2 or 4 register sets)
+  constexpr int BDIST = (FTM == 64 && NPW == 4) ? 1 : 3;  // k-steps the W loads run ahead (2 or 4 register sets)
   loadb(b0, 0);
   if constexpr (BDIST == 3) {
     loadb(b1, 1);
@@ -604,6 +652,7 @@ __global__ __launch_bounds__(512, FTM == 64 ? 4 : 2) void gather_fc0_kernel(cons
   asm volatile("" : "+s"(mma_on));
   // k-step kidx on the fragments `cur`; `fre` (used one step ago) is refilled with step kidx + 3
   auto step = [&](const uint4 (&cur)[2][2], uint4 (&fre)[2][2]) {
+    FC_STAMP(20, s);
     if (mma_on) {
       loadb(fre, kidx + BDIST);
       const uint32_t *pa = lds + (s & 1) * FSLAB + kin * FKSTEP;
@@ -644,7 +693,9 @@ __global__ __launch_bounds__(512, FTM == 64 ? 4 : 2) void gather_fc0_kernel(cons
     }
     ++kidx;
     if (++kin == ksl) {  // slab consumed: hand the buffer back, the next one is ready behind the barrier
+      FC_STAMP(21, s);
       slab_barrier();
+      FC_STAMP(22, s);
       ++s;
       kin = 0;
       ksl = s < S ? A.S[s].nk : 0;
@@ -666,6 +717,7 @@ __global__ __launch_bounds__(512, FTM == 64 ? 4 : 2) void gather_fc0_kernel(cons
       step(b1, b0);
     }
   }
+  FC_STAMP(23, s);
   if (dbg & 4) return;
   const float inv = BF ? 1.f : w_scale(amax[0], true);
 #pragma unroll
@@ -685,6 +737,7 @@ __global__ __launch_bounds__(512, FTM == 64 ? 4 : 2) void gather_fc0_kernel(cons
         }
       }
     }
+  FC_STAMP(24, s);
 }
 
 // Bounding box of the clamped corner coordinates (the ones produce_slab reads) of a tile's 64 points x 7 displacements at
@@ -944,7 +997,7 @@ extern "C" int svr_gather_fc0_run(const svr_gather_desc *d, const float *points,
   // SVR_FC0_XCD=1: tiles contiguous per XCD (Morton neighbours share an L2) instead of dealt round-robin over the eight
   static const int xcd = (getenv("SVR_FC0_XCD") && getenv("SVR_FC0_XCD")[0] == '1') ? 1 : 0;
   const unsigned grid = xcd ? xcd_grid(cdiv(M, FTM)) : (unsigned)cdiv(M, FTM);
-  hipLaunchKernelGGL(gather_fc0_kernel<false>, dim3(grid), dim3(512), FC_LDS_BYTES, (hipStream_t)stream, ws.Ad, points,
+  hipLaunchKernelGGL(gather_fc0_kernel<false>, dim3(grid), dim3(NTHR), FC_LDS_BYTES, (hipStream_t)stream, ws.Ad, points,
                      ws.p0, ws.amax, eb, Y, ldy, feat, (int)ldf, keep_levels ? (int)pad_start : -1, M, d->N, d->displacement,
                      d->align_corners, relu, dbg, ws.boxes, xcd);
   return launch_status("gather_fc0_run");
@@ -957,6 +1010,14 @@ extern "C" int svr_gather_fc0_fwd(const svr_gather_desc *d, const float *points,
   if (rc != SVR_OK) return rc;
   return svr_gather_fc0_run(d, points, bias, Y, ldy, n_out, feat, ldf, keep_cols, keep_levels, epilogue, workspace, stream);
 }
+
+#ifdef SVR_FC0_MEASURE
+// measurement builds only (not declared in include/svr_hip.h): buffer of FC_ST_TILES * 8 * FC_ST_N u64 for the in-kernel timeline
+extern "C" int svr_gather_fc0_stamps(void *buf) {
+  unsigned long long *p = (unsigned long long *)buf;
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(fc_stamps), &p, sizeof(p));
+}
+#endif
 
 // ------------------------------------------------------------------------------------------------------------------
 // bf16-storage variant (see the file header): levels' `vol` pointers are bf16 volumes, W is given in f32 and rounded to
@@ -999,7 +1060,7 @@ extern "C" int svr_gather_fc0_bf16_run(const svr_gather_desc *d, const float *po
             hipGetErrorString(lds_attr));
   const float *eb = epilogue == SVR_EPI_NONE ? nullptr : bias;
   const int relu = epilogue == SVR_EPI_BIAS_RELU ? 1 : 0;
-  hipLaunchKernelGGL(gather_fc0_kernel<true>, dim3((unsigned)cdiv(M, FTM)), dim3(512), FC_LDS_BYTES, (hipStream_t)stream, ws.Ad, points,
+  hipLaunchKernelGGL(gather_fc0_kernel<true>, dim3((unsigned)cdiv(M, FTM)), dim3(NTHR), FC_LDS_BYTES, (hipStream_t)stream, ws.Ad, points,
                      ws.p0, ws.amax, eb, reinterpret_cast<float *>(Y), ldy, (float *)nullptr, 0, -1, M, d->N, d->displacement,
                      d->align_corners, relu, 0, (const FcBox *)nullptr, 0);
   return launch_status("gather_fc0_bf16_run");
