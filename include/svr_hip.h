@@ -285,6 +285,27 @@ int svr_linear_bwd_weight_bf16x3(const float *dY, int64_t lddy, const float *X, 
                                  int64_t lddw, float *db, int64_t M, int64_t N, int64_t K,
                                  void *workspace, void *stream);
 
+/* The same two backward products at f32 LEVEL on the f16 matrix cores ("f16x3s": the scaled 3-product f16 split).  The
+ * reference computes its backward in fp32 (util/arguments.py:30, precision 32); bf16x3 above carries 16 mantissa bits per
+ * operand, this carries 22 -- at the same three matrix instructions per block.  f16 has 5 exponent bits, so a gradient
+ * operand is first multiplied by an exact power of two that brings its |max| into [2^13, 2^14):
+ *   svr_amax_f32: amax[0] = bit pattern of max |X[m][n]| (one pass; N, ld multiples of 4, rows 16-byte aligned), or the
+ *   amax_dx output of svr_linear_bwd_data_f16x3 (|max| of the dX it stored: the next layer's dY needs no extra pass).
+ * amax_dy == NULL: no scaling (values must then lie in f16's range).  The weight operand is normalised the same way when
+ * its planes are prepared (PREPARE / RUN as above: dY NULL = prepare from W, W NULL = run); the activation operand X of
+ * the weight gradient is taken as it is (|x| < 65504; below |x| ~ 0.1 its correction term has an absolute error floor of
+ * 3e-8 |dY|).  Errors against f64: ~3e-7 (the exact-f32 kernels' own level), bf16x3: ~1e-5.                              */
+int svr_amax_f32(const float *X, int64_t ld, int64_t M, int64_t N, uint32_t *amax, void *stream);
+int64_t svr_linear_bwd_data_f16x3_workspace(int64_t N, int64_t K);
+int svr_linear_bwd_data_f16x3(const float *dY, int64_t lddy, const float *W, int64_t ldw, float *dX,
+                              int64_t lddx, int64_t M, int64_t N, int64_t K, int epilogue,
+                              const float *mask, int64_t ldmask, const uint32_t *amax_dy, uint32_t *amax_dx,
+                              void *workspace, void *stream);
+int64_t svr_linear_bwd_weight_f16x3_workspace(int64_t M, int64_t N, int64_t K);
+int svr_linear_bwd_weight_f16x3(const float *dY, int64_t lddy, const float *X, int64_t ldx, float *dW,
+                                int64_t lddw, float *db, int64_t M, int64_t N, int64_t K,
+                                const uint32_t *amax_dy, void *workspace, void *stream);
+
 /* fc_out (Conv1d(hidden,1,1), model/ifnet.py:35,58-59): logits[r(m)] = H[m,:].w + b, where
  * r(m) = row_map[m] if row_map != NULL (rows were processed in Morton order: scatter the logits back
  * to the caller's point order) else m.                                                            */

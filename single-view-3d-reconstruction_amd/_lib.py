@@ -82,6 +82,11 @@ SIGNATURES = {
     "svr_linear_bwd_data_bf16x3": (C.c_int, [P, I64, P, I64, P, I64, I64, I64, I64, C.c_int, P, I64, P, P]),
     "svr_linear_bwd_weight_bf16x3_workspace": (I64, [I64, I64, I64]),
     "svr_linear_bwd_weight_bf16x3": (C.c_int, [P, I64, P, I64, P, I64, P, I64, I64, I64, P, P]),
+    "svr_amax_f32": (C.c_int, [P, I64, I64, I64, P, P]),
+    "svr_linear_bwd_data_f16x3_workspace": (I64, [I64, I64]),
+    "svr_linear_bwd_data_f16x3": (C.c_int, [P, I64, P, I64, P, I64, I64, I64, I64, C.c_int, P, I64, P, P, P, P]),
+    "svr_linear_bwd_weight_f16x3_workspace": (I64, [I64, I64, I64]),
+    "svr_linear_bwd_weight_f16x3": (C.c_int, [P, I64, P, I64, P, I64, P, I64, I64, I64, P, P, P]),
     "svr_fc_out_fwd": (C.c_int, [P, I64, P, P, P, P, I64, I64, P]),
     "svr_fc_out_bwd_workspace": (I64, [I64, I64]),
     "svr_fc_out_bwd": (C.c_int, [P, I64, P, P, P, P, I64, P, P, I64, I64, P, P]),

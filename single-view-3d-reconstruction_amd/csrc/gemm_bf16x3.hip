@@ -18,6 +18,7 @@
 // so the fragment reads (ds_read_b128, lane <-> row) and the transposing stores (ds_write_b128) are conflict free.
 // Tiles that share an operand panel are dispatched to one XCD (common.h: xcd_logical).
 #include "common.h"
+#include "f16x3.h"
 
 using namespace svr;
 
@@ -402,12 +403,17 @@ __device__ __forceinline__ bf16x8 tr_frag(const uint32_t *plane, int byte0, int 
 // ahead, 246 VGPRs) 2.57 vs 2.51, three sets spill (10.8 ms).  Neither the barrier count nor the load latency binds
 // this kernel; per k-step a wave issues ~110 VALU instructions for the bf16 splits and 16 ds_write_b64 against 24 MFMAs
 // (768 cycles), and the LDS pipe of a CU is ~80 % busy relative to its matrix pipes.  SVR_TN_STAGES=2 selects it.
-template <int STAGES>
+// F16 ("f16x3s", svr_linear_bwd_weight_f16x3): the scaled f16 split instead of the bf16 one -- dY is multiplied by 2^s (amax_dy:
+// its |max| brought to [2^13, 2^14), exact), both operands split into hi = rn16(v) and lo' = rn16((v - hi) 2^11), products
+// hi hi + (hi 2^-11) lo' + lo' (hi 2^-11) with the 2^-11 applied to the hi FRAGMENTS in registers (v_pk_mul_f16), result * 2^-s:
+// 22 mantissa bits per operand instead of 16, the same three matrix instructions per block.  X (activations) is not scaled:
+// |x| < 65504, and below |x| ~ 0.1 the correction term carries an absolute error floor of 3e-8 |dY| (gemm_f16x3.hip).
+template <int STAGES, bool F16 = false>
 __global__ __launch_bounds__(256, 2) void linear_tn_x3_tr_kernel(const float *__restrict__ dY, int64_t lddy,
                                                               const float *__restrict__ X, int64_t ldx,
                                                               float *__restrict__ slab, float *__restrict__ dbpart,
                                                               int64_t M, int64_t N, int64_t K, int64_t rows_per_split,
-                                                              int splits) {
+                                                              int splits, const uint32_t *__restrict__ amax_dy) {
   __shared__ __attribute__((aligned(16))) uint32_t lds[STAGES * 4 * TR_XPLANE];  // per stage: dY hi, dY mid, X hi, X mid: [32 m][128 cols]
   uint32_t *la = lds, *lx = lds + 2 * TR_XPLANE;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -433,6 +439,8 @@ __global__ __launch_bounds__(256, 2) void linear_tn_x3_tr_kernel(const float *__
   };
   const bool want_db = dbpart != nullptr && j0 == 0;
   float4 dbs = make_float4(0.f, 0.f, 0.f, 0.f);
+  float sy = 1.f;
+  if constexpr (F16) sy = amax_dy ? w_scale(amax_dy[0], false) : 1.f;
   auto lstore = [&](int64_t k0, int stage) {
     uint32_t *la = lds + stage * 4 * TR_XPLANE, *lx = la + 2 * TR_XPLANE;
 #pragma unroll
@@ -443,12 +451,22 @@ __global__ __launch_bounds__(256, 2) void linear_tn_x3_tr_kernel(const float *__
       const float4 a = ok ? av[i] : make_float4(0.f, 0.f, 0.f, 0.f), x = ok ? xv[i] : make_float4(0.f, 0.f, 0.f, 0.f);
       if (want_db) { dbs.x += a.x; dbs.y += a.y; dbs.z += a.z; dbs.w += a.w; }
       uint32_t h0, m0, h1, m1;
-      split2(a.x, a.y, h0, m0);
-      split2(a.z, a.w, h1, m1);
+      if constexpr (F16) {
+        split_x(a.x * sy, a.y * sy, h0, m0);
+        split_x(a.z * sy, a.w * sy, h1, m1);
+      } else {
+        split2(a.x, a.y, h0, m0);
+        split2(a.z, a.w, h1, m1);
+      }
       *reinterpret_cast<uint2 *>(la + off) = make_uint2(h0, h1);
       *reinterpret_cast<uint2 *>(la + TR_XPLANE + off) = make_uint2(m0, m1);
-      split2(x.x, x.y, h0, m0);
-      split2(x.z, x.w, h1, m1);
+      if constexpr (F16) {
+        split_x(x.x, x.y, h0, m0);
+        split_x(x.z, x.w, h1, m1);
+      } else {
+        split2(x.x, x.y, h0, m0);
+        split2(x.z, x.w, h1, m1);
+      }
       *reinterpret_cast<uint2 *>(lx + off) = make_uint2(h0, h1);
       *reinterpret_cast<uint2 *>(lx + TR_XPLANE + off) = make_uint2(m0, m1);
     }
@@ -486,6 +504,26 @@ __global__ __launch_bounds__(256, 2) void linear_tn_x3_tr_kernel(const float *__
         bh[j] = tr_frag(lx, boff[ks][j][0], boff[ks][j][1]);
         bm[j] = tr_frag(lx + TR_XPLANE, boff[ks][j][0], boff[ks][j][1]);
       }
+      if constexpr (F16) {   // the same 16-bit lanes read as halves
+        f16x8 fah[2], fam[2], fbh[2], fbm[2], fahs[2], fbhs[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          fah[j] = __builtin_bit_cast(f16x8, ah[j]);
+          fam[j] = __builtin_bit_cast(f16x8, am[j]);
+          fbh[j] = __builtin_bit_cast(f16x8, bh[j]);
+          fbm[j] = __builtin_bit_cast(f16x8, bm[j]);
+          fahs[j] = scale_2m11(fah[j]);
+          fbhs[j] = scale_2m11(fbh[j]);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fam[i], fbhs[j], acc[i][j], 0, 0, 0);   // lo'(dY) hi(x) 2^-11
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fahs[i], fbm[j], acc[i][j], 0, 0, 0);   // hi(dY) 2^-11 lo'(x)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[i], fbh[j], acc[i][j], 0, 0, 0);
+          }
+      } else {
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -494,6 +532,7 @@ __global__ __launch_bounds__(256, 2) void linear_tn_x3_tr_kernel(const float *__
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bm[j], acc[i][j], 0, 0, 0);
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
         }
+      }
     }
   };
   if (kbeg < kend) {
@@ -523,9 +562,11 @@ __global__ __launch_bounds__(256, 2) void linear_tn_x3_tr_kernel(const float *__
     }
   }
   float *out = slab + split * N * K;
+  float inv = 1.f;
+  if constexpr (F16) inv = amax_dy ? w_scale(amax_dy[0], true) : 1.f;
   foreach_acc<2, 2>(acc, [&](int row, int col, float v) {
     int64_t i = i0 + row, j = j0 + col;
-    if (i < N && j < K) out[i * K + j] = v;
+    if (i < N && j < K) out[i * K + j] = F16 ? v * inv : v;
   });
   if (want_db) {  // fixed-order sum over the 8 row groups that share a column quad
     float *red = reinterpret_cast<float *>(lds);
@@ -705,10 +746,10 @@ extern "C" int svr_linear_bwd_weight_bf16x3(const float *dY, int64_t lddy, const
     static const int tr_stages = getenv("SVR_TN_STAGES") ? atoi(getenv("SVR_TN_STAGES")) : 1;   // measurement switch
     if (tr_stages == 2)
       hipLaunchKernelGGL(linear_tn_x3_tr_kernel<2>, grid, dim3(256), 0, s, dY, lddy, X, ldx, slab, db ? dbpart : nullptr, M, N, K,
-                         rps, splits);
+                         rps, splits, (const uint32_t *)nullptr);
     else
       hipLaunchKernelGGL(linear_tn_x3_tr_kernel<1>, grid, dim3(256), 0, s, dY, lddy, X, ldx, slab, db ? dbpart : nullptr, M, N, K,
-                         rps, splits);
+                         rps, splits, (const uint32_t *)nullptr);
     hipLaunchKernelGGL(slab_reduce_x3_kernel, dim3((unsigned)cdiv(N * K, 64)), dim3(256), 0, s, slab, dW, N, K, lddw, splits);
     if (db) hipLaunchKernelGGL(dy_db_reduce_kernel, dim3((unsigned)N), dim3(256), 0, s, dbpart, db, N, (int64_t)splits);
     return launch_status("linear_bwd_weight_bf16x3");
@@ -718,4 +759,32 @@ extern "C" int svr_linear_bwd_weight_bf16x3(const float *dY, int64_t lddy, const
   hipLaunchKernelGGL(slab_reduce_x3_kernel, dim3((unsigned)cdiv(N * K, 64)), dim3(256), 0, s, slab, dW, N, K, lddw, splits);
   if (db) hipLaunchKernelGGL(dy_db_reduce_kernel, dim3((unsigned)N), dim3(256), 0, s, dbpart, db, N, parts);
   return launch_status("linear_bwd_weight_bf16x3");
+}
+
+// ---- dW on the scaled f16 split ("f16x3s"): f32-level at the bf16x3 kernel's cost; same workspace layout ---------------------
+extern "C" int64_t svr_linear_bwd_weight_f16x3_workspace(int64_t M, int64_t N, int64_t K) {
+  return svr_linear_bwd_weight_bf16x3_workspace(M, N, K);
+}
+
+extern "C" int svr_linear_bwd_weight_f16x3(const float *dY, int64_t lddy, const float *X, int64_t ldx, float *dW, int64_t lddw,
+                                           float *db, int64_t M, int64_t N, int64_t K, const uint32_t *amax_dy, void *workspace,
+                                           void *stream) {
+  SVR_CHECK(dY && X && dW && workspace, SVR_E_BADARG, "linear_bwd_weight_f16x3: null pointer");
+  SVR_CHECK(M > 0 && N >= 4 && K >= 4 && N % 4 == 0 && K % 4 == 0, SVR_E_BADSHAPE, "linear_bwd_weight_f16x3: M=%ld N=%ld K=%ld (N, K %% 4)", (long)M, (long)N, (long)K);
+  SVR_CHECK(lddy % 4 == 0 && ((uintptr_t)dY & 15) == 0 && ldx % 4 == 0 && ((uintptr_t)X & 15) == 0, SVR_E_ALIGN,
+            "linear_bwd_weight_f16x3: dY and X must be 16-byte aligned with leading dimensions that are multiples of 4");
+  hipStream_t s = (hipStream_t)stream;
+  int64_t rps;
+  int splits = tn_splits(M, N, K, &rps);
+  const int64_t Mpad = tn_mpad(M);
+  char *w = (char *)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+  float *slab = (float *)w;
+  w += align256b((int64_t)splits * N * K * 4) + 2 * align256b(N * Mpad * 2);
+  float *dbpart = (float *)w;
+  dim3 grid(xcd_grid(cdiv(K, TN_TN) * cdiv(N, TN_TM) * splits));
+  hipLaunchKernelGGL((linear_tn_x3_tr_kernel<1, true>), grid, dim3(256), 0, s, dY, lddy, X, ldx, slab, db ? dbpart : nullptr, M, N, K,
+                     rps, splits, amax_dy);
+  hipLaunchKernelGGL(slab_reduce_x3_kernel, dim3((unsigned)cdiv(N * K, 64)), dim3(256), 0, s, slab, dW, N, K, lddw, splits);
+  if (db) hipLaunchKernelGGL(dy_db_reduce_kernel, dim3((unsigned)N), dim3(256), 0, s, dbpart, db, N, (int64_t)splits);
+  return launch_status("linear_bwd_weight_f16x3");
 }

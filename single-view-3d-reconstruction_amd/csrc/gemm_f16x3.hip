@@ -55,13 +55,14 @@ __device__ __forceinline__ f16x8 read_frag(const uint32_t *plane, int row, int l
 __device__ __forceinline__ int64_t wplane_index(int64_t k, int plane, int64_t n, int64_t N) {
   return (((k >> 4) * 2 + plane) * N + n) * 16 + (k & 15);
 }
+// transposed: plane row n / reduction index k are W's COLUMN / ROW (the weight operand of dX = dY W: rows = dX columns)
 __global__ void split_w_kernel(const float *__restrict__ W, int64_t ldw, const uint32_t *__restrict__ amax,
-                               uint16_t *__restrict__ p0, int64_t N, int64_t K) {
+                               uint16_t *__restrict__ p0, int64_t N, int64_t K, int transposed) {
   int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // over (n, k/2)
   if (idx >= N * (K / 2)) return;
   const int64_t n = idx / (K / 2), k = (idx % (K / 2)) * 2;
   const float sc = w_scale(amax[0], false);
-  const float w0 = W[n * ldw + k] * sc, w1 = W[n * ldw + k + 1] * sc;
+  const float w0 = (transposed ? W[k * ldw + n] : W[n * ldw + k]) * sc, w1 = (transposed ? W[(k + 1) * ldw + n] : W[n * ldw + k + 1]) * sc;
   const uint32_t hi = pack_f16(w0, w1);
   const f32x2 h = unpack_f16(hi);
   *reinterpret_cast<uint32_t *>(p0 + wplane_index(k, 0, n, N)) = hi;
@@ -76,11 +77,16 @@ __global__ void split_w_kernel(const float *__restrict__ W, int64_t ldw, const u
 // add up).  The k-step is therefore software pipelined INSIDE the wave: two LDS stages and two register sets, so
 // that the split + LDS stores of step k+1 and the global loads of step k+2 sit in the same barrier-free region
 // as the MFMAs of step k and can be issued between them (MFMA co-execution); one barrier per step.
-template <int TN, int NX, int SCHED>
+// BWD: the same kernel as the data-gradient GEMM dX = dY W of the scaled f16 split ("f16x3s", svr_linear_bwd_data_f16x3):
+// X = dY, the planes hold W TRANSPOSED; dY is multiplied by 2^sx (amax_x: its |max| brought to [2^13, 2^14), exact) on the
+// way into the split so that gradients of any magnitude sit in f16's normal range, the epilogue multiplies by 2^-(s + sx),
+// applies the ReLU mask of the layer below and (amax_y) leaves |max| of what it stored for the next layer's scale.
+template <int TN, int NX, int SCHED, bool BWD = false>
 __global__ __launch_bounds__(2 * TN, 1024 / (2 * TN) >= 4 ? 3 : 2) void linear_nt_h3_kernel(
     const float *__restrict__ X, int64_t ldx, const uint16_t *__restrict__ W0,
     const uint32_t *__restrict__ amax, const float *__restrict__ bias, float *__restrict__ Y, int64_t ldy, int64_t M,
-    int64_t N, int64_t K, int relu) {
+    int64_t N, int64_t K, int relu, const uint32_t *__restrict__ amax_x, const float *__restrict__ mask, int64_t ldm,
+    uint32_t *__restrict__ amax_y) {
   constexpr int NT = 2 * TN, BPLANE = TN * YLW, XPT = 512 / NT, STAGE = 2 * APLANE + 2 * BPLANE;
   __shared__ __attribute__((aligned(16))) uint32_t lds[2 * STAGE];  // two stages of (hi/lo planes of X and W)
   const int t = threadIdx.x;
@@ -109,6 +115,8 @@ __global__ __launch_bounds__(2 * TN, 1024 / (2 * TN) >= 4 ? 3 : 2) void linear_n
   };
   Regs ra, rb;
   const int64_t klast = K - YK;
+  float sx = 1.f;
+  if constexpr (BWD) sx = amax_x ? w_scale(amax_x[0], false) : 1.f;
   auto load = [&](Regs &r, int64_t k0) {
     k0 = k0 < klast ? k0 : klast;  // past the end: re-read the last step (never used), keeps the loop branch free
 #pragma unroll
@@ -129,8 +137,13 @@ __global__ __launch_bounds__(2 * TN, 1024 / (2 * TN) >= 4 ? 3 : 2) void linear_n
 #pragma unroll
     for (int i = 0; i < XPT; ++i) {
       uint32_t h0, l0, h1, l1;
-      split_x(r.x[i].x, r.x[i].y, h0, l0);
-      split_x(r.x[i].z, r.x[i].w, h1, l1);
+      if constexpr (BWD) {
+        split_x(r.x[i].x * sx, r.x[i].y * sx, h0, l0);
+        split_x(r.x[i].z * sx, r.x[i].w * sx, h1, l1);
+      } else {
+        split_x(r.x[i].x, r.x[i].y, h0, l0);
+        split_x(r.x[i].z, r.x[i].w, h1, l1);
+      }
       const int off = slot_dw((t >> 2) + (NT / 4) * i, (t & 3) >> 1) + (t & 1) * 2;   // 4 halves = half a slot
       *reinterpret_cast<uint2 *>(st + off) = make_uint2(h0, h1);
       *reinterpret_cast<uint2 *>(st + APLANE + off) = make_uint2(l0, l1);
@@ -195,7 +208,9 @@ __global__ __launch_bounds__(2 * TN, 1024 / (2 * TN) >= 4 ? 3 : 2) void linear_n
     if (k0 + YK < K) step(k0 + YK, 1, ra, rb);
   }
 
-  const float inv = w_scale(amax[0], true);
+  float inv = w_scale(amax[0], true);
+  if constexpr (BWD) inv *= amax_x ? w_scale(amax_x[0], true) : 1.f;
+  float vmax = 0.f;
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -208,10 +223,36 @@ __global__ __launch_bounds__(2 * TN, 1024 / (2 * TN) >= 4 ? 3 : 2) void linear_n
         if (m < M && n < N) {
           float v = acc[i][j][r] * inv + bv;
           if (relu) v = fmaxf(v, 0.f);
+          if constexpr (BWD) {
+            if (mask) v = mask[m * ldm + n] > 0.f ? v : 0.f;
+            vmax = fmaxf(vmax, fabsf(v));
+          }
           Y[m * ldy + n] = v;
         }
       }
     }
+  if constexpr (BWD) {
+    if (amax_y) {   // |max| of this workgroup's part of dX (non-negative floats order like unsigned integers)
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));
+      if (lane == 0 && vmax > 0.f) atomicMax(amax_y, __float_as_uint(vmax));
+    }
+  }
+}
+
+// |max| of an (M, N) f32 matrix (leading dimension ld, N % 4 == 0, 16-byte aligned rows) -> bit pattern in amax[0] (zeroed by
+// the host first): the scale of a gradient operand of the scaled f16 split
+__global__ __launch_bounds__(256) void amax_rows_kernel(const float *__restrict__ X, int64_t ld, int64_t M, int64_t N,
+                                                        uint32_t *__restrict__ amax) {
+  const int64_t q = N / 4, total = M * q;
+  float m = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const float4 v = *reinterpret_cast<const float4 *>(X + (i / q) * ld + (i % q) * 4);
+    m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(amax, __float_as_uint(m));
 }
 
 }  // namespace
@@ -231,7 +272,7 @@ extern "C" int svr_linear_fwd_f16x3(const float *X, int64_t ldx, const float *W,
   if (W) {
     (void)hipMemsetAsync(amax, 0, sizeof(uint32_t), s);
     hipLaunchKernelGGL(w_amax_kernel, dim3((unsigned)std::min<int64_t>(cdiv(N * K, 1024), 1024)), dim3(256), 0, s, W, ldw, N, K, amax);
-    hipLaunchKernelGGL(split_w_kernel, dim3((unsigned)cdiv(N * (K / 2), 256)), dim3(256), 0, s, W, ldw, amax, p0, N, K);
+    hipLaunchKernelGGL(split_w_kernel, dim3((unsigned)cdiv(N * (K / 2), 256)), dim3(256), 0, s, W, ldw, amax, p0, N, K, 0);
   }
   if (!X) return launch_status("linear_fwd_f16x3 (prepare)");
   SVR_CHECK(ldx % 4 == 0 && ((uintptr_t)X & 15) == 0, SVR_E_ALIGN, "linear_fwd_f16x3: X must be 16-byte aligned");
@@ -243,10 +284,51 @@ extern "C" int svr_linear_fwd_f16x3(const float *X, int64_t ldx, const float *W,
   // the compiler's own order and 2.50 for iglp_opt(0)
   if (N <= 64) {  // narrow outputs (the UNet's 32- and 64-channel layers): 128 x 64 tiles, two waves, half the wasted columns
     dim3 grid(xcd_grid(cdiv(N, 64) * cdiv(M, TM)));
-    hipLaunchKernelGGL((linear_nt_h3_kernel<64, 0, 2>), grid, dim3(128), 0, s, X, ldx, p0, amax, eb, Y, ldy, M, N, K, relu);
+    hipLaunchKernelGGL((linear_nt_h3_kernel<64, 0, 2>), grid, dim3(128), 0, s, X, ldx, p0, amax, eb, Y, ldy, M, N, K, relu,
+                       (const uint32_t *)nullptr, (const float *)nullptr, (int64_t)0, (uint32_t *)nullptr);
     return launch_status("linear_fwd_f16x3");
   }
   dim3 grid(xcd_grid(cdiv(N, 128) * cdiv(M, TM)));
-  hipLaunchKernelGGL((linear_nt_h3_kernel<128, 0, 2>), grid, dim3(256), 0, s, X, ldx, p0, amax, eb, Y, ldy, M, N, K, relu);
+  hipLaunchKernelGGL((linear_nt_h3_kernel<128, 0, 2>), grid, dim3(256), 0, s, X, ldx, p0, amax, eb, Y, ldy, M, N, K, relu,
+                     (const uint32_t *)nullptr, (const float *)nullptr, (int64_t)0, (uint32_t *)nullptr);
   return launch_status("linear_fwd_f16x3");
+}
+
+// ---- scaled f16 split for the BACKWARD products ("f16x3s"): f32-level gradients at the cost of the bf16x3 split -------------
+extern "C" int svr_amax_f32(const float *X, int64_t ld, int64_t M, int64_t N, uint32_t *amax, void *stream) {
+  SVR_CHECK(amax, SVR_E_BADARG, "amax_f32: null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  (void)hipMemsetAsync(amax, 0, sizeof(uint32_t), s);
+  if (M * N == 0) return SVR_OK;
+  SVR_CHECK(X && N % 4 == 0 && ld % 4 == 0 && ((uintptr_t)X & 15) == 0, SVR_E_ALIGN, "amax_f32: N, ld multiples of 4, 16-byte aligned");
+  hipLaunchKernelGGL(amax_rows_kernel, dim3((unsigned)std::min<int64_t>(cdiv(M * (N / 4), 1024), 2048)), dim3(256), 0, s, X, ld, M, N, amax);
+  return launch_status("amax_f32");
+}
+
+extern "C" int64_t svr_linear_bwd_data_f16x3_workspace(int64_t N, int64_t K) { return 2 * N * K * (int64_t)sizeof(uint16_t) + 512; }
+
+extern "C" int svr_linear_bwd_data_f16x3(const float *dY, int64_t lddy, const float *W, int64_t ldw, float *dX, int64_t lddx,
+                                         int64_t M, int64_t N, int64_t K, int epilogue, const float *mask, int64_t ldmask,
+                                         const uint32_t *amax_dy, uint32_t *amax_dx, void *workspace, void *stream) {
+  // dY == NULL: PREPARE only (W -> scale + split TRANSPOSED planes in the workspace);  W == NULL: RUN on a prepared workspace
+  if (M == 0 && dY) return SVR_OK;
+  SVR_CHECK((dY || W) && (!dY || dX) && workspace, SVR_E_BADARG, "linear_bwd_data_f16x3: null pointer");
+  SVR_CHECK(M >= 0 && N > 0 && K > 0 && N % YK == 0, SVR_E_BADSHAPE, "linear_bwd_data_f16x3: M=%ld N=%ld K=%ld (N %% 16)", (long)M, (long)N, (long)K);
+  hipStream_t s = (hipStream_t)stream;
+  uint32_t *amax = (uint32_t *)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+  uint16_t *p0 = (uint16_t *)(amax + 64);
+  if (W) {   // planes of W^T: K rows (dX columns) x N reduction elements
+    (void)hipMemsetAsync(amax, 0, sizeof(uint32_t), s);
+    hipLaunchKernelGGL(w_amax_kernel, dim3((unsigned)std::min<int64_t>(cdiv(N * K, 1024), 1024)), dim3(256), 0, s, W, ldw, N, K, amax);
+    hipLaunchKernelGGL(split_w_kernel, dim3((unsigned)cdiv(K * (N / 2), 256)), dim3(256), 0, s, W, ldw, amax, p0, K, N, 1);
+  }
+  if (!dY) return launch_status("linear_bwd_data_f16x3 (prepare)");
+  SVR_CHECK(lddy % 4 == 0 && ((uintptr_t)dY & 15) == 0, SVR_E_ALIGN, "linear_bwd_data_f16x3: dY must be 16-byte aligned");
+  SVR_CHECK(epilogue == SVR_EPI_NONE || (epilogue == SVR_EPI_MASK && mask), SVR_E_BADARG, "linear_bwd_data_f16x3: epilogue %d", epilogue);
+  if (amax_dx) (void)hipMemsetAsync(amax_dx, 0, sizeof(uint32_t), s);
+  const float *mk = epilogue == SVR_EPI_MASK ? mask : nullptr;
+  dim3 grid(xcd_grid(cdiv(K, 128) * cdiv(M, TM)));
+  hipLaunchKernelGGL((linear_nt_h3_kernel<128, 0, 2, true>), grid, dim3(256), 0, s, dY, lddy, p0, amax, (const float *)nullptr, dX, lddx,
+                     M, K, N, 0, amax_dy, mk, ldmask, amax_dx);
+  return launch_status("linear_bwd_data_f16x3");
 }

@@ -1,6 +1,7 @@
 """Thin tensor-level wrappers over the C ABI: check device/dtype/contiguity, pass raw device
 pointers and the current HIP stream.  torch is used for memory and streams only."""
 import ctypes as C
+import os
 
 import torch
 
@@ -595,6 +596,11 @@ class PreparedWeights:
             check(l.svr_linear_bwd_data_bf16x3(z, 0, C.c_void_p(w.data_ptr()), w.stride(0), z, 0, 0, N, K, EPI_NONE, z, 0, _p(ws),
                                                _stream()), "linear_bwd_data_bf16x3 prepare")
             self._valid[("lb", w.data_ptr())] = w._version
+        if BACKWARD_GEMM == "f16x3s" and N % 16 == 0:
+            ws = self._buf(("lbh", w.data_ptr()), l.svr_linear_bwd_data_f16x3_workspace(N, K), w.device)
+            check(l.svr_linear_bwd_data_f16x3(z, 0, C.c_void_p(w.data_ptr()), w.stride(0), z, 0, 0, N, K, EPI_NONE, z, 0, z, z,
+                                              _p(ws), _stream()), "linear_bwd_data_f16x3 prepare")
+            self._valid[("lbh", w.data_ptr())] = w._version
 
     def finish(self, stream):
         self.ready = torch.cuda.Event()
@@ -661,8 +667,33 @@ def linear_fwd(x, w, bias, relu=True, out=None, mode=None):
 
 
 # Arithmetic of the two backward GEMMs of the point MLP: "bf16x3" (3-term bf16 split on the bf16 matrix cores,
-# ~1.5e-5 relative per product, see gemm_bf16x3.hip) or "f32" (exact-f32 MFMA).  The forward never uses it.
-BACKWARD_GEMM = "bf16x3"
+# ~1.5e-5 relative per product, see gemm_bf16x3.hip), "f16x3s" (the SCALED 3-product f16 split: gradient operands brought
+# into f16's range by an exact power of two taken from their |max|, 22 mantissa bits per operand = f32 level, the same
+# three matrix instructions per block; gemm_f16x3.hip / gemm_bf16x3.hip) or "f32" (exact-f32 MFMA).  The forward never uses it.
+BACKWARD_GEMM = os.environ.get("SVR_BACKWARD", "bf16x3")
+BACKWARD_MODES = ("bf16x3", "f16x3s", "f32")
+
+
+def amax_of(t):
+    """(1,) int32 tensor = bit pattern of max |t| on the device (the power-of-two scale of a gradient operand of the
+    "f16x3s" kernels).  Kernels that produce a gradient leave it on the tensor they return (attribute `_svr_amax`: no extra
+    pass); otherwise one pass over t on the current stream, remembered on the tensor object."""
+    a = getattr(t, "_svr_amax", None)
+    if a is not None:
+        return a
+    _f32(t)
+    a = torch.empty(1, device=t.device, dtype=torch.int32)
+    if t.dim() == 2 and t.stride(1) == 1 and t.shape[1] % 4 == 0 and t.stride(0) % 4 == 0 and t.data_ptr() % 16 == 0:
+        M, N, ld, src = t.shape[0], t.shape[1], t.stride(0), t
+    else:
+        src = t if t.is_contiguous() else t.contiguous()
+        n = src.numel()
+        if n % 4 or src.data_ptr() % 16:
+            raise RuntimeError("amax_of: tensor must have a multiple of 4 elements and be 16-byte aligned")
+        M, N, ld = n // 4, 4, 4
+    check(_lib.lib().svr_amax_f32(C.c_void_p(src.data_ptr()), ld, M, N, _p(a), _stream()), "amax_f32")
+    t._svr_amax = a
+    return a
 
 
 def linear_bwd_data(dy, w, mask=None, out=None, mode=None):
@@ -673,6 +704,25 @@ def linear_bwd_data(dy, w, mask=None, out=None, mode=None):
     if out is None:
         out = torch.empty(M, K, device=dy.device, dtype=torch.float32)
     epi = EPI_MASK if mask is not None else EPI_NONE
+    if ((mode or BACKWARD_GEMM) == "f16x3s" and N % 16 == 0 and dy.stride(1) == 1 and dy.stride(0) % 4 == 0
+            and dy.data_ptr() % 16 == 0 and out.stride(1) == 1):
+        l = _lib.lib()
+        ws = _lookup("lbh", w, mode, "f16x3s") if (w.stride(0) == K and w.stride(1) == 1) else None
+        wptr = C.c_void_p(0) if ws is not None else C.c_void_p(w.data_ptr())      # W NULL: the workspace is prepared
+        if ws is None:
+            assert w.stride(1) == 1
+            ws = torch.empty(l.svr_linear_bwd_data_f16x3_workspace(N, K), device=dy.device, dtype=torch.uint8)
+        amax_dy = amax_of(dy)
+        amax_dx = torch.empty(1, device=dy.device, dtype=torch.int32)
+        check(l.svr_linear_bwd_data_f16x3(C.c_void_p(dy.data_ptr()), dy.stride(0), wptr, w.stride(0),
+                                          C.c_void_p(out.data_ptr()), out.stride(0), M, N, K, epi,
+                                          C.c_void_p(mask.data_ptr()) if mask is not None else C.c_void_p(0),
+                                          mask.stride(0) if mask is not None else 0, _p(amax_dy), _p(amax_dx), _p(ws), _stream()),
+              "linear_bwd_data_f16x3")
+        out._svr_amax = amax_dx        # |max| of what was stored: the next layer's scale, no extra pass
+        return out
+    if (mode or BACKWARD_GEMM) == "f16x3s":
+        mode = "f32"                   # (shapes the f16 kernel does not take: exact f32, never a narrower split)
     if (mode or BACKWARD_GEMM) == "bf16x3" and N % 32 == 0:
         l = _lib.lib()
         ws = _lookup("lb", w, mode, "bf16x3") if (w.stride(0) == K and w.stride(1) == 1) else None
@@ -700,6 +750,15 @@ def linear_bwd_weight(dy, x, want_bias=True, mode=None):
     l = _lib.lib()
     dw = torch.empty(N, K, device=dy.device, dtype=torch.float32)
     db = torch.empty(N, device=dy.device, dtype=torch.float32) if want_bias else None
+    if ((mode or BACKWARD_GEMM) == "f16x3s" and N % 4 == 0 and K % 4 == 0 and N >= 4 and K >= 4 and M > 0 and dy.stride(1) == 1
+            and x.stride(1) == 1 and dy.stride(0) % 4 == 0 and x.stride(0) % 4 == 0 and dy.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0):
+        ws = torch.empty(l.svr_linear_bwd_weight_f16x3_workspace(M, N, K), device=dy.device, dtype=torch.uint8)
+        check(l.svr_linear_bwd_weight_f16x3(C.c_void_p(dy.data_ptr()), dy.stride(0), C.c_void_p(x.data_ptr()), x.stride(0),
+                                            _p(dw), dw.stride(0), _p(db), M, N, K, _p(amax_of(dy)), _p(ws), _stream()),
+              "linear_bwd_weight_f16x3")
+        return dw, db
+    if (mode or BACKWARD_GEMM) == "f16x3s":
+        mode = "f32"
     if (mode or BACKWARD_GEMM) == "bf16x3" and N % 4 == 0:
         ws = torch.empty(l.svr_linear_bwd_weight_bf16x3_workspace(M, N, K), device=dy.device, dtype=torch.uint8)
         check(l.svr_linear_bwd_weight_bf16x3(C.c_void_p(dy.data_ptr()), dy.stride(0), C.c_void_p(x.data_ptr()), x.stride(0),

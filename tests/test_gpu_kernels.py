@@ -311,6 +311,47 @@ def test_linear_fwd_bwd(M, N, K):
         assert G.rel_err(db.cpu().numpy(), dy.double().sum(0).numpy()) < 2e-6
 
 
+@pytest.mark.parametrize("M,N,K,gscale", [(4099, 256, 256, 1e-6), (3000, 256, 800, 3e-3), (1000, 64, 2592, 1.0), (520, 256, 36, 1e-9)])
+def test_linear_backward_at_f32_level_f16x3s(M, N, K, gscale):
+    """The scaled f16 split of the two backward GEMMs ("f16x3s": svr_linear_bwd_data_f16x3 / svr_linear_bwd_weight_f16x3 /
+    svr_amax_f32) against f64, on GRADIENT-like operands: dY of magnitude `gscale` with a heavy tail (rows spread over
+    e^(+-3 sigma)), i.e. far outside f16's range without the power-of-two scale.  Held to the exact-f32 MFMA kernel's gate
+    (2e-6) and to <= 3x that kernel's own error; bf16x3 on the same operands is an order of magnitude away.  The |max| that
+    the data-gradient kernel leaves for the next layer equals the tensor's."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(M + K)
+    x = F.relu(torch.randn(M, K, generator=g)) * torch.exp(torch.randn(M, 1, generator=g))       # activations, O(1), many zeros
+    w = torch.randn(N, K, generator=g) / K ** 0.5
+    dy = torch.randn(M, N, generator=g) * gscale * torch.exp(3 * torch.randn(M, 1, generator=g))
+    dyc, wc, xc = dy.cuda(), w.cuda(), x.cuda()
+    a = ops.amax_of(dyc)
+    assert a.dtype == torch.int32 and float(a.view(torch.float32)) == float(dy.abs().max())
+    dx_ref = (dy.double() @ w.double()) * (x.double() > 0)
+    dw_ref = dy.double().t() @ x.double()
+    err = {}
+    for mode in ("f32", "f16x3s", "bf16x3"):
+        dx = ops.linear_bwd_data(dyc, wc, mask=xc, mode=mode)
+        dw, db = ops.linear_bwd_weight(dyc, xc, mode=mode)
+        err[mode] = (G.rel_err(dx.cpu().numpy(), dx_ref.numpy()), G.rel_err(dw.cpu().numpy(), dw_ref.numpy()))
+        assert G.rel_err(db.cpu().numpy(), dy.double().sum(0).numpy()) < 2e-6
+        if mode == "f16x3s":
+            assert float(dx._svr_amax.view(torch.float32)) == float(dx.abs().max()), "fused |max| of dX"
+            dxn = ops.linear_bwd_data(dyc, wc, mode=mode)                # no mask
+            assert G.rel_err(dxn.cpu().numpy(), (dy.double() @ w.double()).numpy()) < 2e-6
+    for i, what in enumerate(("dX", "dW")):
+        assert err["f32"][i] < 2e-6 and err["f16x3s"][i] < 2e-6, (what, err)
+        assert err["f16x3s"][i] < 3 * err["f32"][i] + 1e-7, (what, err)
+        if N >= 32 and K % 4 == 0:
+            assert err["bf16x3"][i] > 4 * err["f16x3s"][i], (what, err)   # what the mode is for
+    # row-strided operands (the kept-column slices of fc_0's backward) and a prepared workspace give the same bits
+    if K >= 64:
+        big = torch.zeros(M, K + 32, device="cuda")
+        big[:, 16:16 + K] = xc
+        dw2, _ = ops.linear_bwd_weight(dyc, big[:, 16:16 + K], mode="f16x3s")
+        dw1, _ = ops.linear_bwd_weight(dyc, xc, mode="f16x3s")
+        assert torch.equal(dw1, dw2)
+
+
 def test_fc_out_and_bce():
     ops = _ops()
     g = torch.Generator().manual_seed(3)
