@@ -50,8 +50,9 @@ SETUP_STEPS = 2                              # untimed steps before the W warm-u
 ALT_BACKWARD = {
     "backward_exact_f32": ("f32", "the same step with every backward GEMM / convolution on the exact-f32 MFMA kernels "
                                   "(ops.BACKWARD_* = 'f32') instead of the bf16x3 split"),
-    "backward_f32_level": ("bf16x6", "the same step with every backward GEMM / convolution as the 6-product bf16 split "
-                                     "(three bf16 terms per operand, f32-level accuracy at any range; ops.BACKWARD_* = 'bf16x6')"),
+    "backward_f32_level": ("f16x3s", "the same step with every backward GEMM / convolution on the SCALED 3-product f16 split "
+                                     "(gradient operands scaled by a power of two from their |max|: 22 mantissa bits per "
+                                     "operand, f32-level; ops.BACKWARD_* = 'f16x3s')"),
 }
 SPLIT_PRODUCTS = 3                           # f16x3 / bf16x3: three MFMA products per f32-equivalent product
 
@@ -572,8 +573,7 @@ def _ifn_mod():
 def _backward_arithmetic():
     from svr_amd import ops
     modes = {ops.BACKWARD_GEMM, ops.BACKWARD_CONV, ops.BACKWARD_CONV_WEIGHT}
-    names = {"bf16x3": "bf16x3 split (~1.5e-5 per product)", "bf16x6": "bf16x6 split (f32-level)",
-             "f16x3s": "scaled 3-product f16 split (f32-level)", "f32": "exact f32 MFMA"}
+    names = {"bf16x3": "bf16x3 split (~1.5e-5 per product)", "f16x3s": "scaled 3-product f16 split (f32-level)", "f32": "exact f32 MFMA"}
     return " / ".join(names.get(m, m) for m in sorted(modes))
 
 

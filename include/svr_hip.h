@@ -391,6 +391,20 @@ int svr_conv3d_k3_bwd_weight_bf16x3(const float *in, const float *dout, float *d
 int svr_conv3d_k3_bwd_weight_bf16x3_param(const float *in, const float *dout, float *dW, float *db, int32_t B,
                                           int32_t D, int32_t H, int32_t W, int32_t Ci, int32_t Co,
                                           void *workspace, void *stream);
+/* The encoder's two backward products at f32 LEVEL on the scaled f16 split ("f16x3s", see svr_linear_bwd_data_f16x3):
+ * amax_dout = svr_amax_f32 of dout (or the amax output of the kernel that made it; NULL: no scaling), amax_din (may be
+ * NULL) receives |max| of the stored din.  bwd_data: PREPARE / RUN like the bf16x3 entry (dout NULL = prepare from W,
+ * W NULL = run), workspace svr_conv3d_bwd_data_f16x3_workspace(Ci, Co) bytes, Co % 16 == 0, Ci even.  bwd_weight:
+ * workspace svr_conv3d_k3_bwd_weight_bf16x3_workspace(...) bytes, Ci, Co % 4 == 0; param_layout != 0: dW(Co,Ci,3,3,3),
+ * else the packed [tap][ci][co].                                                                                    */
+int64_t svr_conv3d_bwd_data_f16x3_workspace(int32_t Ci, int32_t Co);
+int svr_conv3d_k3_bwd_data_f16x3(const float *dout, const float *W, float *din, int32_t B, int32_t D,
+                                 int32_t H, int32_t Wd, int32_t Ci, int32_t Co, int epilogue,
+                                 const float *mask, const uint32_t *amax_dout, uint32_t *amax_din,
+                                 void *workspace, void *stream);
+int svr_conv3d_k3_bwd_weight_f16x3(const float *in, const float *dout, float *dW, float *db, int32_t B,
+                                   int32_t D, int32_t H, int32_t W, int32_t Ci, int32_t Co, int32_t param_layout,
+                                   const uint32_t *amax_dout, void *workspace, void *stream);
 
 /* ---------------------------------------------------------------------------------------
  * BatchNorm3d (training or eval) + MaxPool3d(2), channels-last

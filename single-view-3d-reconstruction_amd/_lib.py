@@ -109,6 +109,9 @@ SIGNATURES = {
     "svr_conv3d_k3_bwd_weight_bf16x3_workspace": (I64, [I32, I32, I32, I32, I32, I32]),
     "svr_conv3d_k3_bwd_weight_bf16x3": (C.c_int, [P, P, P, P, I32, I32, I32, I32, I32, I32, P, P]),
     "svr_conv3d_k3_bwd_weight_bf16x3_param": (C.c_int, [P, P, P, P, I32, I32, I32, I32, I32, I32, P, P]),
+    "svr_conv3d_bwd_data_f16x3_workspace": (I64, [I32, I32]),
+    "svr_conv3d_k3_bwd_data_f16x3": (C.c_int, [P, P, P, I32, I32, I32, I32, I32, I32, C.c_int, P, P, P, P, P]),
+    "svr_conv3d_k3_bwd_weight_f16x3": (C.c_int, [P, P, P, P, I32, I32, I32, I32, I32, I32, I32, P, P, P]),
     "svr_bn_stats_workspace": (I64, [I64, I32]),
     "svr_bn_stats": (C.c_int, [P, P, I64, I32, P, P]),
     "svr_bn_stats_finalize": (C.c_int, [P, P, P, P, P, P, P, P, I64, I32, F32, F32, P, P]),

@@ -113,6 +113,23 @@ __global__ void pack_bwd_planes_kernel(const float *__restrict__ W, uint16_t *__
   *reinterpret_cast<uint32_t *>(mid + o) = m;
 }
 
+// The same planes for the scaled f16 split ("f16x3s" backward-data): hi(W 2^s), lo(W 2^s) in f16, [2][27][Ci][Co]
+__global__ void pack_bwd_planes_f16_kernel(const float *__restrict__ W, const uint32_t *__restrict__ amax,
+                                           uint16_t *__restrict__ p0, uint16_t *__restrict__ p1, int Ci, int Co) {
+  int idx = blockIdx.x * blockDim.x + threadIdx.x;  // over (tap', ci, co/2)
+  if (idx >= 27 * Ci * (Co / 2)) return;
+  const int co = (idx % (Co / 2)) * 2;
+  const int ci = (idx / (Co / 2)) % Ci;
+  const int tp = idx / ((Co / 2) * Ci);
+  const float sc = w_scale(amax[0], false);
+  const float w0 = W[((size_t)co * Ci + ci) * 27 + (26 - tp)] * sc, w1 = W[((size_t)(co + 1) * Ci + ci) * 27 + (26 - tp)] * sc;
+  const uint32_t hi = pack_f16(w0, w1);
+  const f32x2 h = unpack_f16(hi);
+  const size_t o = ((size_t)tp * Ci + ci) * Co + co;
+  *reinterpret_cast<uint32_t *>(p0 + o) = hi;
+  *reinterpret_cast<uint32_t *>(p1 + o) = pack_f16(w0 - h.x, w1 - h.y);
+}
+
 // W (Co,Ci,3,3,3) f32 -> forward planes [3][27][Co][Ci] bf16 (row = output channel, k = input channel)
 __global__ void pack_fwd_planes_kernel(const float *__restrict__ W, uint16_t *__restrict__ p0, uint16_t *__restrict__ p1,
                                        uint16_t *__restrict__ p2, int Ci, int Co) {
@@ -143,7 +160,15 @@ __global__ __launch_bounds__(256) void conv3d_brick_x3_kernel(const float *__res
                                                               float *__restrict__ out, const float *__restrict__ mask,
                                                               ConvShape s, int nbz, int nby, int nbx, int mode,
                                                               const uint32_t *__restrict__ amax = nullptr,
-                                                              double *__restrict__ spart = nullptr) {
+                                                              double *__restrict__ spart = nullptr,
+                                                              const uint32_t *__restrict__ amax_in = nullptr,
+                                                              uint32_t *__restrict__ amax_out = nullptr) {
+  // amax_in (F16 only; the backward-data product of the scaled f16 split, "f16x3s"): |max| of the input (a gradient): it is
+  // multiplied by the exact power of two that brings that into [2^13, 2^14) on the way into the split, the epilogue divides
+  // again; amax_out: |max| of what this launch stored (the next layer's scale without a pass over the tensor)
+  float sin = 1.f;
+  if constexpr (F16) sin = amax_in ? w_scale(amax_in[0], false) : 1.f;
+  float vmax = 0.f;
   constexpr int BZ = BRZ * VT, HV = (BZ + 2) * HLY * HLX;  // brick depth and halo voxels of this instantiation
   constexpr int SL = CK / 8, XW = SL * 4;    // 16-byte slots / dwords per LDS row (CK 16-bit values, no padding: slot_dw)
   constexpr int HR = (BZ + 2) * HLY * HP;    // halo rows in LDS (x pitch HP)
@@ -246,8 +271,8 @@ __global__ __launch_bounds__(256) void conv3d_brick_x3_kernel(const float *__res
         split3(v.z, v.w, h1, m1, l1);
         *reinterpret_cast<uint2 *>(&sh[NP - 1][hd]) = make_uint2(l0, l1);
       } else if constexpr (F16) {
-        split_x(v.x, v.y, h0, m0);
-        split_x(v.z, v.w, h1, m1);
+        split_x(v.x * sin, v.y * sin, h0, m0);
+        split_x(v.z * sin, v.w * sin, h1, m1);
       } else {
         split2(v.x, v.y, h0, m0);
         split2(v.z, v.w, h1, m1);
@@ -352,7 +377,7 @@ __global__ __launch_bounds__(256) void conv3d_brick_x3_kernel(const float *__res
     const int n = n0 + j * 32 + l31;
     const int nc = min(n, s.Co - 1);
     const float bv = (mode == SVR_EPI_BIAS || mode == SVR_EPI_BIAS_RELU) ? bias[nc] : 0.f;
-    const float inv = F16 ? w_scale(amax[0], true) : 1.f;
+    const float inv = F16 ? w_scale(amax[0], true) * (amax_in ? w_scale(amax_in[0], true) : 1.f) : 1.f;
     const int gz = z0 + wave + BRZ * v;
     // the ReLU mask of the whole tile is fetched up front from clamped coordinates: loads inside the bounds
     // branch would be waited for one at a time
@@ -377,8 +402,14 @@ __global__ __launch_bounds__(256) void conv3d_brick_x3_kernel(const float *__res
         out[o] = val;
         ssum[j] += val;
         ssq[j] = fmaf(val, val, ssq[j]);
+        vmax = fmaxf(vmax, fabsf(val));
       }
     }
+  }
+  if (amax_out) {  // (uniform)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));
+    if (lane == 0 && vmax > 0.f) atomicMax(amax_out, __float_as_uint(vmax));
   }
   if (spart) {  // (uniform) lanes l31 / l31 + 32 of the four waves hold the same channel: fixed-order f64 sum of the 8 partials
     float *red = reinterpret_cast<float *>(&sw[0][0][0][0]);   // the weight buffers are free now: [thread][TNB][2] floats
@@ -419,7 +450,11 @@ __global__ __launch_bounds__(256, 2) void conv3d_brick_p_kernel(const float *__r
                                                              int64_t plane_stride, const float *__restrict__ bias,
                                                              float *__restrict__ out, const float *__restrict__ mask,
                                                              ConvShape s, int nbz, int nby, int nbx, int nbricks, int mode,
-                                                             const uint32_t *__restrict__ amax, double *__restrict__ spart) {
+                                                             const uint32_t *__restrict__ amax, double *__restrict__ spart,
+                                                             const uint32_t *__restrict__ amax_in, uint32_t *__restrict__ amax_out) {
+  float sin = 1.f;   // (see conv3d_brick_x3_kernel)
+  if constexpr (F16) sin = amax_in ? w_scale(amax_in[0], false) : 1.f;
+  float vmax = 0.f;
   constexpr int NP = 2, NC = 32, TG = 3, STEPS = 10;
   constexpr int BZ = BRZ * VT, HV = (BZ + 2) * HLY * HLX;
   constexpr int SL = CK / 8, XW = SL * 4, HR = (BZ + 2) * HLY * HP, KS = CK / 16;
@@ -539,8 +574,8 @@ __global__ __launch_bounds__(256, 2) void conv3d_brick_p_kernel(const float *__r
       const float4 v = make_float4(ok ? hreg[i].x : 0.f, ok ? hreg[i].y : 0.f, ok ? hreg[i].z : 0.f, ok ? hreg[i].w : 0.f);
       uint32_t h0, m0, h1, m1;
       if constexpr (F16) {
-        split_x(v.x, v.y, h0, m0);
-        split_x(v.z, v.w, h1, m1);
+        split_x(v.x * sin, v.y * sin, h0, m0);
+        split_x(v.z * sin, v.w * sin, h1, m1);
       } else {
         split2(v.x, v.y, h0, m0);
         split2(v.z, v.w, h1, m1);
@@ -557,7 +592,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_brick_p_kernel(const float *__r
     float ssum = 0.f, ssq = 0.f;
     const int n = n0 + l31, nc = min(n, s.Co - 1);
     const float bv = (mode == SVR_EPI_BIAS || mode == SVR_EPI_BIAS_RELU) ? bias[nc] : 0.f;
-    const float inv = F16 ? w_scale(amax[0], true) : 1.f;
+    const float inv = F16 ? w_scale(amax[0], true) * (amax_in ? w_scale(amax_in[0], true) : 1.f) : 1.f;
     const bool interior = I.z0 + BZ <= s.D && I.y0 + BRY <= s.H && I.x0 + BRX <= s.W && n0 + NC <= s.Co;   // (uniform)
     char *outb = reinterpret_cast<char *>(out + (int64_t)I.b * s.D * s.H * s.W * s.Co);
     const char *maskb = reinterpret_cast<const char *>(mask + (mode == SVR_EPI_MASK ? (int64_t)I.b * s.D * s.H * s.W * s.Co : 0));
@@ -591,6 +626,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_brick_p_kernel(const float *__r
           *reinterpret_cast<float *>(outb + off[r]) = val;
           ssum += val;
           ssq = fmaf(val, val, ssq);
+          vmax = fmaxf(vmax, fabsf(val));
         }
         acc[v][r] = 0.f;
       }
@@ -697,6 +733,11 @@ __global__ __launch_bounds__(256, 2) void conv3d_brick_p_kernel(const float *__r
     __syncthreads();
     cur = nxt;
   }
+  if (amax_out) {  // (uniform) |max| of everything this workgroup stored
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));
+    if (lane == 0 && vmax > 0.f) atomicMax(amax_out, __float_as_uint(vmax));
+  }
 }
 
 // SVR_CONV_PERSISTENT=0: the one-brick-per-workgroup kernel everywhere (A/B switch, read once)
@@ -721,13 +762,14 @@ int brick_p_resident() {
 }
 template <int CK, bool F16, int VT>
 void launch_brick_p(const float *in, const uint16_t *P0, int64_t plane_stride, const float *bias, float *out, const float *mask,
-                    ConvShape sh, int nbz, int nby, int nbx, int ycols, int mode, const uint32_t *amax, double *spart, hipStream_t s) {
+                    ConvShape sh, int nbz, int nby, int nbx, int ycols, int mode, const uint32_t *amax, double *spart, hipStream_t s,
+                    const uint32_t *amax_in = nullptr, uint32_t *amax_out = nullptr) {
   const int64_t bricks = (int64_t)sh.B * nbz * nby * nbx;
   int gx = brick_p_resident<CK, F16, VT>() / ycols;
   if (gx < 1) gx = 1;
   if (gx > bricks) gx = (int)bricks;
   hipLaunchKernelGGL((conv3d_brick_p_kernel<CK, F16, VT>), dim3((unsigned)gx, (unsigned)ycols), dim3(256), 0, s, in, P0, plane_stride, bias, out,
-                     mask, sh, nbz, nby, nbx, (int)bricks, mode, amax, spart);
+                     mask, sh, nbz, nby, nbx, (int)bricks, mode, amax, spart, amax_in, amax_out);
 }
 
 }  // namespace
@@ -774,6 +816,53 @@ extern "C" int svr_conv3d_k3_bwd_data_bf16x3(const float *dout, const float *W, 
   }
 #undef LAUNCH_X3
   return launch_status("conv3d_bwd_data_bf16x3");
+}
+
+// ---- backward-data on the scaled f16 split ("f16x3s": f32 level at the bf16x3 cost; see svr_linear_bwd_data_f16x3) -------------
+extern "C" int64_t svr_conv3d_bwd_data_f16x3_workspace(int32_t Ci, int32_t Co) { return 2LL * 27 * Ci * Co * (int64_t)sizeof(uint16_t) + 512; }
+
+extern "C" int svr_conv3d_k3_bwd_data_f16x3(const float *dout, const float *W, float *din, int32_t B, int32_t D, int32_t H,
+                                            int32_t Wd, int32_t Ci, int32_t Co, int epilogue, const float *mask,
+                                            const uint32_t *amax_dout, uint32_t *amax_din, void *workspace, void *stream) {
+  // dout == NULL: PREPARE only (W -> scale + split planes in the workspace);  W == NULL: RUN on a workspace prepared earlier
+  SVR_CHECK((dout || W) && (!dout || din) && workspace, SVR_E_BADARG, "conv3d_bwd_data_f16x3: null pointer");
+  SVR_CHECK(Co % 16 == 0 && Ci % 2 == 0 && Ci >= 2, SVR_E_UNSUPPORTED, "conv3d_bwd_data_f16x3: need Co %% 16 == 0, Ci even (Ci=%d Co=%d)", Ci, Co);
+  hipStream_t s = (hipStream_t)stream;
+  uint32_t *amax = (uint32_t *)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+  uint16_t *hi = (uint16_t *)(amax + 64);
+  const int64_t ps = (int64_t)27 * Ci * Co;
+  if (W) {
+    (void)hipMemsetAsync(amax, 0, sizeof(uint32_t), s);
+    hipLaunchKernelGGL(w_amax_kernel, dim3((unsigned)cdiv(ps, 1024)), dim3(256), 0, s, W, ps, (int64_t)1, ps, amax);
+    hipLaunchKernelGGL(pack_bwd_planes_f16_kernel, dim3(cdiv(27 * Ci * (Co / 2), 256)), dim3(256), 0, s, W, amax, hi, hi + ps, Ci, Co);
+  }
+  if (!dout) return launch_status("conv3d_bwd_data_f16x3 (prepare)");
+  SVR_CHECK(B > 0 && D > 0 && H > 0 && Wd > 0, SVR_E_BADSHAPE, "conv3d_bwd_data_f16x3: empty volume");
+  SVR_CHECK(epilogue == SVR_EPI_NONE || (epilogue == SVR_EPI_MASK && mask), SVR_E_BADARG, "conv3d_bwd_data_f16x3: epilogue %d", epilogue);
+  if (amax_din) (void)hipMemsetAsync(amax_din, 0, sizeof(uint32_t), s);
+  ConvShape sh{B, D, H, Wd, /*K=*/Co, /*NOUT=*/Ci};
+  const int nbz = (int)cdiv(D, BRZ), nby = (int)cdiv(H, BRY), nbx = (int)cdiv(Wd, BRX);
+  const unsigned bricks = (unsigned)((int64_t)B * nbz * nby * nbx);
+#define LAUNCH_B3(CKV, TNV)                                                                                                     \
+  hipLaunchKernelGGL((conv3d_brick_x3_kernel<CKV, TNV, 2, true>), dim3(bricks, (unsigned)cdiv(Ci, TNV * 32)), dim3(256), 0, s, dout, \
+                     hi, ps, (const float *)nullptr, din, mask, sh, nbz, nby, nbx, epilogue, amax, (double *)nullptr, amax_dout, amax_din)
+  int tn = Ci <= 32 ? 1 : (Ci <= 64 ? 2 : 4);                        // (the tile choice of svr_conv3d_k3_bwd_data_bf16x3)
+  while (tn > 1 && (int64_t)bricks * cdiv(Ci, tn * 32) < 512) tn /= 2;
+  const int nbz2 = (int)cdiv(D, 2 * BRZ);
+  if (tn == 1 && (int64_t)B * nbz2 * nby * nbx * cdiv(Ci, 32) >= 512) {
+    if (persistent_bricks(sh))
+      launch_brick_p<16, true, 2>(dout, hi, ps, nullptr, din, mask, sh, nbz2, nby, nbx, (int)cdiv(Ci, 32), epilogue, amax, nullptr, s, amax_dout, amax_din);
+    else
+      hipLaunchKernelGGL((conv3d_brick_x3_kernel<16, 1, 2, true, 2>), dim3((unsigned)((int64_t)B * nbz2 * nby * nbx), (unsigned)cdiv(Ci, 32)),
+                         dim3(256), 0, s, dout, hi, ps, (const float *)nullptr, din, mask, sh, nbz2, nby, nbx, epilogue, amax, (double *)nullptr,
+                         amax_dout, amax_din);
+  } else if (Co % 32 == 0) {
+    if (tn == 1) LAUNCH_B3(32, 1); else if (tn == 2) LAUNCH_B3(32, 2); else LAUNCH_B3(32, 4);
+  } else {
+    if (tn == 1) LAUNCH_B3(16, 1); else if (tn == 2) LAUNCH_B3(16, 2); else LAUNCH_B3(16, 4);
+  }
+#undef LAUNCH_B3
+  return launch_status("conv3d_bwd_data_f16x3");
 }
 
 extern "C" int64_t svr_conv3d_fwd_bf16x6_workspace(int32_t Ci, int32_t Co) { return 3LL * 27 * Ci * Co * (int64_t)sizeof(uint16_t) + 256; }

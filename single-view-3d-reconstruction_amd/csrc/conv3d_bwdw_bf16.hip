@@ -19,6 +19,7 @@
 // LDS is double buffered: the next brick's global loads are issued before the MFMA phase and written to the other
 // buffer after it, one barrier per brick.  73 KB per buffer -> one workgroup per CU.
 #include "common.h"
+#include "f16x3.h"
 
 namespace svr {
 void colsum_launch(const float *Y, int64_t ldy, float *out, float *part, int64_t M, int64_t N, hipStream_t s);
@@ -33,7 +34,6 @@ namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 struct ConvShape {
@@ -75,8 +75,11 @@ __device__ __forceinline__ bf16x8 frag(uint32_t a, uint32_t b, uint32_t c, uint3
   return f.v;
 }
 
+// F16 ("f16x3s", svr_conv3d_k3_bwd_weight_f16x3): the scaled f16 split -- dout * 2^s (its |max| brought to [2^13, 2^14)), both
+// operands as hi = rn16(v), lo' = rn16((v - hi) 2^11), products lo'(in) (hi(dout) 2^-11) + (hi(in) 2^-11) lo'(dout) + hi hi with
+// the 2^-11 applied to the hi fragments in registers, slabs * 2^-s: 22 mantissa bits per operand, the same three instructions.
 // MFMA phase of one x-row pair (kq) for tap group G: rows R = (dz, dy) pairs touched by the taps 7G .. 7G+6
-template <int G>
+template <int G, bool F16>
 __device__ __forceinline__ void wgrad_rows(const uint32_t *__restrict__ ibuf, const uint32_t *__restrict__ dbuf, int l31, int r,
                                            f32x16 (&acc)[TAPS_PER_WAVE]) {
   constexpr int T0 = G * TAPS_PER_WAVE, T1 = (T0 + TAPS_PER_WAVE < 27) ? T0 + TAPS_PER_WAVE : 27;
@@ -110,19 +113,31 @@ __device__ __forceinline__ void wgrad_rows(const uint32_t *__restrict__ ibuf, co
 #if defined(SVR_WG_EXP) && SVR_WG_EXP == 1   // measurement build: no matrix instructions (fragments still read and shifted)
       acc[i][0] += (float)am[0] * (float)b_hi[1] + (float)ah[2] * (float)b_mid[3] + (float)ah[7];
 #else
+      if constexpr (F16) {
+        const f16x8 fam = __builtin_bit_cast(f16x8, am), fah = __builtin_bit_cast(f16x8, ah);
+        const f16x8 fbh = __builtin_bit_cast(f16x8, b_hi), fbm = __builtin_bit_cast(f16x8, b_mid);
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fam, scale_2m11(fbh), acc[i], 0, 0, 0);
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(scale_2m11(fah), fbm, acc[i], 0, 0, 0);
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah, fbh, acc[i], 0, 0, 0);
+      } else {
       acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, b_hi, acc[i], 0, 0, 0);
       acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b_mid, acc[i], 0, 0, 0);
       acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, b_hi, acc[i], 0, 0, 0);
+      }
 #endif
     }
   }
 }
 
+template <bool F16>
 __global__ __launch_bounds__(NT) void conv3d_bwd_weight_x3_kernel(const float *__restrict__ in,
                                                                   const float *__restrict__ dout,
                                                                   float *__restrict__ slab, ConvShape s, int nbz, int nby,
-                                                                  int nbx, int co_tiles, float *__restrict__ dbpart) {
+                                                                  int nbx, int co_tiles, float *__restrict__ dbpart,
+                                                                  const uint32_t *__restrict__ amax_dout) {
   __shared__ uint32_t lds[2 * BUF];
+  float sy = 1.f;
+  if constexpr (F16) sy = amax_dout ? w_scale(amax_dout[0], false) : 1.f;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int l31 = lane & 31, lh = lane >> 5;
   const int grp = wave & 3, half = wave >> 2;
@@ -200,7 +215,8 @@ __global__ __launch_bounds__(NT) void conv3d_bwd_weight_x3_kernel(const float *_
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
           uint32_t h, m;
-          split2((iok[j] & 1) ? v0[c] : 0.f, (iok[j] & 2) ? v1[c] : 0.f, h, m);
+          if constexpr (F16) split_x((iok[j] & 1) ? v0[c] : 0.f, (iok[j] & 2) ? v1[c] : 0.f, h, m);
+          else split2((iok[j] & 1) ? v0[c] : 0.f, (iok[j] & 2) ? v1[c] : 0.f, h, m);
           d[c * CIS] = h;
           d[IN_PLANE + c * CIS] = m;
         }
@@ -217,7 +233,8 @@ __global__ __launch_bounds__(NT) void conv3d_bwd_weight_x3_kernel(const float *_
         v0[c] = (dok & 1) ? v0[c] : 0.f;
         v1[c] = (dok & 2) ? v1[c] : 0.f;
         uint32_t h, m;
-        split2(v0[c], v1[c], h, m);
+        if constexpr (F16) split_x(v0[c] * sy, v1[c] * sy, h, m);
+        else split2(v0[c], v1[c], h, m);
         d[c * COS] = h;
         d[DO_PLANE + c * COS] = m;
       }
@@ -251,10 +268,10 @@ __global__ __launch_bounds__(NT) void conv3d_bwd_weight_x3_kernel(const float *_
     for (int kq = 0; kq < 4; ++kq) {
       const int r = 2 * (half * 4 + kq) + lh;  // x-row of the brick handled by this half-wave: r = vz*4 + vy
       switch (grp) {  // wave-uniform
-        case 0: wgrad_rows<0>(ibuf, dbuf, l31, r, acc); break;
-        case 1: wgrad_rows<1>(ibuf, dbuf, l31, r, acc); break;
-        case 2: wgrad_rows<2>(ibuf, dbuf, l31, r, acc); break;
-        default: wgrad_rows<3>(ibuf, dbuf, l31, r, acc); break;
+        case 0: wgrad_rows<0, F16>(ibuf, dbuf, l31, r, acc); break;
+        case 1: wgrad_rows<1, F16>(ibuf, dbuf, l31, r, acc); break;
+        case 2: wgrad_rows<2, F16>(ibuf, dbuf, l31, r, acc); break;
+        default: wgrad_rows<3, F16>(ibuf, dbuf, l31, r, acc); break;
       }
       if (kq == 1 && more) {  // first part of the next brick has arrived: park it in the other buffer, fetch the rest
         store(lds + (cur ^ 1) * BUF, 0);
@@ -278,6 +295,8 @@ __global__ __launch_bounds__(NT) void conv3d_bwd_weight_x3_kernel(const float *_
     }
   }
   // slab layout shared with conv3d.hip's reduce kernel: [part][tap][pair][32 ci][32 co]
+  float inv = 1.f;
+  if constexpr (F16) inv = amax_dout ? w_scale(amax_dout[0], true) : 1.f;
   const int pairs = gridDim.y;
   const int64_t part = (int64_t)blockIdx.x * 2 + half;
 #pragma unroll
@@ -286,7 +305,7 @@ __global__ __launch_bounds__(NT) void conv3d_bwd_weight_x3_kernel(const float *_
     if (tap < 27) {
       float *o = slab + ((part * 27 + tap) * pairs + pair) * 1024;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) o[((r & 3) + 8 * (r >> 2) + 4 * lh) * 32 + l31] = acc[i][r];
+      for (int r = 0; r < 16; ++r) o[((r & 3) + 8 * (r >> 2) + 4 * lh) * 32 + l31] = F16 ? acc[i][r] * inv : acc[i][r];
     }
   }
 }
@@ -327,7 +346,15 @@ extern "C" int64_t svr_conv3d_k3_bwd_weight_bf16x3_workspace(int32_t B, int32_t 
 
 namespace {
 int bwd_weight_x3(const float *in, const float *dout, float *dWp, float *db, int32_t B, int32_t D, int32_t H, int32_t W, int32_t Ci,
-                  int32_t Co, void *workspace, void *stream, int param_layout);
+                  int32_t Co, void *workspace, void *stream, int param_layout, bool f16 = false, const uint32_t *amax_dout = nullptr);
+}
+
+// The weight gradient on the scaled f16 split ("f16x3s": f32 level, see svr_linear_bwd_weight_f16x3); amax_dout: svr_amax_f32 of
+// dout (or the amax output of the kernel that produced it).  param_layout != 0: dW(Co,Ci,3,3,3), else the packed [tap][ci][co].
+extern "C" int svr_conv3d_k3_bwd_weight_f16x3(const float *in, const float *dout, float *dW, float *db, int32_t B, int32_t D,
+                                              int32_t H, int32_t W, int32_t Ci, int32_t Co, int32_t param_layout,
+                                              const uint32_t *amax_dout, void *workspace, void *stream) {
+  return bwd_weight_x3(in, dout, dW, db, B, D, H, W, Ci, Co, workspace, stream, param_layout ? 1 : 0, true, amax_dout);
 }
 
 extern "C" int svr_conv3d_k3_bwd_weight_bf16x3(const float *in, const float *dout, float *dWp, float *db, int32_t B,
@@ -346,7 +373,7 @@ extern "C" int svr_conv3d_k3_bwd_weight_bf16x3_param(const float *in, const floa
 
 namespace {
 int bwd_weight_x3(const float *in, const float *dout, float *dWp, float *db, int32_t B, int32_t D, int32_t H, int32_t W, int32_t Ci,
-                  int32_t Co, void *workspace, void *stream, int param_layout) {
+                  int32_t Co, void *workspace, void *stream, int param_layout, bool f16, const uint32_t *amax_dout) {
   SVR_CHECK(B > 0 && D > 0 && H > 0 && W > 0, SVR_E_BADSHAPE, "conv3d_bwd_weight_bf16x3: empty volume %dx%dx%dx%d", B, D, H, W);
   SVR_CHECK(in && dout && dWp && workspace, SVR_E_BADARG, "conv3d_bwd_weight_bf16x3: null pointer");
   SVR_CHECK(Ci >= 4 && Ci % 4 == 0 && Co % 4 == 0 && Co >= 4, SVR_E_UNSUPPORTED,
@@ -363,8 +390,12 @@ int bwd_weight_x3(const float *in, const float *dout, float *dWp, float *db, int
   const int parts = x3_parts(B, D, H, W, Ci, Co);
   float *slab = (float *)workspace;
   float *dbpart = db ? slab + (int64_t)parts * 2 * 27 * cit * cot * 1024 : nullptr;
-  hipLaunchKernelGGL(conv3d_bwd_weight_x3_kernel, dim3((unsigned)parts, (unsigned)(cit * cot)), dim3(NT), 0, s, in, dout,
-                     slab, sh, nbz, nby, nbx, cot, dbpart);
+  if (f16)
+    hipLaunchKernelGGL(conv3d_bwd_weight_x3_kernel<true>, dim3((unsigned)parts, (unsigned)(cit * cot)), dim3(NT), 0, s, in, dout,
+                       slab, sh, nbz, nby, nbx, cot, dbpart, amax_dout);
+  else
+    hipLaunchKernelGGL(conv3d_bwd_weight_x3_kernel<false>, dim3((unsigned)parts, (unsigned)(cit * cot)), dim3(NT), 0, s, in, dout,
+                       slab, sh, nbz, nby, nbx, cot, dbpart, (const uint32_t *)nullptr);
   // one launch: slabs -> dW (either layout) and, in its last Co workgroups, the bias-gradient partials -> db
   conv3d_bwd_weight_reduce_launch(slab, dWp, Ci, Co, cit, cot, parts * 2, s, param_layout, dbpart, db, parts);
   return launch_status("conv3d_bwd_weight_bf16x3");

@@ -578,6 +578,11 @@ class PreparedWeights:
             check(l.svr_conv3d_k3_bwd_data_bf16x3(z, _p(w), z, 0, 0, 0, 0, Ci, Co, EPI_NONE, z, _p(ws), _stream()),
                   "conv3d_bwd_data_bf16x3 prepare")
             self._valid[("cb", w.data_ptr())] = w._version
+        if BACKWARD_CONV == "f16x3s" and Ci % 2 == 0 and Co % 16 == 0:
+            ws = self._buf(("cbh", w.data_ptr()), l.svr_conv3d_bwd_data_f16x3_workspace(Ci, Co), w.device)
+            check(l.svr_conv3d_k3_bwd_data_f16x3(z, _p(w), z, 0, 0, 0, 0, Ci, Co, EPI_NONE, z, z, z, _p(ws), _stream()),
+                  "conv3d_bwd_data_f16x3 prepare")
+            self._valid[("cbh", w.data_ptr())] = w._version
 
     def add_linear(self, w):
         """w (N,K) row-major: forward (f16x3) and backward-data (bf16x3) planes, where those modes apply."""
@@ -841,7 +846,7 @@ def conv3d_k3(x, wp, bias=None, relu=False, mask=None):
 
 
 # Arithmetic of the encoder's backward-data convolutions: "bf16x3" (conv3d_bf16.hip) or "f32".
-BACKWARD_CONV = "bf16x3"
+BACKWARD_CONV = os.environ.get("SVR_BACKWARD", "bf16x3")     # "bf16x3", "f16x3s" (scaled f16 split: f32 level) or "f32"
 # ... and of its forward convolutions: "f16x3" (3-product f16 split, f32-level accuracy for |x| < 65504), "bf16x6"
 # (6-product bf16 split, any f32 range) or "f32" (exact-f32 MFMA)
 FORWARD_CONV = "f16x3"
@@ -913,6 +918,21 @@ def conv3d_k3_bwd_data(dout, w, mask=None, mode=None):
     B, D, H, W, Co = dout.shape
     Ci = w.shape[1]
     assert w.shape[0] == Co
+    if (mode or BACKWARD_CONV) == "f16x3s" and Ci % 2 == 0 and Co % 16 == 0 and dout.is_contiguous() and dout.numel() % 4 == 0:
+        l = _lib.lib()
+        din = torch.empty(B, D, H, W, Ci, device=dout.device, dtype=torch.float32)
+        ws = _lookup("cbh", w, mode, "f16x3s")
+        wptr = C.c_void_p(0) if ws is not None else _p(w)                          # W NULL: the workspace is prepared
+        if ws is None:
+            ws = torch.empty(l.svr_conv3d_bwd_data_f16x3_workspace(Ci, Co), device=dout.device, dtype=torch.uint8)
+        amax_din = torch.empty(1, device=dout.device, dtype=torch.int32)
+        check(l.svr_conv3d_k3_bwd_data_f16x3(_p(dout), wptr, _p(din), B, D, H, W, Ci, Co,
+                                             EPI_MASK if mask is not None else EPI_NONE, _p(mask), _p(amax_of(dout)), _p(amax_din),
+                                             _p(ws), _stream()), "conv3d_bwd_data_f16x3")
+        din._svr_amax = amax_din
+        return din
+    if (mode or BACKWARD_CONV) == "f16x3s":
+        mode = "f32"                   # (shapes the f16 kernel does not take: exact f32, never a narrower split)
     if (mode or BACKWARD_CONV) == "bf16x3" and Ci % 2 == 0 and Co % 16 == 0:
         l = _lib.lib()
         din = torch.empty(B, D, H, W, Ci, device=dout.device, dtype=torch.float32)
@@ -928,8 +948,9 @@ def conv3d_k3_bwd_data(dout, w, mask=None, mode=None):
     return conv3d_k3(dout, wb, mask=mask)
 
 
-# Arithmetic of the encoder's weight gradients: "bf16x3" (conv3d_bwdw_bf16.hip) or "f32" (exact-f32 MFMA)
-BACKWARD_CONV_WEIGHT = "bf16x3"
+# Arithmetic of the encoder's weight gradients: "bf16x3" (conv3d_bwdw_bf16.hip), "f16x3s" (its scaled f16 form: f32 level)
+# or "f32" (exact-f32 MFMA)
+BACKWARD_CONV_WEIGHT = os.environ.get("SVR_BACKWARD", "bf16x3")
 
 
 def conv3d_k3_bwd_weight(x, dout, want_bias=True, mode=None, param_layout=False):
@@ -941,7 +962,16 @@ def conv3d_k3_bwd_weight(x, dout, want_bias=True, mode=None, param_layout=False)
     l = _lib.lib()
     # the split-precision kernel's 32-bit offsets inside one sample (conv3d_bwdw_bf16.hip); larger volumes take the f32 kernel
     fits = D * H * W <= (1 << 24) and D * H * W * max(Ci, Co) < (1 << 30)
-    if not fits and (mode or BACKWARD_CONV_WEIGHT) == "bf16x3":
+    if not fits and (mode or BACKWARD_CONV_WEIGHT) in ("bf16x3", "f16x3s"):
+        mode = "f32"
+    if (mode or BACKWARD_CONV_WEIGHT) == "f16x3s" and Ci % 4 == 0 and Co % 4 == 0 and dout.is_contiguous() and dout.numel() % 4 == 0:
+        ws = torch.empty(l.svr_conv3d_k3_bwd_weight_bf16x3_workspace(B, D, H, W, Ci, Co), device=x.device, dtype=torch.uint8)
+        dw = torch.empty((Co, Ci, 3, 3, 3) if param_layout else (27, Ci, Co), device=x.device, dtype=torch.float32)
+        db = torch.empty(Co, device=x.device, dtype=torch.float32) if want_bias else None
+        check(l.svr_conv3d_k3_bwd_weight_f16x3(_p(x), _p(dout), _p(dw), _p(db), B, D, H, W, Ci, Co, 1 if param_layout else 0,
+                                               _p(amax_of(dout)), _p(ws), _stream()), "conv3d_k3_bwd_weight_f16x3")
+        return dw, db
+    if (mode or BACKWARD_CONV_WEIGHT) == "f16x3s":
         mode = "f32"
     if (mode or BACKWARD_CONV_WEIGHT) == "bf16x3" and Ci % 4 == 0 and Co % 4 == 0 and param_layout:
         ws = torch.empty(l.svr_conv3d_k3_bwd_weight_bf16x3_workspace(B, D, H, W, Ci, Co), device=x.device, dtype=torch.uint8)

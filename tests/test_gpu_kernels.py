@@ -426,6 +426,40 @@ def test_conv3d_fwd_bwd(B, dims, Ci, Co):
             assert G.rel_err(_ncdhw(d3).numpy(), (gx * (x > 0)).detach().numpy()) < tol, mode
 
 
+@pytest.mark.parametrize("B,dims,Ci,Co,gscale", [(2, (10, 6, 12), 16, 32, 1e-5), (1, (8, 8, 8), 32, 32, 1.0), (2, (7, 5, 6), 32, 64, 3e-8),
+                                                  (1, (6, 6, 6), 64, 64, 1e-3), (1, (4, 5, 6), 64, 128, 1e-6), (2, (4, 4, 4), 128, 128, 20.0),
+                                                  (2, (17, 16, 24), 16, 32, 1e-4)])
+def test_conv3d_backward_at_f32_level_f16x3s(B, dims, Ci, Co, gscale):
+    """The encoder's two backward products on the scaled f16 split ("f16x3s": svr_conv3d_k3_bwd_data_f16x3 /
+    svr_conv3d_k3_bwd_weight_f16x3) against f64 autograd, with a GRADIENT-like dout (magnitude `gscale`, per-voxel spread
+    e^(+-2 sigma): outside f16's range without the scale).  Held to the exact-f32 kernel's gate (3e-6) and to <= 3x its own
+    error; bf16x3 is an order of magnitude away.  The last case takes the persistent 32-column kernel (>= 512 bricks)."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(Ci * 1000 + Co + 7)
+    x = F.relu(torch.randn(B, Ci, *dims, generator=g)).requires_grad_(True)
+    w = (torch.randn(Co, Ci, 3, 3, 3, generator=g) / (27 * Ci) ** 0.5).requires_grad_(True)
+    pre = F.conv3d(x.double(), w.double(), None, padding=1)
+    dy = torch.randn(pre.shape, generator=g) * gscale * torch.exp(2 * torch.randn(B, 1, *dims, generator=g))
+    gx, gw = torch.autograd.grad(pre, (x, w), dy.double())
+    dyc, xc, wc = _cl(dy), _cl(x.detach()), w.detach().cuda()
+    err = {}
+    for mode in ("f32", "f16x3s", "bf16x3"):
+        dw, db = ops.conv3d_k3_bwd_weight(xc, dyc, mode=mode, param_layout=True)
+        dwp, _ = ops.conv3d_k3_bwd_weight(xc, dyc, mode=mode)
+        assert torch.equal(ops.conv3d_unpack_wgrad(dwp, Ci, Co), dw), mode
+        assert G.rel_err(db.cpu().numpy(), dy.double().sum((0, 2, 3, 4)).numpy()) < 3e-6
+        d2 = ops.conv3d_k3_bwd_data(dyc, wc, mode=mode)
+        d3 = ops.conv3d_k3_bwd_data(dyc, wc, mask=xc, mode=mode)
+        err[mode] = (G.rel_err(_ncdhw(d2).numpy(), gx.numpy()), G.rel_err(dw.cpu().numpy(), gw.numpy()),
+                     G.rel_err(_ncdhw(d3).numpy(), (gx * (x > 0)).detach().numpy()))
+        if mode == "f16x3s":
+            assert float(d3._svr_amax.view(torch.float32)) == float(d3.abs().max()), "fused |max| of din"
+    for i, what in enumerate(("din", "dW", "din masked")):
+        assert err["f32"][i] < 3e-6 and err["f16x3s"][i] < 3e-6, (what, err)
+        assert err["f16x3s"][i] < 3 * err["f32"][i] + 1e-7, (what, err)
+        assert err["bf16x3"][i] > 4 * err["f16x3s"][i], (what, err)
+
+
 @pytest.mark.parametrize("B,dims,C,pool", [(2, (9, 7, 10), 16, True), (1, (8, 8, 8), 32, True), (2, (5, 4, 6), 64, True),
                                            (3, (4, 4, 4), 128, True), (2, (3, 2, 2), 128, False)])
 def test_bn_pool_fwd_bwd(B, dims, C, pool):
