@@ -49,10 +49,10 @@ SETUP_STEPS = 2                              # untimed steps before the W warm-u
 # the same step under other backward arithmetic, measured behind the timed region: key -> (ops.BACKWARD_* mode, note)
 ALT_BACKWARD = {
     "backward_exact_f32": ("f32", "the same step with every backward GEMM / convolution on the exact-f32 MFMA kernels "
-                                  "(ops.BACKWARD_* = 'f32') instead of the bf16x3 split"),
-    "backward_f32_level": ("f16x3s", "the same step with every backward GEMM / convolution on the SCALED 3-product f16 split "
-                                     "(gradient operands scaled by a power of two from their |max|: 22 mantissa bits per "
-                                     "operand, f32-level; ops.BACKWARD_* = 'f16x3s')"),
+                                  "(ops.BACKWARD_* = 'f32') instead of the f32-level scaled f16 split"),
+    "backward_bf16x3": ("bf16x3", "the same step with every backward GEMM / convolution on the 3-term bf16 split (16 mantissa bits "
+                                  "per operand, ~1.5e-5 per product: the default of rounds 1-3; ops.BACKWARD_* = 'bf16x3', "
+                                  "SVR_BACKWARD=bf16x3)"),
 }
 SPLIT_PRODUCTS = 3                           # f16x3 / bf16x3: three MFMA products per f32-equivalent product
 
@@ -362,7 +362,7 @@ def main():
     if not a.no_diag and not a.no_f32_backward and a.backward == "production":
         prev = (ops.BACKWARD_GEMM, ops.BACKWARD_CONV, ops.BACKWARD_CONV_WEIGHT)
         for key, (mode, _) in ALT_BACKWARD.items():
-            if mode not in getattr(ops, "BACKWARD_MODES", ("bf16x3", "f32")) or mode in prev:
+            if mode not in ops.BACKWARD_MODES or mode in prev:
                 continue
             ops.BACKWARD_GEMM = ops.BACKWARD_CONV = ops.BACKWARD_CONV_WEIGHT = mode
             try:

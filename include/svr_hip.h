@@ -291,6 +291,8 @@ int svr_linear_bwd_weight_bf16x3(const float *dY, int64_t lddy, const float *X, 
  * operand is first multiplied by an exact power of two that brings its |max| into [2^13, 2^14):
  *   svr_amax_f32: amax[0] = bit pattern of max |X[m][n]| (one pass; N, ld multiples of 4, rows 16-byte aligned), or the
  *   amax_dx output of svr_linear_bwd_data_f16x3 (|max| of the dX it stored: the next layer's dY needs no extra pass).
+ * Every amax OUTPUT (svr_amax_f32's, amax_dx, amax_din, ...) is an atomic maximum: the word must hold 0 (or a lower
+ * bound) on entry -- the library launches no memset for it.
  * amax_dy == NULL: no scaling (values must then lie in f16's range).  The weight operand is normalised the same way when
  * its planes are prepared (PREPARE / RUN as above: dY NULL = prepare from W, W NULL = run); the activation operand X of
  * the weight gradient is taken as it is (|x| < 65504; below |x| ~ 0.1 its correction term has an absolute error floor of
@@ -312,11 +314,13 @@ int svr_linear_bwd_weight_f16x3(const float *dY, int64_t lddy, const float *X, i
 int svr_fc_out_fwd(const float *H, int64_t ldh, const float *w, const float *b, float *logits,
                    const int32_t *row_map, int64_t M, int64_t K, void *stream);
 /* With g[m] = dlogits[r(m)]:  dH[m,k] = g[m]*w[k]*(H[m,k]>0);  dw[k] = sum_m g[m]*H[m,k];
- * db = sum g.  workspace: svr_fc_out_bwd_workspace() bytes.                                 */
+ * db = sum g.  workspace: svr_fc_out_bwd_workspace() bytes.  amax_dh (may be NULL; must hold 0 on entry):
+ * receives the bit pattern of max |dH| -- the scale of the next layer's "f16x3s" products, see
+ * svr_linear_bwd_data_f16x3.                                                                 */
 int64_t svr_fc_out_bwd_workspace(int64_t M, int64_t K);
 int svr_fc_out_bwd(const float *H, int64_t ldh, const float *w, const float *dlogits,
                    const int32_t *row_map, float *dH, int64_t lddh, float *dw, float *db, int64_t M,
-                   int64_t K, void *workspace, void *stream);
+                   int64_t K, uint32_t *amax_dh, void *workspace, void *stream);
 
 /* BCE-with-logits, reduction 'none' -> sum over points -> mean over batch
  * (trainer/trainer_ifnet.py:46).  loss: 1 float; dlogits (B,N) = gscale*(sigmoid(z)-y)/B
@@ -448,7 +452,8 @@ int svr_bn_bwd_reduce(const float *x, const float *dy, const float *dpooled, con
 int svr_bn_bwd_apply(const float *x, const float *dy, const float *dpooled, const uint8_t *argmax,
                      const float *mean_f32, const float *scale_shift, const float *gamma,
                      const double *sums, float *dx, float *dgamma, float *dbeta, int32_t B,
-                     int32_t D, int32_t H, int32_t W, int32_t C, int relu_mask, void *stream);
+                     int32_t D, int32_t H, int32_t W, int32_t C, int relu_mask, uint32_t *amax_dx,
+                     void *stream);   /* amax_dx (may be NULL; 0 on entry): bit pattern of max |dx|, as svr_fc_out_bwd's */
 
 /* ---------------------------------------------------------------------------------------
  * First encoder stage of the 128-architecture as one recomputed unit (stage1.hip):

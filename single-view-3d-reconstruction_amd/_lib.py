@@ -89,7 +89,7 @@ SIGNATURES = {
     "svr_linear_bwd_weight_f16x3": (C.c_int, [P, I64, P, I64, P, I64, P, I64, I64, I64, P, P, P]),
     "svr_fc_out_fwd": (C.c_int, [P, I64, P, P, P, P, I64, I64, P]),
     "svr_fc_out_bwd_workspace": (I64, [I64, I64]),
-    "svr_fc_out_bwd": (C.c_int, [P, I64, P, P, P, P, I64, P, P, I64, I64, P, P]),
+    "svr_fc_out_bwd": (C.c_int, [P, I64, P, P, P, P, I64, P, P, I64, I64, P, P, P]),
     "svr_bce_logits_sum_mean": (C.c_int, [P, P, P, P, I64, I64, F32, P, P]),
     "svr_conv3d_pack_weight": (C.c_int, [P, P, P, I32, I32, P]),
     "svr_conv3d_unpack_wgrad": (C.c_int, [P, P, I32, I32, P]),
@@ -119,7 +119,7 @@ SIGNATURES = {
     "svr_bn_finalize": (C.c_int, [P, P, P, P, P, P, P, I64, I32, F32, F32, C.c_int, P]),
     "svr_bn_apply_pool": (C.c_int, [P, P, P, P, P, I32, I32, I32, I32, I32, P]),
     "svr_bn_bwd_reduce": (C.c_int, [P, P, P, P, P, P, P, I32, I32, I32, I32, I32, P, P]),
-    "svr_bn_bwd_apply": (C.c_int, [P, P, P, P, P, P, P, P, P, P, P, I32, I32, I32, I32, I32, C.c_int, P]),
+    "svr_bn_bwd_apply": (C.c_int, [P, P, P, P, P, P, P, P, P, P, P, I32, I32, I32, I32, I32, C.c_int, P, P]),
     "svr_stage1_supported": (I32, [I32, I32, I32, I32, I32]),
     "svr_stage1_workspace": (I64, [I32, I32, I32, I32]),
     "svr_stage1_fwd": (C.c_int, [P, P, P, P, P, P, P, P, P, P, P, P, P, I32, I32, I32, I32, I32, F32, F32, C.c_int, C.c_int, P, P]),

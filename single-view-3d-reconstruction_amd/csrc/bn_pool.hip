@@ -206,7 +206,9 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(const float *__restrict__ x
                                                      const float *__restrict__ mean, const float *__restrict__ ss,
                                                      const double *__restrict__ sums, double *__restrict__ part,
                                                      float *__restrict__ dx, Vol v, int64_t cells, int relu_mask,
-                                                     float *__restrict__ dgamma, float *__restrict__ dbeta) {
+                                                     float *__restrict__ dgamma, float *__restrict__ dbeta,
+                                                     uint32_t *__restrict__ amax_dx) {
+  float vmax = 0.f;   // APPLY: |max| of the dx this thread stores (amax_dx: the scale of the next "f16x3s" product, no extra pass)
   if (APPLY && blockIdx.x == 0 && (int)threadIdx.x < v.C) {   // dgamma = sum dy*xhat, dbeta = sum dy (no extra launch)
     if (dbeta) dbeta[threadIdx.x] = (float)sums[threadIdx.x];
     if (dgamma) dgamma[threadIdx.x] = (float)sums[v.C + threadIdx.x];
@@ -286,6 +288,7 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(const float *__restrict__ x
             if ((relu_mask & 1) && !(av[i] > 0.f)) o[i] = 0.f;
           }
           *reinterpret_cast<float4 *>(dx + off) = make_float4(o[0], o[1], o[2], o[3]);
+          vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(o[0]), fabsf(o[1]))), fmaxf(fabsf(o[2]), fabsf(o[3])));
         } else {
 #pragma unroll
           for (int i = 0; i < 4; ++i) { f1[i] += gg[i]; f2[i] += gg[i] * xh[i]; }
@@ -296,6 +299,9 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(const float *__restrict__ x
 #pragma unroll
       for (int i = 0; i < 4; ++i) { s1[i] += (double)f1[i]; s2[i] += (double)f2[i]; }
     }
+  }
+  if (APPLY && amax_dx) {  // (uniform)
+svr_amax_publish(amax_dx, vmax);
   }
   if (!APPLY) {
     __shared__ double red[256 * 8];
@@ -445,7 +451,8 @@ extern "C" int svr_bn_bwd_reduce(const float *x, const float *dy, const float *d
   SVR_CHECK(cells < (1LL << 32), SVR_E_UNSUPPORTED, "bn_bwd: %ld cells (32-bit index arithmetic)", (long)cells);
   int blocks = bwd_blocks(cells, C);
   hipLaunchKernelGGL(bn_bwd_kernel<false>, dim3(blocks), dim3(256), 0, s, x, dy, dpooled, argmax, mean_f32, scale_shift,
-                     (const double *)nullptr, (double *)workspace, (float *)nullptr, v, cells, 0, (float *)nullptr, (float *)nullptr);
+                     (const double *)nullptr, (double *)workspace, (float *)nullptr, v, cells, 0, (float *)nullptr, (float *)nullptr,
+                     (uint32_t *)nullptr);
   hipLaunchKernelGGL(sum_parts_kernel, dim3(2 * C), dim3(256), 0, s, (const double *)workspace, sums, 2 * C, blocks);
   return launch_status("bn_bwd_reduce");
 }
@@ -453,7 +460,7 @@ extern "C" int svr_bn_bwd_reduce(const float *x, const float *dy, const float *d
 extern "C" int svr_bn_bwd_apply(const float *x, const float *dy, const float *dpooled, const uint8_t *argmax,
                                 const float *mean_f32, const float *scale_shift, const float *gamma, const double *sums,
                                 float *dx, float *dgamma, float *dbeta, int32_t B, int32_t D, int32_t H, int32_t W,
-                                int32_t C, int relu_mask, void *stream) {
+                                int32_t C, int relu_mask, uint32_t *amax_dx, void *stream) {
   (void)gamma;
   if (int rc = check_c(C)) return rc;
   SVR_CHECK(x && mean_f32 && scale_shift && sums && dx, SVR_E_BADARG, "bn_bwd_apply: null pointer");
@@ -466,6 +473,6 @@ extern "C" int svr_bn_bwd_apply(const float *x, const float *dy, const float *dp
   int64_t blocks = cdiv(cells, CL);
   if (blocks > 65535 * 16) blocks = 65535 * 16;
   hipLaunchKernelGGL(bn_bwd_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, x, dy, dpooled, argmax, mean_f32,
-                     scale_shift, sums, (double *)nullptr, dx, v, cells, relu_mask, dgamma, dbeta);
+                     scale_shift, sums, (double *)nullptr, dx, v, cells, relu_mask, dgamma, dbeta, amax_dx);
   return launch_status("bn_bwd_apply");
 }

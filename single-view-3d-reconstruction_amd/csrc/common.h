@@ -34,6 +34,20 @@ size_t scan_sum_excl_i32_temp_bytes(int64_t n);
 hipError_t scan_sum_excl_i32(void *tmp, size_t tmp_bytes, const int32_t *in, int32_t *out, int64_t n, hipStream_t s);
 }  // namespace svr
 
+#ifdef __HIPCC__
+// Publish a wave's |max| into an amax word (bit pattern of a non-negative float; unsigned order = float order).  Tens of
+// thousands of waves hit ONE address: an atomic per wave cost 0.25 ms on a 0.26 ms BatchNorm pass -- so the wave first reads the
+// word (a stale, smaller value only costs an atomic that changes nothing) and issues the atomic only if it would raise it.
+__device__ __forceinline__ void svr_amax_publish(uint32_t *amax, float vmax) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));
+  if ((threadIdx.x & 63) == 0) {
+    const uint32_t bits = __float_as_uint(vmax);
+    if (bits > *reinterpret_cast<volatile uint32_t *>(amax)) atomicMax(amax, bits);
+  }
+}
+#endif
+
 #define SVR_CHECK(cond, code, ...)      \
   do {                                  \
     if (!(cond)) {                      \

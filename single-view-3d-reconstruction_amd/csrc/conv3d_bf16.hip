@@ -407,9 +407,7 @@ __global__ __launch_bounds__(256) void conv3d_brick_x3_kernel(const float *__res
     }
   }
   if (amax_out) {  // (uniform)
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));
-    if (lane == 0 && vmax > 0.f) atomicMax(amax_out, __float_as_uint(vmax));
+svr_amax_publish(amax_out, vmax);
   }
   if (spart) {  // (uniform) lanes l31 / l31 + 32 of the four waves hold the same channel: fixed-order f64 sum of the 8 partials
     float *red = reinterpret_cast<float *>(&sw[0][0][0][0]);   // the weight buffers are free now: [thread][TNB][2] floats
@@ -734,9 +732,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_brick_p_kernel(const float *__r
     cur = nxt;
   }
   if (amax_out) {  // (uniform) |max| of everything this workgroup stored
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));
-    if (lane == 0 && vmax > 0.f) atomicMax(amax_out, __float_as_uint(vmax));
+svr_amax_publish(amax_out, vmax);
   }
 }
 
@@ -839,7 +835,6 @@ extern "C" int svr_conv3d_k3_bwd_data_f16x3(const float *dout, const float *W, f
   if (!dout) return launch_status("conv3d_bwd_data_f16x3 (prepare)");
   SVR_CHECK(B > 0 && D > 0 && H > 0 && Wd > 0, SVR_E_BADSHAPE, "conv3d_bwd_data_f16x3: empty volume");
   SVR_CHECK(epilogue == SVR_EPI_NONE || (epilogue == SVR_EPI_MASK && mask), SVR_E_BADARG, "conv3d_bwd_data_f16x3: epilogue %d", epilogue);
-  if (amax_din) (void)hipMemsetAsync(amax_din, 0, sizeof(uint32_t), s);
   ConvShape sh{B, D, H, Wd, /*K=*/Co, /*NOUT=*/Ci};
   const int nbz = (int)cdiv(D, BRZ), nby = (int)cdiv(H, BRY), nbx = (int)cdiv(Wd, BRX);
   const unsigned bricks = (unsigned)((int64_t)B * nbz * nby * nbx);

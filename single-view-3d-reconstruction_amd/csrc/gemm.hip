@@ -205,7 +205,8 @@ __global__ __launch_bounds__(256) void fc_out_bwd_kernel(const float *__restrict
                                                          const float *__restrict__ dlogits,
                                                          const int32_t *__restrict__ row_map, float *__restrict__ dH,
                                                          int64_t lddh, float *__restrict__ part, int64_t M, int64_t K,
-                                                         int64_t rows_per_block) {
+                                                         int64_t rows_per_block, uint32_t *__restrict__ amax_dh) {
+  float vmax = 0.f;
   // thread t owns columns t, t+256, ... ; rows looped (coalesced across the wave per row)
   int64_t r0 = (int64_t)blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
   for (int64_t k = threadIdx.x; k < K; k += blockDim.x) {
@@ -213,9 +214,14 @@ __global__ __launch_bounds__(256) void fc_out_bwd_kernel(const float *__restrict
     for (int64_t m = r0; m < r1; ++m) {
       float h = H[m * ldh + k], g = dlogits[row_map ? (int64_t)row_map[m] : m];
       s += g * h;
-      dH[m * lddh + k] = h > 0.f ? g * wk : 0.f;
+      const float d = h > 0.f ? g * wk : 0.f;
+      dH[m * lddh + k] = d;
+      vmax = fmaxf(vmax, fabsf(d));
     }
     part[(int64_t)blockIdx.x * (K + 1) + k] = s;
+  }
+  if (amax_dh) {  // (uniform)
+svr_amax_publish(amax_dh, vmax);
   }
   if (threadIdx.x == 0) {
     float s = 0.f;
@@ -231,7 +237,8 @@ __global__ __launch_bounds__(256) void fc_out_bwd_k256_kernel(const float *__res
                                                               const float *__restrict__ dlogits,
                                                               const int32_t *__restrict__ row_map, float *__restrict__ dH,
                                                               int64_t lddh, float *__restrict__ part, int64_t M,
-                                                              int64_t rows_per_block) {
+                                                              int64_t rows_per_block, uint32_t *__restrict__ amax_dh) {
+  float vmax = 0.f;
   __shared__ float gs[512];
   __shared__ float red[4][257];
   const int t = threadIdx.x, c4 = (t & 63) * 4, rs = t >> 6;
@@ -254,11 +261,15 @@ __global__ __launch_bounds__(256) void fc_out_bwd_k256_kernel(const float *__res
       if (i < nr) {
         const float g = gs[i];
         s.x += g * h[u].x; s.y += g * h[u].y; s.z += g * h[u].z; s.w += g * h[u].w;
-        *reinterpret_cast<float4 *>(dH + (r0 + i) * lddh + c4) =
-            make_float4(h[u].x > 0.f ? g * wk.x : 0.f, h[u].y > 0.f ? g * wk.y : 0.f, h[u].z > 0.f ? g * wk.z : 0.f,
-                        h[u].w > 0.f ? g * wk.w : 0.f);
+        const float4 d = make_float4(h[u].x > 0.f ? g * wk.x : 0.f, h[u].y > 0.f ? g * wk.y : 0.f, h[u].z > 0.f ? g * wk.z : 0.f,
+                                     h[u].w > 0.f ? g * wk.w : 0.f);
+        *reinterpret_cast<float4 *>(dH + (r0 + i) * lddh + c4) = d;
+        vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(d.x), fabsf(d.y))), fmaxf(fabsf(d.z), fabsf(d.w)));
       }
     }
+  }
+  if (amax_dh) {  // (uniform) |max| of the stored dH: the scale of the next layer's "f16x3s" products
+svr_amax_publish(amax_dh, vmax);
   }
   red[rs][c4] = s.x; red[rs][c4 + 1] = s.y; red[rs][c4 + 2] = s.z; red[rs][c4 + 3] = s.w;
   __syncthreads();
@@ -428,17 +439,17 @@ namespace { constexpr int64_t FCO_ROWS = 512; }
 extern "C" int64_t svr_fc_out_bwd_workspace(int64_t M, int64_t K) { return cdiv(M > 0 ? M : 1, FCO_ROWS) * (K + 1) * (int64_t)sizeof(float); }
 
 extern "C" int svr_fc_out_bwd(const float *H, int64_t ldh, const float *w, const float *dlogits, const int32_t *row_map,
-                              float *dH, int64_t lddh, float *dw, float *db, int64_t M, int64_t K, void *workspace,
-                              void *stream) {
+                              float *dH, int64_t lddh, float *dw, float *db, int64_t M, int64_t K, uint32_t *amax_dh,
+                              void *workspace, void *stream) {
   SVR_CHECK(H && w && dlogits && dH && dw && workspace, SVR_E_BADARG, "fc_out_bwd: null pointer");
   SVR_CHECK(M > 0 && K > 0, SVR_E_BADSHAPE, "fc_out_bwd: M=%ld K=%ld", (long)M, (long)K);
   hipStream_t s = (hipStream_t)stream;
   int blocks = (int)cdiv(M, FCO_ROWS);
   float *part = (float *)workspace;
   if (K == 256 && ldh % 4 == 0 && lddh % 4 == 0 && ((((uintptr_t)H | (uintptr_t)dH | (uintptr_t)w)) & 15) == 0)
-    hipLaunchKernelGGL(fc_out_bwd_k256_kernel, dim3((unsigned)blocks), dim3(256), 0, s, H, ldh, w, dlogits, row_map, dH, lddh, part, M, FCO_ROWS);
+    hipLaunchKernelGGL(fc_out_bwd_k256_kernel, dim3((unsigned)blocks), dim3(256), 0, s, H, ldh, w, dlogits, row_map, dH, lddh, part, M, FCO_ROWS, amax_dh);
   else
-    hipLaunchKernelGGL(fc_out_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, s, H, ldh, w, dlogits, row_map, dH, lddh, part, M, K, FCO_ROWS);
+    hipLaunchKernelGGL(fc_out_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, s, H, ldh, w, dlogits, row_map, dH, lddh, part, M, K, FCO_ROWS, amax_dh);
   hipLaunchKernelGGL(fc_out_bwd_final_kernel, dim3((unsigned)(K + 1)), dim3(256), 0, s, part, dw, db, K, blocks);
   return launch_status("fc_out_bwd");
 }

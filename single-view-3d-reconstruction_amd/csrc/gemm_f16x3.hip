@@ -211,31 +211,100 @@ __global__ __launch_bounds__(2 * TN, 1024 / (2 * TN) >= 4 ? 3 : 2) void linear_n
   float inv = w_scale(amax[0], true);
   if constexpr (BWD) inv *= amax_x ? w_scale(amax_x[0], true) : 1.f;
   float vmax = 0.f;
+  // Epilogue.  TN = 128 and float4-able output (round 4): the 128 x 128 tile goes through LDS in two passes of 64 rows (the
+  // operand stages are free behind the loop's last barrier: 32 KB = 64 x 128 floats, rows unpadded -- the accumulator
+  // stores of a wave are 32 consecutive dwords per row, the float4 reads 512 contiguous bytes per row: conflict free), so
+  // that a thread issues 16 float4 stores (and mask loads) on full 512-byte rows instead of 64 dword ones on 128-byte
+  // segments; bias / ReLU / mask / scale / |max| are applied on the way out.
+  const bool coal = TN == 128 && N % 4 == 0 && ldy % 4 == 0 && (((uintptr_t)Y) & 15) == 0 && (!BWD || !mask || (ldm % 4 == 0 && (((uintptr_t)mask) & 15) == 0));
+  if (coal) {
+    float *ct = reinterpret_cast<float *>(lds);
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+      float4 k4[8];
+      if constexpr (BWD) {   // this pass's ReLU mask, all loads up front from clamped coordinates
+        if (mask) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const int64_t m = m0 + 64 * pass + (t >> 5) + 8 * i, c = n0 + (t & 31) * 4;
+            k4[i] = *reinterpret_cast<const float4 *>(mask + (m < M ? m : M - 1) * ldm + (c < N ? c : N - 4));
+          }
+        }
+      }
+      if (wr == pass) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+              ct[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * 128 + wc * 64 + j * 32 + l31] = acc[i][j][r];
+      }
+      __syncthreads();
+      const int c4 = (t & 31) * 4;
+      const int64_t c = n0 + c4;
+      float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (bias && c < N) b4 = *reinterpret_cast<const float4 *>(bias + c);   // N % 4 == 0: never straddles the edge
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int row = (t >> 5) + 8 * i;
+        const int64_t m = m0 + 64 * pass + row;
+        if (m < M && c < N) {
+          float4 v = *reinterpret_cast<const float4 *>(ct + row * 128 + c4);
+          v.x = v.x * inv + b4.x; v.y = v.y * inv + b4.y; v.z = v.z * inv + b4.z; v.w = v.w * inv + b4.w;
+          if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+          if constexpr (BWD) {
+            if (mask) {
+              v.x = k4[i].x > 0.f ? v.x : 0.f; v.y = k4[i].y > 0.f ? v.y : 0.f;
+              v.z = k4[i].z > 0.f ? v.z : 0.f; v.w = k4[i].w > 0.f ? v.w : 0.f;
+            }
+            vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+          }
+          *reinterpret_cast<float4 *>(Y + m * ldy + c) = v;
+        }
+      }
+      __syncthreads();
+    }
+  } else {
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int64_t n = n0 + wc * 64 + j * 32 + l31;
       const float bv = (bias && n < N) ? bias[n] : 0.f;
+      float mk[16];
+      if constexpr (BWD) {
+        // the ReLU mask of the tile: all 16 loads issued together, unconditionally and from clamped coordinates (a load inside
+        // the bounds branch below is waited for on its own: 64 serial memory round trips per thread, +0.4 ms per layer)
+        if (mask) {
+          const int64_t nc = n < N ? n : N - 1;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int64_t m = m0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            mk[r] = mask[(m < M ? m : M - 1) * ldm + nc];
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) mk[r] = 1.f;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int64_t m = m0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        float v = acc[i][j][r] * inv + bv;
+        if (relu) v = fmaxf(v, 0.f);
+        if constexpr (BWD) v = mk[r] > 0.f ? v : 0.f;
         if (m < M && n < N) {
-          float v = acc[i][j][r] * inv + bv;
-          if (relu) v = fmaxf(v, 0.f);
-          if constexpr (BWD) {
-            if (mask) v = mask[m * ldm + n] > 0.f ? v : 0.f;
-            vmax = fmaxf(vmax, fabsf(v));
-          }
+          if constexpr (BWD) vmax = fmaxf(vmax, fabsf(v));
           Y[m * ldy + n] = v;
         }
       }
     }
+  }
   if constexpr (BWD) {
     if (amax_y) {   // |max| of this workgroup's part of dX (non-negative floats order like unsigned integers)
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));
-      if (lane == 0 && vmax > 0.f) atomicMax(amax_y, __float_as_uint(vmax));
+svr_amax_publish(amax_y, vmax);
     }
   }
 }
@@ -250,9 +319,7 @@ __global__ __launch_bounds__(256) void amax_rows_kernel(const float *__restrict_
     const float4 v = *reinterpret_cast<const float4 *>(X + (i / q) * ld + (i % q) * 4);
     m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
   }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-  if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(amax, __float_as_uint(m));
+  svr_amax_publish(amax, m);
 }
 
 }  // namespace
@@ -298,7 +365,6 @@ extern "C" int svr_linear_fwd_f16x3(const float *X, int64_t ldx, const float *W,
 extern "C" int svr_amax_f32(const float *X, int64_t ld, int64_t M, int64_t N, uint32_t *amax, void *stream) {
   SVR_CHECK(amax, SVR_E_BADARG, "amax_f32: null pointer");
   hipStream_t s = (hipStream_t)stream;
-  (void)hipMemsetAsync(amax, 0, sizeof(uint32_t), s);
   if (M * N == 0) return SVR_OK;
   SVR_CHECK(X && N % 4 == 0 && ld % 4 == 0 && ((uintptr_t)X & 15) == 0, SVR_E_ALIGN, "amax_f32: N, ld multiples of 4, 16-byte aligned");
   hipLaunchKernelGGL(amax_rows_kernel, dim3((unsigned)std::min<int64_t>(cdiv(M * (N / 4), 1024), 2048)), dim3(256), 0, s, X, ld, M, N, amax);
@@ -325,7 +391,6 @@ extern "C" int svr_linear_bwd_data_f16x3(const float *dY, int64_t lddy, const fl
   if (!dY) return launch_status("linear_bwd_data_f16x3 (prepare)");
   SVR_CHECK(lddy % 4 == 0 && ((uintptr_t)dY & 15) == 0, SVR_E_ALIGN, "linear_bwd_data_f16x3: dY must be 16-byte aligned");
   SVR_CHECK(epilogue == SVR_EPI_NONE || (epilogue == SVR_EPI_MASK && mask), SVR_E_BADARG, "linear_bwd_data_f16x3: epilogue %d", epilogue);
-  if (amax_dx) (void)hipMemsetAsync(amax_dx, 0, sizeof(uint32_t), s);
   const float *mk = epilogue == SVR_EPI_MASK ? mask : nullptr;
   dim3 grid(xcd_grid(cdiv(K, 128) * cdiv(M, TM)));
   hipLaunchKernelGGL((linear_nt_h3_kernel<128, 0, 2, true>), grid, dim3(256), 0, s, dY, lddy, p0, amax, (const float *)nullptr, dX, lddx,

@@ -671,12 +671,48 @@ def linear_fwd(x, w, bias, relu=True, out=None, mode=None):
     return out
 
 
-# Arithmetic of the two backward GEMMs of the point MLP: "bf16x3" (3-term bf16 split on the bf16 matrix cores,
-# ~1.5e-5 relative per product, see gemm_bf16x3.hip), "f16x3s" (the SCALED 3-product f16 split: gradient operands brought
-# into f16's range by an exact power of two taken from their |max|, 22 mantissa bits per operand = f32 level, the same
-# three matrix instructions per block; gemm_f16x3.hip / gemm_bf16x3.hip) or "f32" (exact-f32 MFMA).  The forward never uses it.
-BACKWARD_GEMM = os.environ.get("SVR_BACKWARD", "bf16x3")
+# Arithmetic of the two backward GEMMs of the point MLP: "f16x3s" (DEFAULT since round 4: the SCALED 3-product f16 split --
+# gradient operands brought into f16's range by an exact power of two taken from their |max|, 22 mantissa bits per operand =
+# f32 level like the reference's fp32 backward, the same three matrix instructions per block; gemm_f16x3.hip /
+# gemm_bf16x3.hip), "bf16x3" (3-term bf16 split, ~1.5e-5 relative per product: 4 % faster per step, the default of rounds
+# 1-3; SVR_BACKWARD=bf16x3) or "f32" (exact-f32 MFMA).  The forward never uses them.
+BACKWARD_GEMM = os.environ.get("SVR_BACKWARD", "f16x3s")
 BACKWARD_MODES = ("bf16x3", "f16x3s", "f32")
+
+
+class _AmaxSlots:
+    """Zero-initialised int32 words for the atomic-maximum outputs of the "f16x3s" kernels, without a memset launch and an
+    allocator call per word: one ring of 512 words per (device, stream), its halves zeroed alternately by ONE fill each
+    time the ring enters them -- a half is reused ~250 words (several training steps) after its words were handed out, by
+    when the tensors that referred to them are gone.  A word is produced and zeroed on the stream that owns the ring; a
+    consumer on another stream is ordered behind the producer by the same event that orders it behind the tensor itself."""
+    N = 512
+
+    def __init__(self):
+        self._rings = {}
+
+    def take(self, device):
+        if torch.cuda.is_current_stream_capturing():      # a replayed graph must zero its words itself
+            return torch.zeros(1, device=device, dtype=torch.int32)
+        key = (device, torch.cuda.current_stream(device).cuda_stream)
+        r = self._rings.get(key)
+        if r is None:
+            r = self._rings[key] = {"buf": torch.zeros(self.N, device=device, dtype=torch.int32), "i": 0}
+        i = r["i"]
+        if i % (self.N // 2) == 0 and (i or r.get("lap")):    # entering a half whose words were used a lap ago
+            r["buf"][i:i + self.N // 2].zero_()
+        r["i"] = (i + 1) % self.N
+        if r["i"] == 0:
+            r["lap"] = True
+        return r["buf"][i:i + 1]
+
+
+_amax_slots = _AmaxSlots()
+
+
+def amax_slot(device):
+    """A zeroed (1,) int32 word for an amax output."""
+    return _amax_slots.take(device)
 
 
 def amax_of(t):
@@ -687,7 +723,7 @@ def amax_of(t):
     if a is not None:
         return a
     _f32(t)
-    a = torch.empty(1, device=t.device, dtype=torch.int32)
+    a = amax_slot(t.device)
     if t.dim() == 2 and t.stride(1) == 1 and t.shape[1] % 4 == 0 and t.stride(0) % 4 == 0 and t.data_ptr() % 16 == 0:
         M, N, ld, src = t.shape[0], t.shape[1], t.stride(0), t
     else:
@@ -718,7 +754,7 @@ def linear_bwd_data(dy, w, mask=None, out=None, mode=None):
             assert w.stride(1) == 1
             ws = torch.empty(l.svr_linear_bwd_data_f16x3_workspace(N, K), device=dy.device, dtype=torch.uint8)
         amax_dy = amax_of(dy)
-        amax_dx = torch.empty(1, device=dy.device, dtype=torch.int32)
+        amax_dx = amax_slot(dy.device)
         check(l.svr_linear_bwd_data_f16x3(C.c_void_p(dy.data_ptr()), dy.stride(0), wptr, w.stride(0),
                                           C.c_void_p(out.data_ptr()), out.stride(0), M, N, K, epi,
                                           C.c_void_p(mask.data_ptr()) if mask is not None else C.c_void_p(0),
@@ -793,8 +829,11 @@ def fc_out_bwd(h, w, dlogits, row_map=None):
     dh = torch.empty(M, K, device=h.device, dtype=torch.float32)
     dw = torch.empty(K, device=h.device, dtype=torch.float32)
     db = torch.empty(1, device=h.device, dtype=torch.float32)
+    amax = amax_slot(h.device) if BACKWARD_GEMM == "f16x3s" else None       # |max| of dh for the next layer's scaled split
     check(l.svr_fc_out_bwd(_p(h), h.stride(0), _p(w), _p(dlogits), _p(row_map), _p(dh), dh.stride(0), _p(dw), _p(db), M, K,
-                           _p(ws), _stream()), "fc_out_bwd")
+                           _p(amax), _p(ws), _stream()), "fc_out_bwd")
+    if amax is not None:
+        dh._svr_amax = amax
     return dh, dw, db
 
 
@@ -846,7 +885,7 @@ def conv3d_k3(x, wp, bias=None, relu=False, mask=None):
 
 
 # Arithmetic of the encoder's backward-data convolutions: "bf16x3" (conv3d_bf16.hip) or "f32".
-BACKWARD_CONV = os.environ.get("SVR_BACKWARD", "bf16x3")     # "bf16x3", "f16x3s" (scaled f16 split: f32 level) or "f32"
+BACKWARD_CONV = os.environ.get("SVR_BACKWARD", "f16x3s")     # "bf16x3", "f16x3s" (scaled f16 split: f32 level) or "f32"
 # ... and of its forward convolutions: "f16x3" (3-product f16 split, f32-level accuracy for |x| < 65504), "bf16x6"
 # (6-product bf16 split, any f32 range) or "f32" (exact-f32 MFMA)
 FORWARD_CONV = "f16x3"
@@ -925,7 +964,7 @@ def conv3d_k3_bwd_data(dout, w, mask=None, mode=None):
         wptr = C.c_void_p(0) if ws is not None else _p(w)                          # W NULL: the workspace is prepared
         if ws is None:
             ws = torch.empty(l.svr_conv3d_bwd_data_f16x3_workspace(Ci, Co), device=dout.device, dtype=torch.uint8)
-        amax_din = torch.empty(1, device=dout.device, dtype=torch.int32)
+        amax_din = amax_slot(dout.device)
         check(l.svr_conv3d_k3_bwd_data_f16x3(_p(dout), wptr, _p(din), B, D, H, W, Ci, Co,
                                              EPI_MASK if mask is not None else EPI_NONE, _p(mask), _p(amax_of(dout)), _p(amax_din),
                                              _p(ws), _stream()), "conv3d_bwd_data_f16x3")
@@ -950,7 +989,7 @@ def conv3d_k3_bwd_data(dout, w, mask=None, mode=None):
 
 # Arithmetic of the encoder's weight gradients: "bf16x3" (conv3d_bwdw_bf16.hip), "f16x3s" (its scaled f16 form: f32 level)
 # or "f32" (exact-f32 MFMA)
-BACKWARD_CONV_WEIGHT = os.environ.get("SVR_BACKWARD", "bf16x3")
+BACKWARD_CONV_WEIGHT = os.environ.get("SVR_BACKWARD", "f16x3s")
 
 
 def conv3d_k3_bwd_weight(x, dout, want_bias=True, mode=None, param_layout=False):
@@ -1045,8 +1084,12 @@ def bn_backward(x, dy, dpooled, argmax, mean, ss, relu_mask=True, training=True)
     dx = torch.empty_like(x)
     dgamma = torch.empty(Cc, device=dev, dtype=torch.float32)
     dbeta = torch.empty(Cc, device=dev, dtype=torch.float32)
+    amax = amax_slot(dev) if "f16x3s" in (BACKWARD_CONV, BACKWARD_CONV_WEIGHT, BACKWARD_GEMM) else None
     check(l.svr_bn_bwd_apply(_p(x), _p(dy), _p(dpooled), _p(argmax), _p(mean), _p(ss), C.c_void_p(0), _p(sums), _p(dx),
-                             _p(dgamma), _p(dbeta), B, D, H, W, Cc, int(relu_mask) | (0 if training else 2), _stream()), "bn_bwd_apply")
+                             _p(dgamma), _p(dbeta), B, D, H, W, Cc, int(relu_mask) | (0 if training else 2), _p(amax), _stream()),
+          "bn_bwd_apply")
+    if amax is not None:
+        dx._svr_amax = amax         # |max| of dx: the scale of the convolution gradients' scaled f16 split, no extra pass
     return dx, dgamma, dbeta
 
 

@@ -14,6 +14,8 @@ Tolerances (SURVEY.md §7 hard part 1: rel = max|a-b| / max|b|):
   Adam step: the first update is lr*sign(g) (|g| >> eps), so a sign flip of a noise-level gradient
   element moves that weight by 2*lr: every element must be within 2.1*lr of the reference and at
   most 5% of a tensor's elements may differ by more than 1e-5*max|w|."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -150,12 +152,13 @@ def test_dense_grid_inference_matches_per_chunk_reference_loop():
 
 
 def test_gradient_arithmetic_ab_production_split_vs_exact_f32():
-    """What the production arithmetic (f16x3 forward GEMMs / convs, bf16x3 backward GEMMs / convs / weight gradients)
-    contributes to the gradients ON TOP of the mask-flip noise that the reference gates above have to allow: the same
-    cfg1 step on the GPU with the backward switches at "f32" (exact-f32 MFMA kernels) and at their production values.
-    The forward arithmetic is the production one in both runs (it is deterministic, so both backward passes see the
-    same ReLU masks / pool arg-maxes and the float atomics only differ in summation order): the difference isolates
-    the bf16x3 backward products -- every gradient tensor <= 1e-4 in L2 norm and <= 1e-3 in its largest element.  The
+    """What the backward arithmetic contributes to the gradients ON TOP of the mask-flip noise that the reference gates above
+    have to allow: the same cfg1 step on the GPU with the backward switches at "f32" (exact-f32 MFMA kernels, twice: what the
+    float atomics' summation order alone moves), at their production value "f16x3s" (the scaled 3-product f16 split, f32
+    LEVEL: the reference computes its backward in fp32, util/arguments.py:30) and at "bf16x3" (the faster optional mode, 16
+    mantissa bits per operand).  The forward arithmetic is the production one in every run (it is deterministic, so all
+    backward passes see the same ReLU masks / pool arg-maxes).  Gates: f16x3s within 4e-6 in L2 of the exact-f32 kernels on
+    EVERY gradient tensor (two exact-f32 runs differ by up to ~2e-6), bf16x3 within 1e-4 / 1e-3 in the largest element.  The
     forward switches are A/B-ed on the logits: 5e-5 (per kernel they are held to 2e-6 / 3e-6 in test_gpu_kernels.py)."""
     import svr_amd  # noqa: F401
     from svr_amd import ops
@@ -171,53 +174,41 @@ def test_gradient_arithmetic_ab_production_split_vs_exact_f32():
         bce_with_logits_sum_mean(logits, occ.cuda()).backward()
         return logits.detach().cpu(), {n: p.grad.detach().cpu().double() for n, p in m.named_parameters()}
 
-    try:
-        assert saved["BACKWARD_GEMM"] == "bf16x3" and saved["FORWARD_GEMM"] == "f16x3"      # the production defaults
-        lz_prod, g_prod = run()
+    def backward_mode(mode):
         for k in switches:
             if k.startswith("BACKWARD"):
-                setattr(ops, k, "f32")
+                setattr(ops, k, mode)
+
+    try:
+        if os.environ.get("SVR_BACKWARD") is None:
+            assert saved["BACKWARD_GEMM"] == saved["BACKWARD_CONV"] == saved["BACKWARD_CONV_WEIGHT"] == "f16x3s"   # the production defaults
+        assert saved["FORWARD_GEMM"] == "f16x3"
+        backward_mode("f16x3s")
+        lz_prod, g_prod = run()
+        backward_mode("f32")
         lz_same, g_exact = run()
         _, g_exact2 = run()               # the same arithmetic again: what the float atomics' summation order alone moves
-        for k in switches:
-            if k.startswith("BACKWARD"):
-                setattr(ops, k, "f16x3s")
-        lz_h, g_h = run()
+        backward_mode("bf16x3")
+        lz_b, g_b = run()
         for k in switches:
             setattr(ops, k, "f32")
         lz_exact, _ = run()
     finally:
         for k, v in saved.items():
             setattr(ops, k, v)
-    assert torch.equal(lz_prod, lz_same)                      # same forward bits -> same masks in both backward passes
+    assert torch.equal(lz_prod, lz_same) and torch.equal(lz_b, lz_same)   # same forward bits -> same masks in every backward pass
     assert G.rel_err(lz_prod.numpy(), lz_exact.numpy()) < 5e-5     # nine conv layers + BN deep: same order as vs the reference
-    worst = (0.0, 0.0, "")
-    for name, a in g_exact.items():
-        b = g_prod[name]
-        nrm = float((a - b).norm() / a.norm().clamp_min(1e-30))
-        mx = float((a - b).abs().max() / a.abs().max().clamp_min(1e-30))
-        worst = max(worst, (nrm, mx, name))
-        assert nrm < 1e-4 and mx < 1e-3, (name, nrm, mx)
-    print("A/B production vs exact-f32 arithmetic: worst gradient L2 diff %.2e (max-element %.2e) at %s" % worst)
-    # the f32-LEVEL backward mode (scaled f16 split, ops.BACKWARD_* = "f16x3s"): same forward bits, every
-    # gradient tensor within 2e-6 in L2 of the exact-f32 kernels' -- the level at which two f32 implementations differ
-    assert torch.equal(lz_h, lz_same)
-    worst_h, noise = (0.0, 0.0, ""), (0.0, 0.0, "")
     rows = []
     for name, a in g_exact.items():
-        b, a2 = g_h[name], g_exact2[name]
-        nrm = float((a - b).norm() / a.norm().clamp_min(1e-30))
-        mx = float((a - b).abs().max() / a.abs().max().clamp_min(1e-30))
-        n2 = float((a - a2).norm() / a.norm().clamp_min(1e-30))
-        noise = max(noise, (n2, float((a - a2).abs().max() / a.abs().max().clamp_min(1e-30)), name))
-        worst_h = max(worst_h, (nrm, mx, name))
-        rows.append((nrm, n2, float((a - g_prod[name]).norm() / a.norm().clamp_min(1e-30)), name))
+        def l2(b):
+            return float((a - b).norm() / a.norm().clamp_min(1e-30))
+        mxb = float((a - g_b[name]).abs().max() / a.abs().max().clamp_min(1e-30))
+        rows.append((l2(g_prod[name]), l2(g_exact2[name]), l2(g_b[name]), mxb, name))
     for r in sorted(rows, reverse=True)[:6]:
-        print("   L2 diff vs exact f32: f16x3s %.2e | exact f32 again %.2e | bf16x3 %.2e | %s" % r)
-    print("A/B f16x3s vs exact-f32 arithmetic: worst gradient L2 diff %.2e (max-element %.2e) at %s; two exact-f32 runs differ by "
-          "%.2e (max-element %.2e) at %s" % (worst_h + noise))
-    for nrm, n2, _, name in rows:
-        assert nrm < 4e-6, (name, nrm, n2)
+        print("   L2 diff vs exact f32: f16x3s %.2e | exact f32 again %.2e | bf16x3 %.2e (max-element %.2e) | %s" % r)
+    for h, n2, b, mxb, name in rows:
+        assert h < 4e-6, (name, h, n2)                 # production: f32 level
+        assert b < 1e-4 and mxb < 1e-3, (name, b, mxb)   # the optional 16-bit split
 
 
 def test_eval_mode_backward_matches_oracle():

@@ -763,11 +763,16 @@ def test_fused_gather_fc0_with_non_finite_volume_values():
     assert torch.equal(hb[~bad.cuda()], base[~bad.cuda()])
 
 
-def test_prepared_weight_planes_give_the_same_bits_and_expire():
+@pytest.mark.parametrize("bwd", ["f16x3s", "bf16x3"])
+def test_prepared_weight_planes_give_the_same_bits_and_expire(bwd):
     """include/svr_hip.h PREPARE / RUN: a split-precision layer run on a workspace prepared ahead (data operand NULL, then W
-    NULL) returns the bits of the one-call form, for all four entry points; ops.PreparedWeights serves a parameter's planes
-    only until the parameter is modified in place (an optimizer step) or invalidate()."""
+    NULL) returns the bits of the one-call form, for the forward entry points and the backward-data ones of both split modes
+    (the f32-level "f16x3s" default and "bf16x3"); ops.PreparedWeights serves a parameter's planes only until the parameter is
+    modified in place (an optimizer step) or invalidate()."""
     ops = _ops()
+    saved = (ops.BACKWARD_GEMM, ops.BACKWARD_CONV)
+    ops.BACKWARD_GEMM = ops.BACKWARD_CONV = bwd
+    kc, kl = ("cbh", "lbh") if bwd == "f16x3s" else ("cb", "lb")
     g = torch.Generator().manual_seed(77)
     x = torch.randn(2, 6, 5, 7, 32, generator=g).cuda()
     w = (torch.randn(64, 32, 3, 3, 3, generator=g) / 30).cuda()
@@ -776,19 +781,19 @@ def test_prepared_weight_planes_give_the_same_bits_and_expire():
     xm = torch.randn(3000, 256, generator=g).cuda()
     wl = (torch.randn(256, 256, generator=g) / 16).cuda()
     bl = torch.randn(256, generator=g).cuda()
-    base = (ops.conv3d_k3_fwd(x, w, b), ops.conv3d_k3_bwd_data(dy, w, mask=x), ops.linear_fwd(xm, wl, bl),
-            ops.linear_bwd_data(xm, wl, mask=xm))
-    prep = ops.PreparedWeights()
-    side = torch.cuda.Stream()
-    side.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(side):
-        prep.begin()
-        prep.add_conv(w)
-        prep.add_linear(wl)
-        prep.finish(side)
-    ops.set_prepared(prep)
     try:
-        assert all(prep.lookup(k, t) is not None for k, t in (("cf", w), ("cb", w), ("lf", wl), ("lb", wl)))
+        base = (ops.conv3d_k3_fwd(x, w, b), ops.conv3d_k3_bwd_data(dy, w, mask=x), ops.linear_fwd(xm, wl, bl),
+                ops.linear_bwd_data(xm, wl, mask=xm))
+        prep = ops.PreparedWeights()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            prep.begin()
+            prep.add_conv(w)
+            prep.add_linear(wl)
+            prep.finish(side)
+        ops.set_prepared(prep)
+        assert all(prep.lookup(k, t) is not None for k, t in (("cf", w), (kc, w), ("lf", wl), (kl, wl)))
         got = (ops.conv3d_k3_fwd(x, w, b), ops.conv3d_k3_bwd_data(dy, w, mask=x), ops.linear_fwd(xm, wl, bl),
                ops.linear_bwd_data(xm, wl, mask=xm))
         for a_, b_ in zip(base, got):
@@ -797,7 +802,7 @@ def test_prepared_weight_planes_give_the_same_bits_and_expire():
         assert ops._lookup("cf", w, "f32", "f16x3") is None and prep.lookup("cf", w.clone()) is None
         # an in-place update (optimizer step) expires the planes: the op prepares its own again and follows the new values
         w.mul_(2.0)
-        assert prep.lookup("cf", w) is None and prep.lookup("cb", w) is None and prep.lookup("lf", wl) is not None
+        assert prep.lookup("cf", w) is None and prep.lookup(kc, w) is None and prep.lookup("lf", wl) is not None
         zb = torch.zeros_like(b)
         y2 = ops.conv3d_k3_fwd(x, w, zb, relu=False)
         assert G.rel_err(y2.cpu().numpy(), (2 * ops.conv3d_k3_fwd(x, w / 2, zb, relu=False)).cpu().numpy()) < 1e-6
@@ -805,6 +810,7 @@ def test_prepared_weight_planes_give_the_same_bits_and_expire():
         assert prep.lookup("lf", wl) is None
     finally:
         ops.set_prepared(None)
+        ops.BACKWARD_GEMM, ops.BACKWARD_CONV = saved
 
 
 @pytest.mark.parametrize("B,dims,Ci,Co", [(2, (10, 6, 12), 16, 32), (1, (9, 9, 9), 32, 32), (2, (7, 5, 6), 32, 64), (1, (6, 6, 6), 64, 64),
