@@ -244,6 +244,7 @@ def main():
         sys.exit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {a.gpus}")
 
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # main + two side streams + RCCL's (see the package's __init__)
+    os.environ.setdefault("NCCL_DEBUG", "WARN")       # (RCCL's version banner goes to STDOUT at its default level: the compact line must stay the only JSON there)
     import torch
     import torch.distributed as dist
     import svr_amd  # noqa: F401
