@@ -37,6 +37,12 @@ using namespace svr;
 
 namespace {
 
+#ifdef SVR_FC0_MEASURE
+__device__ unsigned long long *fc_stamps = nullptr;   // measurement builds: timeline / debug buffer (svr_gather_fc0_stamps)
+__device__ const float *fc_dbg_pt0 = nullptr;         // ... and the point pointer of the tile whose geometry table is dumped
+__device__ int fc_dbg_C = 64;                         // ... at the level with this many channels
+#endif
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define GLOBAL_AS __attribute__((address_space(1)))
@@ -85,12 +91,26 @@ constexpr int FC_MAX_SLABS = 56;
 // from there with ds_read_b128 (16 lanes = one voxel's 256 bytes: all 64 banks, conflict free) -- same values, same order
 // of operations, bit-identical features.  The box of every (tile, level) comes from fc0_boxes_kernel (one wave per tile, in
 // front of the launch); a tile whose box is larger, or that straddles two samples, keeps the global loads (box.nvox = 0).
-constexpr int FC_STAGE_VOX = 160;
+#ifndef FC_GEO_CHECK
+#define FC_GEO_CHECK 0   // debug (measurement builds): both geometry forms, compared value by value inside the kernel
+#endif
+#ifndef FC_GEO_LDS
+// 1: per-level sample geometry of a tile in LDS (per row and AXIS: 9 KB) instead of 42 producer registers, which lets a producer
+// wave keep two passes in flight inside 128 VGPRs: 2.35 instead of 2.49 ms stand-alone.  NOT the default: with one or two passes
+// in flight (FC_DEPTH 1 / 2) some (row, displacement) items of the UPPER half-wave come out wrong (8-10 of 12 level checks of
+// tools/exp/dbg_fc0.py, the same rows from run to run within a build), with three (FC_DEPTH=3) every check passes.  Established
+// with measurement builds (tools/exp/dbg_geo*.py, FC_GEO_CHECK): the table is correct right after it is written (levels 2-3, ten
+// tiles, against a host restatement), two consecutive reads of an entry always agree (no concurrent writer), and when BOTH forms
+// are computed the LDS values equal the register values lane by lane (and the output is then right).  Extra s_waitcnt vmcnt(0) /
+// lgkmcnt(0) around the table, unmerged reads and unsigned lane arithmetic do not change it.  Cause not found -> not shipped.
+#define FC_GEO_LDS 0
+#endif
+constexpr int FC_STAGE_VOX = FC_GEO_LDS ? 144 : 160;   // (144: the geometry table takes 9 KB of the 80 KB a workgroup may use)
 constexpr int FC_STAGE_DW = FC_STAGE_VOX * 64;   // dwords of the staging region (64 channels per voxel)
 constexpr int FC_NSTAGE = 2;                     // at most two staged levels
 struct FcBox { int nvox, b, z0, y0, x0, by, bx, pad; };   // per (tile, staged level): 32 bytes, scalar loads
 #ifndef FC_DEPTH
-#define FC_DEPTH (FC_NPW == 8 ? 2 : 1)
+#define FC_DEPTH ((FC_NPW == 8 || FC_GEO_LDS) ? 2 : 1)
 #endif
 #ifndef FC_PRIO
 #define FC_PRIO 0  // s_setprio of the producer waves (the second-dispatched half of the workgroup loses VALU arbitration by age)
@@ -101,7 +121,14 @@ struct FcBox { int nvox, b, z0, y0, x0, by, bx, pad; };   // per (tile, staged l
 #ifndef FC_FMA
 #define FC_FMA 0   // corner sum: 0 = ATen's rounding (bit-identical to F.grid_sample), 1 = one v_pk_fma_f32 per step
 #endif
-constexpr int FC_LDS_BYTES = 2 * FSLAB * 4 + FC_STAGE_DW * 4;   // two slab buffers + the staging region
+// Geometry table (FC_GEO_LDS): per tile row 36 dwords = byte offsets [axis x, y, z][variant 0, -d, +d][corner 0, 1], then the
+// weights in the same order (0 where the corner lies outside the volume).  A displacement moves ONE axis, so the 7 x 3 axis
+// evaluations of a row's displacements are 9 distinct ones; a pass reads 3 + 3 eight-byte entries instead of 14 ds_bpermute
+// and keeps no geometry in registers -- which is what lets a producer wave have TWO passes in flight inside 128 VGPRs.
+constexpr int GEO_ROW_DW = 36;
+constexpr int FC_GEO_DW = FC_GEO_LDS ? FTM * GEO_ROW_DW : 0;
+constexpr int FC_LDS_BYTES = 2 * FSLAB * 4 + FC_STAGE_DW * 4 + FC_GEO_DW * 4;   // two slab buffers + the staging region + geometry
+static_assert(2 * FC_LDS_BYTES <= 160 * 1024 || FTM != 64, "two workgroups per CU");
 
 struct FcLevel {
   const float *vol;
@@ -249,25 +276,95 @@ __device__ __forceinline__ void level_geometry(const FcLevel L, const float *__r
   }
 }
 
+// FC_GEO_LDS: the wave's RPW rows x 9 (axis, variant) evaluations, one per lane and round, into the geometry table.  Only this wave
+// reads its rows' entries (LDS operations of a wave are ordered: no barrier).  Same operations in the same order as
+// sample_corner / corner_weights, so corner indices and weights are bit-identical.
+template <bool BF, bool STAGED>
+__device__ __forceinline__ void level_geometry_lds(const FcLevel L, const float *__restrict__ pt0, int last, int b0, int rem0, int N,
+                                                   float disp, int ac, int pw, int lane, const FcBox box, uint32_t *__restrict__ geo) {
+#if defined(FC_DBG_WAIT) && (FC_DBG_WAIT & 2)
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#endif
+  constexpr uint32_t EB = BF ? 2u : 4u;
+  constexpr int ITEMS = RPW * 9;
+  const GLOBAL_AS float *pg = (const GLOBAL_AS float *)pt0;
+#pragma unroll
+  for (int r = 0; r < (ITEMS + 63) / 64; ++r) {
+    const int idx = min(r * 64 + lane, ITEMS - 1);      // (the tail lanes redo the last item: same values, same address)
+    const int rl = idx / 9, av = idx % 9, axis = av / 3, var = av % 3;
+    const int row = min(RPW * pw + rl, last);
+    float g = 2.0f * pg[(uint32_t)row * 3u + (uint32_t)(2 - axis)];
+    if (var == 1) g = g + (-disp);
+    if (var == 2) g = g + disp;
+    const int S = axis == 0 ? L.W : (axis == 1 ? L.H : L.D);
+    const float i = unnormalize(g, S, ac), i0f = floorf(i);
+    const float w0 = (i0f + 1.0f) - i, w1 = i - i0f;
+    const int i0 = clamp_int(i0f);
+    const bool v0 = i0 >= 0 && i0 < S, v1 = i0 + 1 >= 0 && i0 + 1 < S;
+    const int c0 = min(max(i0, 0), S - 1), c1 = min(max(i0 + 1, 0), S - 1);
+    uint32_t o0, o1;
+    if constexpr (STAGED) {   // byte offsets inside the staged box: [z][y][x][64 channels of this half]
+      (void)b0; (void)rem0; (void)N;
+      const int base = axis == 0 ? box.x0 : (axis == 1 ? box.y0 : box.z0);
+      const int mul = axis == 0 ? 256 : (axis == 1 ? box.bx * 256 : box.by * box.bx * 256);
+      o0 = (uint32_t)((c0 - base) * mul);
+      o1 = (uint32_t)((c1 - base) * mul);
+    } else {
+      const int b = b0 + (int)((uint32_t)(rem0 + row) / (uint32_t)N);
+      const uint32_t mul = axis == 0 ? (uint32_t)L.C : (axis == 1 ? (uint32_t)(L.W * L.C) : (uint32_t)(L.H * L.W * L.C));   // host: < 2^30 elements
+      const uint32_t add = axis == 2 ? (uint32_t)(b * L.D) : 0u;
+      o0 = (add + (uint32_t)c0) * mul * EB;
+      o1 = (add + (uint32_t)c1) * mul * EB;
+    }
+    // (stored with the TYPES they are read back with in produce_slab -- u32x2_t offsets, f32x2_t weights: a float load may be
+    // moved across an unsigned store to the same address under strict aliasing, and was: wrong rows, run to run different)
+    LDS_AS char *d = (LDS_AS char *)geo + ((RPW * pw + rl) * GEO_ROW_DW + av * 2) * 4;
+    *reinterpret_cast<LDS_AS u32x2_t *>(d) = u32x2_t{o0, o1};
+    *reinterpret_cast<LDS_AS f32x2_t *>(d + 72) = f32x2_t{v0 ? w0 : 0.f, v1 ? w1 : 0.f};
+  }
+#if defined(FC_DBG_WAIT) && (FC_DBG_WAIT & 1)
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#else
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the table is complete before this wave's passes read it
+#endif
+#ifdef SVR_FC0_MEASURE
+  // debug dump (fc_stamps set, first tile only): level L.C == 64's table of this wave -> buffer rows [pw][16][36]
+  if (fc_stamps && pt0 == fc_dbg_pt0 && L.C == fc_dbg_C) {
+    uint32_t *dst = reinterpret_cast<uint32_t *>(fc_stamps) + pw * RPW * GEO_ROW_DW;
+    for (int i = lane; i < RPW * GEO_ROW_DW; i += 64) dst[i] = geo[RPW * pw * GEO_ROW_DW + i];
+  }
+#endif
+}
+
 template <int LP, int NJ, bool BF, bool STAGED = false>
 __device__ __forceinline__ void produce_slab(const FcLevel L, const FcSlab S, uint32_t *__restrict__ buf, int64_t m0, int64_t M,
                                              float *__restrict__ feat, int row_stride, int pw, int lane, const Geo &G,
-                                             const uint32_t *stage = nullptr) {
+                                             const uint32_t *stage = nullptr, const uint32_t *geo = nullptr) {
   constexpr int PPW0 = 64 / LP, PPW = PPW0 < RPW ? PPW0 : RPW, NP = RPW / PPW, LPI = LP / NJ, NC = LPI * 4, DEPTH = NP <= FC_DEPTH ? NP : (FC_DEPTH < 3 ? FC_DEPTH : 3);  // passes in flight (the fine levels miss the caches: all of a slab's passes)
   const int C = L.C;
   const GLOBAL_AS char *vol = (const GLOBAL_AS char *)L.vol;
   constexpr uint32_t EB = BF ? 2u : 4u;   // bytes per stored channel value
   // the register set that holds this slab's displacements (j0 is even for NJ == 2: both sit in one set)
   int ge[GEO_N];
+  if constexpr (!FC_GEO_LDS || FC_GEO_CHECK == 1) {
 #pragma unroll
-  for (int k = 0; k < GEO_N; ++k) ge[k] = G.v[0][k];
+    for (int k = 0; k < GEO_N; ++k) ge[k] = G.v[0][k];
 #pragma unroll
-  for (int r = 1; r < GEO_SETS; ++r)
-    if (S.j0 / GEO_IPS == r) {   // (wave uniform)
+    for (int r = 1; r < GEO_SETS; ++r)
+      if (S.j0 / GEO_IPS == r) {   // (wave uniform)
 #pragma unroll
-      for (int k = 0; k < GEO_N; ++k) ge[k] = G.v[r][k];
-    }
-  const int g = lane / LP, q = lane % LP, jj = q / LPI, c4 = (q % LPI) * 4;
+        for (int k = 0; k < GEO_N; ++k) ge[k] = G.v[r][k];
+      }
+  }
+  // (lane is opaque to the compiler here -- gather_fc0_kernel hides it per slab -- so its range is stated: unsigned shifts / masks
+  // instead of the signed-division sequences with 16-bit SDWA pieces that the unknown range produced)
+  const unsigned ul = (unsigned)lane & 63u;
+  const int g = (int)(ul / (unsigned)LP), q = (int)(ul % (unsigned)LP), jj = (int)((unsigned)q / (unsigned)LPI), c4 = (int)((unsigned)q % (unsigned)LPI) * 4;
+  // FC_GEO_LDS: byte addresses of this lane's three table entries (the displacement moves one axis) in row 0 of the wave
+  const int jd = S.j0 + jj;
+  const int gx8 = (jd == 1 ? 1 : (jd == 2 ? 2 : 0)) * 8, gy8 = (3 + (jd == 3 ? 1 : (jd == 4 ? 2 : 0))) * 8,
+            gz8 = (6 + (jd == 5 ? 1 : (jd == 6 ? 2 : 0))) * 8;
+  const LDS_AS char *grow = (const LDS_AS char *)geo + (RPW * pw + (g < RPW ? g : RPW - 1)) * (GEO_ROW_DW * 4);
   const int src0 = (((S.j0 + jj) % GEO_IPS) * RPW + g) << 2;   // + it * PPW rows
   const uint32_t xoff = STAGED ? (uint32_t)c4 * 4u : (uint32_t)(S.c0 + c4) * EB;
   const int col = jj * NC + c4;  // column inside the slab
@@ -289,10 +386,65 @@ __device__ __forceinline__ void produce_slab(const FcLevel L, const FcSlab S, ui
   auto fetch = [&](Iter &I, int it) {
     const int src = src0 + it * (PPW * 4);
     uint32_t zy[4], x[2];
+    if constexpr (FC_GEO_LDS) {
+      const LDS_AS char *gp = grow + it * (PPW * GEO_ROW_DW * 4);
+      const u32x2_t xo = *reinterpret_cast<const LDS_AS u32x2_t *>(gp + gx8), yo = *reinterpret_cast<const LDS_AS u32x2_t *>(gp + gy8),
+                    zo = *reinterpret_cast<const LDS_AS u32x2_t *>(gp + gz8);
+      zy[0] = zo.x + yo.x; zy[1] = zo.x + yo.y; zy[2] = zo.y + yo.x; zy[3] = zo.y + yo.y;
+      x[0] = xo.x + xoff; x[1] = xo.y + xoff;
+#if FC_GEO_CHECK == 2 && defined(SVR_FC0_MEASURE)
+      {   // read the three entries AGAIN (nothing may write them in between): differences = a concurrent writer
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const LDS_AS char *gp2 = gp;
+        asm volatile("" : "+v"(gp2));
+        const u32x2_t xo2 = *reinterpret_cast<const LDS_AS u32x2_t *>(gp2 + gx8), yo2 = *reinterpret_cast<const LDS_AS u32x2_t *>(gp2 + gy8),
+                      zo2 = *reinterpret_cast<const LDS_AS u32x2_t *>(gp2 + gz8);
+        const uint32_t a6[6] = {xo.x, xo.y, yo.x, yo.y, zo.x, zo.y}, b6[6] = {xo2.x, xo2.y, yo2.x, yo2.y, zo2.x, zo2.y};
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+          if (a6[i] != b6[i] && fc_stamps) {
+            const unsigned long long n = atomicAdd(fc_stamps, 1ull);
+            if (n < 200) {
+              unsigned long long *o = fc_stamps + 8 + n * 4;
+              o[0] = ((unsigned long long)blockIdx.x << 32) | (unsigned)(S.level << 24 | pw << 16 | lane << 8 | it << 4 | i);
+              o[1] = ((unsigned long long)a6[i] << 32) | b6[i];
+              o[2] = ((unsigned long long)(unsigned)S.j0 << 32) | (unsigned)(LP << 8 | NJ);
+              o[3] = 0;
+            }
+          }
+      }
+#endif
+#if FC_GEO_CHECK == 1 && defined(SVR_FC0_MEASURE)
+      {
+        uint32_t r6[6];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) r6[i] = (uint32_t)__builtin_amdgcn_ds_bpermute(src, ge[i]);
+#pragma unroll
+        for (int a = 0; a < 2; ++a) r6[4 + a] = (uint32_t)__builtin_amdgcn_ds_bpermute(src, ge[4 + a]) + xoff;
+        const uint32_t l6[6] = {zy[0], zy[1], zy[2], zy[3], x[0], x[1]};
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+          if (l6[i] != r6[i] && fc_stamps && (PPW0 <= RPW || g < RPW)) {
+            const unsigned long long n = atomicAdd(fc_stamps, 1ull);
+            if (n < 200) {
+              unsigned long long *o = fc_stamps + 8 + n * 4;
+              o[0] = ((unsigned long long)blockIdx.x << 32) | (unsigned)(S.level << 24 | pw << 16 | lane << 8 | it << 4 | i);
+              o[1] = ((unsigned long long)l6[i] << 32) | r6[i];
+              o[2] = ((unsigned long long)(unsigned)S.j0 << 32) | (unsigned)(LP << 8 | NJ);
+              o[3] = 0;
+            }
+          }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) zy[i] = r6[i];
+        x[0] = r6[4]; x[1] = r6[5];
+      }
+#endif
+    } else {
 #pragma unroll
     for (int i = 0; i < 4; ++i) zy[i] = (uint32_t)__builtin_amdgcn_ds_bpermute(src, ge[i]);
 #pragma unroll
     for (int a = 0; a < 2; ++a) x[a] = (uint32_t)__builtin_amdgcn_ds_bpermute(src, ge[4 + a]) + xoff;
+    }
     if constexpr (BF) {   // four bf16 channels = one 8-byte load; widened to f32 exactly (bf16 = the upper half of an f32)
       u32x2_t raw[8];
 #pragma unroll
@@ -312,7 +464,37 @@ __device__ __forceinline__ void produce_slab(const FcLevel L, const FcSlab S, ui
   };
   auto finish = [&](const Iter &I, int it) {
     float w[8];
-    {
+    if constexpr (FC_GEO_LDS) {   // (wx wy) wz in ATen's order, from the three per-axis pairs (a pair is 0 outside the volume)
+      const LDS_AS char *gp = grow + it * (PPW * GEO_ROW_DW * 4) + 72;
+#if defined(FC_DBG_WAIT) && (FC_DBG_WAIT & 4)
+      asm volatile("" : "+v"(gp));     // (debug: keeps the weight reads from being merged with the offset reads into ds_read2_b64)
+#endif
+      const f32x2_t wx = *reinterpret_cast<const LDS_AS f32x2_t *>(gp + gx8), wy = *reinterpret_cast<const LDS_AS f32x2_t *>(gp + gy8),
+                    wz = *reinterpret_cast<const LDS_AS f32x2_t *>(gp + gz8);
+      const float wxy[4] = {wx.x * wy.x, wx.y * wy.x, wx.x * wy.y, wx.y * wy.y};
+#pragma unroll
+      for (int k = 0; k < 8; ++k) w[k] = wxy[k & 3] * (k < 4 ? wz.x : wz.y);
+#if FC_GEO_CHECK == 1 && defined(SVR_FC0_MEASURE)
+      {
+        const int src = src0 + it * (PPW * 4);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const float wr = __int_as_float(__builtin_amdgcn_ds_bpermute(src, ge[6 + k]));
+          if (__float_as_uint(wr) != __float_as_uint(w[k]) && !(wr == 0.f && w[k] == 0.f) && fc_stamps && (PPW0 <= RPW || g < RPW)) {
+            const unsigned long long n = atomicAdd(fc_stamps, 1ull);
+            if (n < 200) {
+              unsigned long long *o = fc_stamps + 8 + n * 4;
+              o[0] = ((unsigned long long)blockIdx.x << 32) | (unsigned)(S.level << 24 | pw << 16 | lane << 8 | it << 4 | (8 + k));
+              o[1] = ((unsigned long long)__float_as_uint(w[k]) << 32) | __float_as_uint(wr);
+              o[2] = ((unsigned long long)(unsigned)S.j0 << 32) | (unsigned)(LP << 8 | NJ);
+              o[3] = ((unsigned long long)__float_as_uint(wz.x) << 32) | __float_as_uint(wz.y);
+            }
+          }
+          w[k] = wr;
+        }
+      }
+#endif
+    } else {
       const int src = src0 + it * (PPW * 4);
 #pragma unroll
       for (int k = 0; k < 8; ++k) w[k] = __int_as_float(__builtin_amdgcn_ds_bpermute(src, ge[6 + k]));
@@ -469,7 +651,8 @@ __device__ __forceinline__ void stage_box(const FcLevel L, int c0, const FcBox b
 template <bool BF>
 __device__ __forceinline__ void produce(const FcArgs &A, int s, uint32_t *buf, const float *points, int64_t m0, int64_t M,
                                         int N, float disp, int ac, float *feat, int row_stride, int pw, int lane, int dbg,
-                                        uint32_t *stage, const FcBox *__restrict__ boxes, Geo &G, int rowb) {
+                                        uint32_t *stage, const FcBox *__restrict__ boxes, Geo &G, int rowb, uint32_t *geo, int last,
+                                        int b0, int rem0) {
   const FcSlab S = A.S[s];
   const FcLevel L = A.L[S.level];
   if constexpr (!BF) {
@@ -480,8 +663,11 @@ __device__ __forceinline__ void produce(const FcArgs &A, int s, uint32_t *buf, c
         return;
       }
       if (box.nvox > 0) {
-        if (S.geo) level_geometry<BF, true>(L, points + m0 * 3, rowb, disp, ac, lane, box, G);
-        produce_slab<16, 1, BF, true>(L, S, buf, m0, M, feat, row_stride, pw, lane, G, stage);
+        if (S.geo) {
+          if constexpr (FC_GEO_LDS) level_geometry_lds<BF, true>(L, points + m0 * 3, last, b0, rem0, N, disp, ac, pw, lane, box, geo);
+          if constexpr (!FC_GEO_LDS || FC_GEO_CHECK == 1) level_geometry<BF, true>(L, points + m0 * 3, rowb, disp, ac, lane, box, G);
+        }
+        produce_slab<16, 1, BF, true>(L, S, buf, m0, M, feat, row_stride, pw, lane, G, stage, geo);
         return;
       }
     }
@@ -495,13 +681,16 @@ __device__ __forceinline__ void produce(const FcArgs &A, int s, uint32_t *buf, c
     produce_c1<BF>(L, S, buf, points, m0, M, N, disp, ac, feat, row_stride, pw * 64 + lane);
     return;
   }
-  if (S.geo) level_geometry<BF, false>(L, points + m0 * 3, rowb, disp, ac, lane, FcBox{}, G);
+  if (S.geo) {
+    if constexpr (FC_GEO_LDS) level_geometry_lds<BF, false>(L, points + m0 * 3, last, b0, rem0, N, disp, ac, pw, lane, FcBox{}, geo);
+    if constexpr (!FC_GEO_LDS || FC_GEO_CHECK == 1) level_geometry<BF, false>(L, points + m0 * 3, rowb, disp, ac, lane, FcBox{}, G);
+  }
   switch (S.lp * 4 + S.nj) {
-    case 16 * 4 + 1: produce_slab<16, 1, BF>(L, S, buf, m0, M, feat, row_stride, pw, lane, G); break;
-    case 16 * 4 + 2: produce_slab<16, 2, BF>(L, S, buf, m0, M, feat, row_stride, pw, lane, G); break;
-    case 8 * 4 + 1: produce_slab<8, 1, BF>(L, S, buf, m0, M, feat, row_stride, pw, lane, G); break;
-    case 8 * 4 + 2: produce_slab<8, 2, BF>(L, S, buf, m0, M, feat, row_stride, pw, lane, G); break;
-    case 4 * 4 + 1: produce_slab<4, 1, BF>(L, S, buf, m0, M, feat, row_stride, pw, lane, G); break;
+    case 16 * 4 + 1: produce_slab<16, 1, BF>(L, S, buf, m0, M, feat, row_stride, pw, lane, G, nullptr, geo); break;
+    case 16 * 4 + 2: produce_slab<16, 2, BF>(L, S, buf, m0, M, feat, row_stride, pw, lane, G, nullptr, geo); break;
+    case 8 * 4 + 1: produce_slab<8, 1, BF>(L, S, buf, m0, M, feat, row_stride, pw, lane, G, nullptr, geo); break;
+    case 8 * 4 + 2: produce_slab<8, 2, BF>(L, S, buf, m0, M, feat, row_stride, pw, lane, G, nullptr, geo); break;
+    case 4 * 4 + 1: produce_slab<4, 1, BF>(L, S, buf, m0, M, feat, row_stride, pw, lane, G, nullptr, geo); break;
   }
 }
 
@@ -525,7 +714,7 @@ __global__ void args_store_kernel(FcArgs A, FcArgs *__restrict__ dst) {
 // In-kernel timeline (measurement builds only; MI355X_MICROARCH.md "In-kernel stamps"): lane 0 of every wave of the tiles
 // [FC_ST_TILE0, FC_ST_TILE0 + FC_ST_TILES) appends (event id << 56 | slab << 48 | s_memtime) to its own row of a buffer that
 // nothing else reads (svr_gather_fc0_stamps sets the pointer; tools/exp/fc0_timeline.py reads it back).
-__device__ unsigned long long *fc_stamps = nullptr;
+
 constexpr int FC_ST_TILE0 = 3000, FC_ST_TILES = 8, FC_ST_N = 1024;
 #define FC_STAMP_INIT()                                                                                          \
   unsigned long long *st_p = nullptr;                                                                            \
@@ -576,14 +765,15 @@ __global__ __launch_bounds__(NTHR, FC_MINWAVES) void gather_fc0_kernel(const FcA
       for (int cc = pad_start; cc < row_stride; ++cc) feat[(m0 + (t - 256)) * row_stride + cc] = 0.f;
     // slab s + 1 is produced into the buffer the consumers are not reading, then the barrier hands both over (ONE call site:
     // with a second, peeled call for slab 0 the compiler inlined all five slab shapes twice and spilled 268 B / lane)
-    Geo G;   // the sample geometry of the level in work (level_geometry), alive across that level's slabs
-    int rowb;
-    {
+    Geo G;   // the sample geometry of the level in work (level_geometry), alive across that level's slabs (register form)
+    int rowb = 0;
+    const int last = (int)min<int64_t>(M - 1 - m0, FTM - 1);     // last valid row of the tile
+    const int b0 = (int)(m0 / N), rem0 = (int)(m0 - (int64_t)b0 * N);   // (uniform) sample of row 0 and its position in it
+    uint32_t *geo = lds + 2 * FSLAB + FC_STAGE_DW;
+    if constexpr (!FC_GEO_LDS || FC_GEO_CHECK == 1) {
       static_assert(FTM <= 256, "row in the low byte of rowb");
-      const int last = (int)min<int64_t>(M - 1 - m0, FTM - 1);
       const int row = min(RPW * pw + lane % RPW, last);
-      const int b0 = (int)(m0 / N);                                // (uniform)
-      rowb = row | ((b0 + (int)((uint32_t)((int)(m0 - (int64_t)b0 * N) + row) / (uint32_t)N)) << 8);
+      rowb = row | ((b0 + (int)((uint32_t)(rem0 + row) / (uint32_t)N)) << 8);
       asm volatile("" : "+v"(rowb));    // one register, not its recomputable pieces hoisted and spilled
     }
     for (int s = -1; s < S; ++s) {
@@ -595,7 +785,7 @@ __global__ __launch_bounds__(NTHR, FC_MINWAVES) void gather_fc0_kernel(const FcA
       FC_STAMP(1, s + 1);
       if (s + 1 < S && !(dbg & 1))
         produce<BF>(A, s + 1, lds + ((s + 1) & 1) * FSLAB, points, m0, M, N, disp, ac, feat, row_stride, pw, lane_s, dbg, lds + 2 * FSLAB,
-                    boxes + tile * FC_NSTAGE, G, rowb_s);
+                    boxes + tile * FC_NSTAGE, G, rowb_s, geo, last, b0, rem0);
       FC_STAMP(2, s + 1);
       slab_barrier();
       FC_STAMP(3, s + 1);
@@ -1016,6 +1206,11 @@ extern "C" int svr_gather_fc0_fwd(const svr_gather_desc *d, const float *points,
 extern "C" int svr_gather_fc0_stamps(void *buf) {
   unsigned long long *p = (unsigned long long *)buf;
   return (int)hipMemcpyToSymbol(HIP_SYMBOL(fc_stamps), &p, sizeof(p));
+}
+extern "C" int svr_gather_fc0_dbg_level(int C) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(fc_dbg_C), &C, sizeof(C)); }
+extern "C" int svr_gather_fc0_dbg_points(const void *pts) {
+  const float *p = (const float *)pts;
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(fc_dbg_pt0), &p, sizeof(p));
 }
 #endif
 
