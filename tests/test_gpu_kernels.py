@@ -352,6 +352,45 @@ def test_linear_backward_at_f32_level_f16x3s(M, N, K, gscale):
         assert torch.equal(dw1, dw2)
 
 
+def test_f16x3s_edge_cases_zero_huge_tiny_and_non_finite_gradients():
+    """Scaled f16 split at the edges of its scale: an all-zero gradient (|max| = 0: scale 1, exact zeros out), gradients of
+    magnitude 1e30 and 1e-30 (the power-of-two scale is clamped to 2^+-100; f32-level results either way), a single outlier
+    1e6 times the rest (the small elements keep >= 11 bits: their products are far below the outlier's), and a NaN / inf
+    gradient (propagates as non-finite into the rows / columns it touches and nowhere else -- never a silently wrong finite
+    number)."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(5)
+    M, N, K = 1500, 256, 256
+    x = F.relu(torch.randn(M, K, generator=g)).cuda()
+    w = (torch.randn(N, K, generator=g) / 16).cuda()
+    dy0 = torch.randn(M, N, generator=g)
+    z = torch.zeros(M, N).cuda()
+    assert float(ops.amax_of(z).view(torch.float32)) == 0.0
+    assert not ops.linear_bwd_data(z, w, mode="f16x3s").any() and not ops.linear_bwd_weight(z, x, mode="f16x3s")[0].any()
+    for scale in (1e30, 1e-30):
+        dy = (dy0 * scale).cuda()
+        dx = ops.linear_bwd_data(dy, w, mode="f16x3s")
+        dw, _ = ops.linear_bwd_weight(dy, x, mode="f16x3s")
+        assert G.rel_err(dx.cpu().double().numpy() / scale, (dy0.double() @ w.cpu().double()).numpy()) < 2e-6, scale
+        assert G.rel_err(dw.cpu().double().numpy() / scale, (dy0.double().t() @ x.cpu().double()).numpy()) < 2e-6, scale
+    dy = dy0.clone()
+    dy[7, 3] = 1e6                                              # one outlier sets the scale
+    dx = ops.linear_bwd_data(dy.cuda(), w, mode="f16x3s").cpu().double()
+    ref = dy.double() @ w.cpu().double()
+    rows = torch.arange(M) != 7
+    assert G.rel_err(dx[7].numpy(), ref[7].numpy()) < 2e-6
+    # rows without the outlier: relative to THEIR magnitude the error is bounded by the split's 2^-11 on elements 2^-20 below |max|
+    assert G.rel_err(dx[rows].numpy(), ref[rows].numpy()) < 2e-3
+    for bad in (float("nan"), float("inf")):
+        dy = dy0.clone()
+        dy[11, 5] = bad
+        dx = ops.linear_bwd_data(dy.cuda(), w, mode="f16x3s").cpu()
+        dw, _ = ops.linear_bwd_weight(dy.cuda(), x, mode="f16x3s")
+        assert not torch.isfinite(dx[11]).all() and not torch.isfinite(dw[5].cpu()).all()
+        ok_rows = torch.arange(M) != 11
+        assert torch.isfinite(dx[ok_rows]).all()
+
+
 def test_fc_out_and_bce():
     ops = _ops()
     g = torch.Generator().manual_seed(3)
