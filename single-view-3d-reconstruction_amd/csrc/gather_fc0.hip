@@ -286,12 +286,15 @@ __device__ __forceinline__ void level_geometry_lds(const FcLevel L, const float 
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 #endif
   constexpr uint32_t EB = BF ? 2u : 4u;
-  constexpr int ITEMS = RPW * 9;
   const GLOBAL_AS float *pg = (const GLOBAL_AS float *)pt0;
+  // lane -> (row = lane % RPW, slot = lane / RPW); round r evaluates (axis, variant) number r (64 / RPW) + slot, the last round's
+  // surplus slots redo number 8 (same values, same address): shifts and masks only
+  constexpr int SLOTS = 64 / RPW, ROUNDS = (9 + SLOTS - 1) / SLOTS;
+  const unsigned ul = (unsigned)lane & 63u;
 #pragma unroll
-  for (int r = 0; r < (ITEMS + 63) / 64; ++r) {
-    const int idx = min(r * 64 + lane, ITEMS - 1);      // (the tail lanes redo the last item: same values, same address)
-    const int rl = idx / 9, av = idx % 9, axis = av / 3, var = av % 3;
+  for (int r = 0; r < ROUNDS; ++r) {
+    const int rl = (int)(ul % (unsigned)RPW);
+    const int av = min(r * SLOTS + (int)(ul / (unsigned)RPW), 8), axis = (av * 11) >> 5, var = av - 3 * axis;
     const int row = min(RPW * pw + rl, last);
     float g = 2.0f * pg[(uint32_t)row * 3u + (uint32_t)(2 - axis)];
     if (var == 1) g = g + (-disp);

@@ -704,7 +704,17 @@ class _AmaxSlots:
         r["i"] = (i + 1) % self.N
         if r["i"] == 0:
             r["lap"] = True
-        return r["buf"][i:i + 1]
+        r["serial"] = r.get("serial", 0) + 1
+        w = r["buf"][i:i + 1]
+        w._svr_ring, w._svr_serial = r, r["serial"]       # (how old the word is: fresh() below)
+        return w
+
+    @staticmethod
+    def fresh(w):
+        """Is this word still the one that was handed out?  (A gradient tensor kept across many steps and fed to a later
+        backward would otherwise be scaled by whatever the recycled word holds by then.)"""
+        r = getattr(w, "_svr_ring", None)
+        return r is None or r["serial"] - w._svr_serial < _AmaxSlots.N // 2 - 8
 
 
 _amax_slots = _AmaxSlots()
@@ -720,7 +730,7 @@ def amax_of(t):
     "f16x3s" kernels).  Kernels that produce a gradient leave it on the tensor they return (attribute `_svr_amax`: no extra
     pass); otherwise one pass over t on the current stream, remembered on the tensor object."""
     a = getattr(t, "_svr_amax", None)
-    if a is not None:
+    if a is not None and _AmaxSlots.fresh(a):
         return a
     _f32(t)
     a = amax_slot(t.device)

@@ -381,6 +381,13 @@ def test_f16x3s_edge_cases_zero_huge_tiny_and_non_finite_gradients():
     assert G.rel_err(dx[7].numpy(), ref[7].numpy()) < 2e-6
     # rows without the outlier: relative to THEIR magnitude the error is bounded by the split's 2^-11 on elements 2^-20 below |max|
     assert G.rel_err(dx[rows].numpy(), ref[rows].numpy()) < 2e-3
+    # a gradient tensor that outlives its amax word (the pool recycles words after ~250 more were handed out): recomputed
+    t = (dy0 * 3.0).cuda()
+    a0 = ops.amax_of(t)
+    for _ in range(300):
+        ops.amax_slot(t.device)
+    a1 = ops.amax_of(t)
+    assert a1.data_ptr() != a0.data_ptr() and float(a1.view(torch.float32)) == float(t.abs().max())
     for bad in (float("nan"), float("inf")):
         dy = dy0.clone()
         dy[11, 5] = bad
