@@ -349,7 +349,7 @@ __device__ __forceinline__ void produce_slab(const FcLevel L, const FcSlab S, ui
   constexpr uint32_t EB = BF ? 2u : 4u;   // bytes per stored channel value
   // the register set that holds this slab's displacements (j0 is even for NJ == 2: both sit in one set)
   int ge[GEO_N];
-  if constexpr (!FC_GEO_LDS || FC_GEO_CHECK == 1) {
+  if constexpr (!FC_GEO_LDS || (FC_GEO_CHECK & 1)) {
 #pragma unroll
     for (int k = 0; k < GEO_N; ++k) ge[k] = G.v[0][k];
 #pragma unroll
@@ -417,7 +417,7 @@ __device__ __forceinline__ void produce_slab(const FcLevel L, const FcSlab S, ui
           }
       }
 #endif
-#if FC_GEO_CHECK == 1 && defined(SVR_FC0_MEASURE)
+#if (FC_GEO_CHECK == 1 || FC_GEO_CHECK == 3) && defined(SVR_FC0_MEASURE)
       {
         uint32_t r6[6];
 #pragma unroll
@@ -437,9 +437,11 @@ __device__ __forceinline__ void produce_slab(const FcLevel L, const FcSlab S, ui
               o[3] = 0;
             }
           }
+        if constexpr (FC_GEO_CHECK == 1) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) zy[i] = r6[i];
-        x[0] = r6[4]; x[1] = r6[5];
+          for (int i = 0; i < 4; ++i) zy[i] = r6[i];
+          x[0] = r6[4]; x[1] = r6[5];
+        }
       }
 #endif
     } else {
@@ -477,7 +479,7 @@ __device__ __forceinline__ void produce_slab(const FcLevel L, const FcSlab S, ui
       const float wxy[4] = {wx.x * wy.x, wx.y * wy.x, wx.x * wy.y, wx.y * wy.y};
 #pragma unroll
       for (int k = 0; k < 8; ++k) w[k] = wxy[k & 3] * (k < 4 ? wz.x : wz.y);
-#if FC_GEO_CHECK == 1 && defined(SVR_FC0_MEASURE)
+#if (FC_GEO_CHECK == 1 || FC_GEO_CHECK == 3) && defined(SVR_FC0_MEASURE)
       {
         const int src = src0 + it * (PPW * 4);
 #pragma unroll
@@ -493,7 +495,7 @@ __device__ __forceinline__ void produce_slab(const FcLevel L, const FcSlab S, ui
               o[3] = ((unsigned long long)__float_as_uint(wz.x) << 32) | __float_as_uint(wz.y);
             }
           }
-          w[k] = wr;
+          if constexpr (FC_GEO_CHECK == 1) w[k] = wr;
         }
       }
 #endif
@@ -668,7 +670,7 @@ __device__ __forceinline__ void produce(const FcArgs &A, int s, uint32_t *buf, c
       if (box.nvox > 0) {
         if (S.geo) {
           if constexpr (FC_GEO_LDS) level_geometry_lds<BF, true>(L, points + m0 * 3, last, b0, rem0, N, disp, ac, pw, lane, box, geo);
-          if constexpr (!FC_GEO_LDS || FC_GEO_CHECK == 1) level_geometry<BF, true>(L, points + m0 * 3, rowb, disp, ac, lane, box, G);
+          if constexpr (!FC_GEO_LDS || (FC_GEO_CHECK & 1)) level_geometry<BF, true>(L, points + m0 * 3, rowb, disp, ac, lane, box, G);
         }
         produce_slab<16, 1, BF, true>(L, S, buf, m0, M, feat, row_stride, pw, lane, G, stage, geo);
         return;
@@ -686,7 +688,7 @@ __device__ __forceinline__ void produce(const FcArgs &A, int s, uint32_t *buf, c
   }
   if (S.geo) {
     if constexpr (FC_GEO_LDS) level_geometry_lds<BF, false>(L, points + m0 * 3, last, b0, rem0, N, disp, ac, pw, lane, FcBox{}, geo);
-    if constexpr (!FC_GEO_LDS || FC_GEO_CHECK == 1) level_geometry<BF, false>(L, points + m0 * 3, rowb, disp, ac, lane, FcBox{}, G);
+    if constexpr (!FC_GEO_LDS || (FC_GEO_CHECK & 1)) level_geometry<BF, false>(L, points + m0 * 3, rowb, disp, ac, lane, FcBox{}, G);
   }
   switch (S.lp * 4 + S.nj) {
     case 16 * 4 + 1: produce_slab<16, 1, BF>(L, S, buf, m0, M, feat, row_stride, pw, lane, G, nullptr, geo); break;
@@ -773,7 +775,7 @@ __global__ __launch_bounds__(NTHR, FC_MINWAVES) void gather_fc0_kernel(const FcA
     const int last = (int)min<int64_t>(M - 1 - m0, FTM - 1);     // last valid row of the tile
     const int b0 = (int)(m0 / N), rem0 = (int)(m0 - (int64_t)b0 * N);   // (uniform) sample of row 0 and its position in it
     uint32_t *geo = lds + 2 * FSLAB + FC_STAGE_DW;
-    if constexpr (!FC_GEO_LDS || FC_GEO_CHECK == 1) {
+    if constexpr (!FC_GEO_LDS || (FC_GEO_CHECK & 1)) {
       static_assert(FTM <= 256, "row in the low byte of rowb");
       const int row = min(RPW * pw + lane % RPW, last);
       rowb = row | ((b0 + (int)((uint32_t)(rem0 + row) / (uint32_t)N)) << 8);
