@@ -244,7 +244,12 @@ def main():
         sys.exit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {a.gpus}")
 
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # main + two side streams + RCCL's (see the package's __init__)
-    os.environ.setdefault("NCCL_DEBUG", "WARN")       # (RCCL's version banner goes to STDOUT at its default level: the compact line must stay the only JSON there)
+    # RCCL prints its version banner to file descriptor 1 whatever NCCL_DEBUG says (profiles/r04_bench_torchrun_world1.json:
+    # five lines in front of the JSON).  The compact line must be the only thing on stdout: Python's sys.stdout moves to a
+    # duplicate of the real stdout and descriptor 1 itself is pointed at stderr, so native libraries print there.
+    sys.stdout.flush()
+    sys.stdout = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     import torch
     import torch.distributed as dist
     import svr_amd  # noqa: F401
@@ -357,6 +362,25 @@ def main():
                 os.environ["SVR_NO_SIDE_STREAM"] = prev_env
             for mod, name, orig in diag:
                 setattr(mod, name, orig)
+    # the stand-alone feature gather (svr_gather_trilinear_fwd: the (B*N, 2592) feature rows written to HBM -- the kernel the
+    # north star's "fraction of the HBM roofline on the trilinear feature gather" is stated on; callers that want the rows
+    # themselves use it, the step uses the fused kernel above): a few launches behind the timed region, HIP events on the
+    # launch stream.  Present in the PMC passes of tools/pmc_traffic.sh too (they keep the diagnostics on).
+    unfused_ms = None
+    if not a.no_diag and rank == 0:
+        with torch.no_grad():
+            ext = trainer.ifnet.ifnet_feature_extractor
+            lv = ext.encode_levels(batch["input"])
+            pts_u = ops.morton_order(batch["points"].float().contiguous(), want_sorted=True)[1]    # as IFNet.forward visits them
+            rows = ops.gather_fwd(lv, pts_u, ext._layout, ext._disp, ext._align)
+            ku = _KernelTimer(torch)
+            orig_g = ku.wrap(ops, "gather_fwd")
+            for _ in range(5):
+                ops.gather_fwd(lv, pts_u, ext._layout, ext._disp, ext._align, out=rows)
+            torch.cuda.synchronize()
+            ops.gather_fwd = orig_g
+            unfused_ms = _stats(ku.times("gather_fwd"))
+            del rows, lv
     # what the step costs WITHOUT the bf16x3 split in the backward: a few extra steps behind the timed
     # region with the backward GEMMs / convolutions on the exact-f32 MFMA kernels (rank 0's clock; never the headline)
     alt_ms = {}
@@ -485,6 +509,8 @@ def main():
 
     if rank == 0:
         res = report(a, world, dt, loss, step_ms, host_ms, kt, kd, ranks, forms, fwd_ms, query, arena, grown0)
+        if unfused_ms:
+            res["roofline_gather_rows"] = gather_rows_roofline(a, unfused_ms)
         res["rccl"] = {"world_size": world, "launched_by_torchrun": launched, "backend": "nccl (RCCL)" if launched else None,
                        "device_count": torch.cuda.device_count(),
                        "devices": {str(r["rank"]): r["device"] for r in ranks}}
@@ -522,6 +548,11 @@ def compact(res):
                                          if r["traffic"] else None,
                        "compulsory_bytes": r["compulsory_bytes_per_launch"], "algorithmic_bytes": r["algorithmic_bytes_per_launch"],
                        "ms_per_launch": r["ms_per_launch"], "mfma_frac": r.get("mfma_frac_of_f16_peak")}
+    g = res.get("roofline_gather_rows")
+    if g:
+        out["roofline_gather_rows"] = {"kernel": g["kernel_short"], "bound": "hbm", "unit": "GB/s", "peak": g["peak"],
+                                       "achieved": g["achieved"], "frac": g["frac"], "traffic": g["traffic"],
+                                       "ms_per_launch": g["ms_per_launch"]}
     c = res.get("cpu_baseline")
     if c:
         out["cpu_baseline"] = {"value": c["value"], "value_median": c["value_median"], "unit": c["unit"], "cores": c["cores"],
@@ -589,6 +620,27 @@ def _arithmetic():
     short = (f"f32 storage; fwd gemm {ops.FORWARD_GEMM}, fwd conv {ops.FORWARD_CONV}, conv_in {'f16x3' if ops.stage1_arith() else 'f32'}; "
              f"bwd gemm {ops.BACKWARD_GEMM}, bwd conv {ops.BACKWARD_CONV}, wgrad {ops.BACKWARD_CONV_WEIGHT}; BN/gather/scatter f32")
     return long, short
+
+
+def gather_rows_roofline(a, ms):
+    """Roofline entry of the stand-alone gather (rows to HBM): counter-measured HBM bytes of profiles/gather_traffic.json over
+    the live median launch time.  Its traffic is dominated by the 4.1 GB of rows it must write (compulsory, streaming -- the
+    part of the counter that the calibration of profiles/r04_fetch_calibration.json finds exact)."""
+    npts = a.batch * a.points
+    t = _traffic(a)
+    traffic = t.get("hbm_bytes_per_launch")
+    med = ms["median"]
+    rate = traffic / (med * 1e-3) / 1e9 if traffic else None
+    return {"kernel": "gather_fwd_fused_kernel (svr_gather_trilinear_fwd: all 6 levels, (B*N, 2592) f32 rows written to HBM)",
+            "kernel_short": "gather_fwd_fused_kernel (stand-alone gather, rows to HBM)",
+            "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBPS, "achieved": rate,
+            "frac": (rate / HBM_PEAK_GBPS) if rate else None, "traffic": traffic,
+            "write_bytes": t.get("write_bytes"), "fetch_bytes_corrected_x2": t.get("fetch_bytes_corrected_x2"),
+            "rows_bytes_written": npts * 2592 * 4,
+            "algorithmic_bytes_per_launch": npts * GATHER_BYTES_PER_POINT_F32,
+            "ms_per_launch": med, "ms_per_launch_stats": ms,
+            "note": "5 launches behind the timed region on the main stream (nothing beside them); not part of the step, which "
+                    "runs the fused gather -> fc_0 kernel of `roofline` instead"}
 
 
 def _traffic(a):

@@ -60,6 +60,7 @@ def _canned(world):
                        _Arena(), 3)
     res["rccl"] = {"world_size": world, "launched_by_torchrun": world > 1, "backend": "nccl (RCCL)", "device_count": 8,
                    "devices": {str(r): r for r in range(world)}}
+    res["roofline_gather_rows"] = bench.gather_rows_roofline(a, bench._stats([2.11, 2.13, 2.12, 2.2, 2.12]))
     for key in bench.ALT_BACKWARD:
         res[key] = {"ms_per_step": 24.9, "value": 1.6e7, "unit": "query-points/s", "note": bench.ALT_BACKWARD[key][1]}
     if world == 1:
@@ -94,6 +95,10 @@ def test_compact_line_is_short_and_complete(world, tmp_path):
     if r["frac"] is not None:
         assert 0 < r["frac"] <= 1 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
         assert "stored" in r["traffic_source"]
+    g = c["roofline_gather_rows"]                            # the stand-alone gather (rows to HBM) beside the fused kernel
+    assert g["ms_per_launch"] == pytest.approx(2.12) and g["bound"] == "hbm" and len(g["kernel"]) <= 60
+    if g["frac"] is not None:
+        assert 0 < g["frac"] <= 1 and abs(g["frac"] - g["achieved"] / g["peak"]) < 1e-3
     assert c["value"] == pytest.approx(world * 8 * 50000 / 15.4e-3, rel=1e-3)
     if world == 1:
         b = c["cpu_baseline"]
