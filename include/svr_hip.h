@@ -537,6 +537,38 @@ typedef struct svr_conv2d_desc {
 int svr_conv2d_im2col(const svr_conv2d_desc *d, float *col, void *stream);
 int svr_conv2d_col2im(const svr_conv2d_desc *d, const float *dcol, float *dvirt, float *dsrc0, float *dsrc1, void *stream);
 
+/* The same blocks as IMPLICIT GEMMs (round 4; the default of model/unet.py's hip backend, conv2d_igemm.hip): no patch matrix.
+ * The A operand of the split-precision MFMA GEMM is gathered from the channels-last input -- a reduction step is 16 channels of
+ * one tap; activation and concatenation are applied on the way in.  Descriptors here have upsample = 0: a decoder block first
+ * writes its input  V = upsample_x2(act(cat(src0, src1)))  once with svr_conv2d_virtual (1x the activation; any descriptor)
+ * and convolves {src0 = V, act = 0}.
+ *   svr_conv2d_prepare   W (Cout, C, k, k) as nn.Conv2d holds it -> f16 hi / lo planes of the forward product and (want_bwd)
+ *                        of the backward-data product in `planes` (svr_conv2d_planes_bytes); amax: one device word, left with
+ *                        max|W| (the scale of the split).  Once per weight version.
+ *   svr_conv2d_fwd       Y (B, Ho, Wo, Cout) = conv(act(cat(src0, src1))) + bias (bias may be NULL)
+ *   svr_conv2d_bwd_data  dIn (B, H, W, C0 + C1) = gradient of the convolution's (activated, concatenated) input from
+ *                        dY (B, Ho, Wo, Cout); amax_dy: word holding max|dY| (scaled f16 split), NULL = unscaled.  Stride-2
+ *                        layers run as four stride-1 problems, one per parity class of the input pixel.
+ *   svr_conv2d_finish_bwd  dIn (or, for an upsampled block, the gradient of V) -> gradients of src0 / src1: upsample adjoint
+ *                        (gather form), activation derivative, channel split.  `d` is the BLOCK's descriptor (upsample as is).
+ *   svr_conv2d_bwd_weight  dW (Cout, C, k, k) in the parameter's own layout and db (Cout, may be NULL) from dY and the gathered
+ *                        input; workspace svr_conv2d_bwd_weight_workspace bytes.
+ * Layers with few output tiles split the reduction over workgroups and sum the partial outputs in a fixed order (workspace
+ * svr_conv2d_workspace_bytes; deterministic, no atomics).  Limits: B*H*W and B*Ho*Wo < 2^24.                                  */
+int64_t svr_conv2d_planes_bytes(int32_t Cout, int32_t C, int32_t k);
+int svr_conv2d_prepare(const float *W, int32_t Cout, int32_t C, int32_t k, int32_t stride, int32_t want_bwd, uint32_t *amax,
+                       void *planes, void *stream);
+int64_t svr_conv2d_workspace_bytes(const svr_conv2d_desc *d, int32_t Cout);
+int svr_conv2d_virtual(const svr_conv2d_desc *d, float *V, void *stream);
+int svr_conv2d_fwd(const svr_conv2d_desc *d, const void *planes, const uint32_t *amax_w, const float *bias, float *Y, int32_t Cout,
+                   void *workspace, void *stream);
+int svr_conv2d_bwd_data(const svr_conv2d_desc *d, const void *planes, const uint32_t *amax_w, const float *dY,
+                        const uint32_t *amax_dy, int32_t Cout, float *dIn, void *workspace, void *stream);
+int svr_conv2d_finish_bwd(const svr_conv2d_desc *d, const float *dvirt, float *dsrc0, float *dsrc1, void *stream);
+int64_t svr_conv2d_bwd_weight_workspace(const svr_conv2d_desc *d, int32_t Cout);
+int svr_conv2d_bwd_weight(const svr_conv2d_desc *d, const float *dY, const uint32_t *amax_dy, int32_t Cout, float *dW, float *db,
+                          void *workspace, void *stream);
+
 /* ---------------------------------------------------------------------------------------
  * Occupancy labelling against a triangle mesh (replaces check_mesh_contains,
  * data_processing/libmesh/inside_mesh.py:5-155, and the Cython TriangleHash, libmesh/triangle_hash.pyx:8-85,

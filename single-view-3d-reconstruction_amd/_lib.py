@@ -126,6 +126,15 @@ SIGNATURES = {
     "svr_stage1_bwd": (C.c_int, [P, P, P, P, P, P, P, P, P, P, P, P, P, P, I32, I32, I32, I32, I32, C.c_int, C.c_int, P, P]),
     "svr_conv2d_im2col": (C.c_int, [C.POINTER(Conv2dDesc), P, P]),
     "svr_conv2d_col2im": (C.c_int, [C.POINTER(Conv2dDesc), P, P, P, P, P]),
+    "svr_conv2d_planes_bytes": (I64, [I32, I32, I32]),
+    "svr_conv2d_prepare": (C.c_int, [P, I32, I32, I32, I32, I32, P, P, P]),
+    "svr_conv2d_workspace_bytes": (I64, [C.POINTER(Conv2dDesc), I32]),
+    "svr_conv2d_virtual": (C.c_int, [C.POINTER(Conv2dDesc), P, P]),
+    "svr_conv2d_fwd": (C.c_int, [C.POINTER(Conv2dDesc), P, P, P, P, I32, P, P]),
+    "svr_conv2d_bwd_data": (C.c_int, [C.POINTER(Conv2dDesc), P, P, P, P, I32, P, P, P]),
+    "svr_conv2d_finish_bwd": (C.c_int, [C.POINTER(Conv2dDesc), P, P, P, P]),
+    "svr_conv2d_bwd_weight_workspace": (I64, [C.POINTER(Conv2dDesc), I32]),
+    "svr_conv2d_bwd_weight": (C.c_int, [C.POINTER(Conv2dDesc), P, P, I32, P, P, P, P]),
     "svr_mesh_hash_entries": (I64, [P, I64, P, I64, I32, P]),
     "svr_mesh_hash_build": (C.c_int, [P, I64, P, I64, I32, P, P, P, I64]),
     "svr_mesh_contains": (C.c_int, [P, I32, I64, P, P, P, I32, P, P, P, P]),

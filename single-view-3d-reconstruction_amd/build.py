@@ -35,6 +35,7 @@ SOURCES = {
     "mesh_occupancy.hip": ["-ffp-contract=off"],
     "sample_io.hip": [],
     "conv2d.hip": [],
+    "conv2d_igemm.hip": [],
 }
 COMMON = ["-O3", "-fPIC", "--offload-arch=gfx950", "-munsafe-fp-atomics", "-std=c++17", "-I" + INCLUDE, "-I" + CSRC,
           # per-kernel register / scratch report into build/<file>.log (resource_usage() parses it: a kernel that starts to

@@ -228,3 +228,44 @@ extern "C" int svr_conv2d_col2im(const svr_conv2d_desc *d, const float *dcol, fl
   }
   return launch_status("conv2d_col2im");
 }
+
+// ---- pieces of the implicit-GEMM path (conv2d_igemm.hip) ---------------------------------------------------------------
+// V (B, Hv, Wv, C0 + C1) = [x2 bilinear upsample]( act( cat(src0, src1) ) ): the input of a decoder convolution, written once
+// (the im2col gather with a 1 x 1 window)
+extern "C" int svr_conv2d_virtual(const svr_conv2d_desc *d, float *V, void *stream) {
+  SVR_CHECK(d && d->src0 && V && d->B > 0 && d->H > 0 && d->W > 0 && d->C0 > 0 && d->C1 >= 0, SVR_E_BADARG, "conv2d_virtual: bad descriptor");
+  SVR_CHECK(d->C1 == 0 || d->src1, SVR_E_BADARG, "conv2d_virtual: C1 = %d without a second source", d->C1);
+  SVR_CHECK(d->act >= 0 && d->act <= 2, SVR_E_BADARG, "conv2d_virtual: act %d", d->act);
+  const int Hv = d->upsample ? 2 * d->H : d->H, Wv = d->upsample ? 2 * d->W : d->W, C = d->C0 + d->C1;
+  const Src2 S{d->src0, d->src1, d->C0, d->C1};
+  const bool vec = C % 4 == 0 && d->C0 % 4 == 0 && (((uintptr_t)d->src0 | (uintptr_t)d->src1 | (uintptr_t)V) & 15) == 0;
+  const int64_t total = (int64_t)d->B * Hv * Wv * (vec ? C / 4 : C);
+  SVR_CHECK(cdiv(total, 256) < (1LL << 31), SVR_E_UNSUPPORTED, "conv2d_virtual: %ld work items", (long)total);
+  if (vec)
+    hipLaunchKernelGGL(im2col2d_kernel<4>, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, S, V, d->B, d->H, d->W, 1, 1, 0,
+                       Hv, Wv, d->act, d->upsample, total);
+  else
+    hipLaunchKernelGGL(im2col2d_kernel<1>, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, S, V, d->B, d->H, d->W, 1, 1, 0,
+                       Hv, Wv, d->act, d->upsample, total);
+  return launch_status("conv2d_virtual");
+}
+
+// gradients with respect to the two sources from dvirt (B, Hv, Wv, C0 + C1), the gradient of the convolution's (activated,
+// upsampled, concatenated) input: upsample adjoint in gather form, activation derivative, split over the sources
+extern "C" int svr_conv2d_finish_bwd(const svr_conv2d_desc *d, const float *dvirt, float *dsrc0, float *dsrc1, void *stream) {
+  SVR_CHECK(d && d->src0 && dvirt && (dsrc0 || dsrc1) && d->B > 0 && d->H > 0 && d->W > 0 && d->C0 > 0 && d->C1 >= 0, SVR_E_BADARG,
+            "conv2d_finish_bwd: bad descriptor");
+  SVR_CHECK(d->C1 == 0 || d->src1, SVR_E_BADARG, "conv2d_finish_bwd: C1 = %d without a second source", d->C1);
+  const int C = d->C0 + d->C1;
+  const Src2 S{d->src0, d->src1, d->C0, d->C1};
+  const bool vec = C % 4 == 0 && d->C0 % 4 == 0 &&
+                   (((uintptr_t)d->src0 | (uintptr_t)d->src1 | (uintptr_t)dvirt | (uintptr_t)dsrc0 | (uintptr_t)dsrc1) & 15) == 0;
+  const int64_t ts = (int64_t)d->B * d->H * d->W * (vec ? C / 4 : C);
+  if (vec)
+    hipLaunchKernelGGL(conv2d_finish_bwd_kernel<4>, dim3((unsigned)cdiv(ts, 256)), dim3(256), 0, (hipStream_t)stream, dvirt, S, dsrc0, dsrc1,
+                       d->B, d->H, d->W, d->act, d->upsample, ts);
+  else
+    hipLaunchKernelGGL(conv2d_finish_bwd_kernel<1>, dim3((unsigned)cdiv(ts, 256)), dim3(256), 0, (hipStream_t)stream, dvirt, S, dsrc0, dsrc1,
+                       d->B, d->H, d->W, d->act, d->upsample, ts);
+  return launch_status("conv2d_finish_bwd");
+}

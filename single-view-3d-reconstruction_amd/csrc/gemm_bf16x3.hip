@@ -18,6 +18,7 @@
 // so the fragment reads (ds_read_b128, lane <-> row) and the transposing stores (ds_write_b128) are conflict free.
 // Tiles that share an operand panel are dispatched to one XCD (common.h: xcd_logical).
 #include "common.h"
+#include "conv2d_virt.h"
 #include "f16x3.h"
 
 using namespace svr;
@@ -408,12 +409,22 @@ __device__ __forceinline__ bf16x8 tr_frag(const uint32_t *plane, int byte0, int 
 // hi hi + (hi 2^-11) lo' + lo' (hi 2^-11) with the 2^-11 applied to the hi FRAGMENTS in registers (v_pk_mul_f16), result * 2^-s:
 // 22 mantissa bits per operand instead of 16, the same three matrix instructions per block.  X (activations) is not scaled:
 // |x| < 65504, and below |x| ~ 0.1 the correction term carries an absolute error floor of 3e-8 |dY| (gemm_f16x3.hip).
-template <int STAGES, bool F16 = false>
+// CONV (UNet weight gradients as an implicit GEMM, conv2d_igemm.hip): X is not a matrix in memory -- row m is output pixel
+// (b, oy, ox), column j = (tap, c) of the reduction order, and X[m][j] = act(in)[b][oy s - p + ky][ox s - p + kx][c] is
+// gathered from the channels-last input (zero outside the image); a thread's columns, hence its tap and channel, are fixed
+// for the whole kernel, only the pixel moves.  dY may have any column count (Cout = 1 in the last decoder layer).
+struct CwGeom {
+  CvSrc S;
+  int Wo, HoWo;
+  float rWo, rHoWo;
+  int k, stride, pad, Cpad;
+};
+template <int STAGES, bool F16 = false, bool CONV = false, bool VEC4 = true>
 __global__ __launch_bounds__(256, 2) void linear_tn_x3_tr_kernel(const float *__restrict__ dY, int64_t lddy,
                                                               const float *__restrict__ X, int64_t ldx,
                                                               float *__restrict__ slab, float *__restrict__ dbpart,
                                                               int64_t M, int64_t N, int64_t K, int64_t rows_per_split,
-                                                              int splits, const uint32_t *__restrict__ amax_dy) {
+                                                              int splits, const uint32_t *__restrict__ amax_dy, const CwGeom G) {
   __shared__ __attribute__((aligned(16))) uint32_t lds[STAGES * 4 * TR_XPLANE];  // per stage: dY hi, dY mid, X hi, X mid: [32 m][128 cols]
   uint32_t *la = lds, *lx = lds + 2 * TR_XPLANE;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -428,13 +439,35 @@ __global__ __launch_bounds__(256, 2) void linear_tn_x3_tr_kernel(const float *__
   // loaders: float4 idx = t + 256 i -> (row = idx >> 5, columns 4 (idx & 31) .. +3); columns past the extent are
   // clamped (they only feed outputs that are never stored), rows past the range are clamped and zeroed on the way in
   float4 av[4], xv[4];
-  const int64_t acol = min(i0 + 4 * (int64_t)(t & 31), N - 4), xcol = min(j0 + 4 * (int64_t)(t & 31), K - 4);
+  const int64_t acol = CONV ? i0 + 4 * (int64_t)(t & 31) : min(i0 + 4 * (int64_t)(t & 31), N - 4), xcol = min(j0 + 4 * (int64_t)(t & 31), K - 4);
+  int ctap_y = 0, ctap_x = 0, cch = 0;
+  if constexpr (CONV) {
+    const int tap = (int)(xcol / G.Cpad);
+    cch = (int)(xcol % G.Cpad);
+    ctap_y = tap / G.k - G.pad;
+    ctap_x = tap % G.k - G.pad;
+  }
   auto gload = [&](int64_t k0) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int64_t m = min(k0 + (t >> 5) + 8 * i, kend - 1);
-      av[i] = *reinterpret_cast<const float4 *>(dY + m * lddy + acol);
-      xv[i] = *reinterpret_cast<const float4 *>(X + m * ldx + xcol);
+      if constexpr (CONV) {
+        if (VEC4 && (N & 3) == 0 && acol + 4 <= N) {
+          av[i] = *reinterpret_cast<const float4 *>(dY + m * lddy + acol);
+        } else {
+          float e[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) e[u] = acol + u < N ? dY[m * lddy + acol + u] : 0.f;
+          av[i] = make_float4(e[0], e[1], e[2], e[3]);
+        }
+        int b, rem, oy, ox;
+        cv_divmod((int)m, G.HoWo, G.rHoWo, b, rem);
+        cv_divmod(rem, G.Wo, G.rWo, oy, ox);
+        xv[i] = cv_load4<VEC4>(G.S, (int64_t)b * G.S.H * G.S.W, oy * G.stride + ctap_y, ox * G.stride + ctap_x, cch);
+      } else {
+        av[i] = *reinterpret_cast<const float4 *>(dY + m * lddy + acol);
+        xv[i] = *reinterpret_cast<const float4 *>(X + m * ldx + xcol);
+      }
     }
   };
   const bool want_db = dbpart != nullptr && j0 == 0;
@@ -448,7 +481,9 @@ __global__ __launch_bounds__(256, 2) void linear_tn_x3_tr_kernel(const float *__
       const int r = (t >> 5) + 8 * i;
       const bool ok = k0 + r < kend;
       const int off = (tr_off(r, (t & 31) >> 1) + 8 * (t & 1)) >> 2;  // dwords
-      const float4 a = ok ? av[i] : make_float4(0.f, 0.f, 0.f, 0.f), x = ok ? xv[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4 a = ok ? av[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+      float4 x = ok ? xv[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+      if constexpr (CONV) x = cv_act4(x, G.S.act);
       if (want_db) { dbs.x += a.x; dbs.y += a.y; dbs.z += a.z; dbs.w += a.w; }
       uint32_t h0, m0, h1, m1;
       if constexpr (F16) {
@@ -746,10 +781,10 @@ extern "C" int svr_linear_bwd_weight_bf16x3(const float *dY, int64_t lddy, const
     static const int tr_stages = getenv("SVR_TN_STAGES") ? atoi(getenv("SVR_TN_STAGES")) : 1;   // measurement switch
     if (tr_stages == 2)
       hipLaunchKernelGGL(linear_tn_x3_tr_kernel<2>, grid, dim3(256), 0, s, dY, lddy, X, ldx, slab, db ? dbpart : nullptr, M, N, K,
-                         rps, splits, (const uint32_t *)nullptr);
+                         rps, splits, (const uint32_t *)nullptr, CwGeom{});
     else
       hipLaunchKernelGGL(linear_tn_x3_tr_kernel<1>, grid, dim3(256), 0, s, dY, lddy, X, ldx, slab, db ? dbpart : nullptr, M, N, K,
-                         rps, splits, (const uint32_t *)nullptr);
+                         rps, splits, (const uint32_t *)nullptr, CwGeom{});
     hipLaunchKernelGGL(slab_reduce_x3_kernel, dim3((unsigned)cdiv(N * K, 64)), dim3(256), 0, s, slab, dW, N, K, lddw, splits);
     if (db) hipLaunchKernelGGL(dy_db_reduce_kernel, dim3((unsigned)N), dim3(256), 0, s, dbpart, db, N, (int64_t)splits);
     return launch_status("linear_bwd_weight_bf16x3");
@@ -783,8 +818,73 @@ extern "C" int svr_linear_bwd_weight_f16x3(const float *dY, int64_t lddy, const 
   float *dbpart = (float *)w;
   dim3 grid(xcd_grid(cdiv(K, TN_TN) * cdiv(N, TN_TM) * splits));
   hipLaunchKernelGGL((linear_tn_x3_tr_kernel<1, true>), grid, dim3(256), 0, s, dY, lddy, X, ldx, slab, db ? dbpart : nullptr, M, N, K,
-                     rps, splits, amax_dy);
+                     rps, splits, amax_dy, CwGeom{});
   hipLaunchKernelGGL(slab_reduce_x3_kernel, dim3((unsigned)cdiv(N * K, 64)), dim3(256), 0, s, slab, dW, N, K, lddw, splits);
   if (db) hipLaunchKernelGGL(dy_db_reduce_kernel, dim3((unsigned)N), dim3(256), 0, s, dbpart, db, N, (int64_t)splits);
   return launch_status("linear_bwd_weight_f16x3");
+}
+
+// ---- UNet weight gradients as an implicit GEMM (conv2d_igemm.hip has the forward / backward-data kernels) -----------------
+namespace {
+// dW (Cout, C, k, k) = sum over the row slabs, written in the parameter's own layout (slab columns are (tap, c padded to 16))
+__global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float *__restrict__ slab, float *__restrict__ dW, int Cout, int C,
+                                                                int kk, int Cpad, int splits) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x, total = (int64_t)Cout * C * kk;
+  if (idx >= total) return;
+  const int tap = (int)(idx % kk), c = (int)((idx / kk) % C), co = (int)(idx / ((int64_t)kk * C));
+  const int64_t K = (int64_t)kk * Cpad, st = (int64_t)Cout * K, at = (int64_t)co * K + (int64_t)tap * Cpad + c;
+  float s = 0.f;
+  for (int z = 0; z < splits; ++z) s += slab[z * st + at];
+  dW[idx] = s;
+}
+int conv_wgrad_splits(int64_t M, int64_t N, int64_t K, int64_t *rows_per_split) {
+  const int64_t tiles = cdiv(N, TN_TM) * cdiv(K, TN_TN);
+  const int64_t want = std::max<int64_t>(1, 384 / tiles);         // the slabs are written and read once each: few, long splits
+  int64_t rps = cdiv(cdiv(M, want), XK) * XK;
+  rps = std::max<int64_t>(rps, 4 * XK);
+  *rows_per_split = rps;
+  return (int)cdiv(M, rps);
+}
+}  // namespace
+
+extern "C" int64_t svr_conv2d_bwd_weight_workspace(const svr_conv2d_desc *d, int32_t Cout) {
+  if (!d) return 0;
+  const int C = d->C0 + d->C1, Cpad = (C + 15) / 16 * 16;
+  const int Ho = (d->H + 2 - d->k) / d->stride + 1, Wo = (d->W + 2 - d->k) / d->stride + 1;
+  int64_t rps;
+  const int64_t K = (int64_t)d->k * d->k * Cpad;
+  const int splits = conv_wgrad_splits((int64_t)d->B * Ho * Wo, Cout, K, &rps);
+  return align256b((int64_t)splits * Cout * K * 4) + align256b((int64_t)splits * Cout * 4) + 256;
+}
+
+extern "C" int svr_conv2d_bwd_weight(const svr_conv2d_desc *d, const float *dY, const uint32_t *amax_dy, int32_t Cout, float *dW,
+                                     float *db, void *workspace, void *stream) {
+  SVR_CHECK(d && d->src0 && dY && dW && workspace && Cout > 0, SVR_E_BADARG, "conv2d_bwd_weight: null pointer");
+  SVR_CHECK((d->k == 4 && d->stride == 2) || (d->k == 3 && d->stride == 1), SVR_E_UNSUPPORTED, "conv2d_bwd_weight: k=%d stride=%d", d->k, d->stride);
+  SVR_CHECK(!d->upsample, SVR_E_UNSUPPORTED, "conv2d_bwd_weight: the x2 upsample is materialised first (svr_conv2d_virtual)");
+  SVR_CHECK(d->C1 == 0 || d->src1, SVR_E_BADARG, "conv2d_bwd_weight: C1 = %d without a second source", d->C1);
+  const int C = d->C0 + d->C1, Cpad = (C + 15) / 16 * 16;
+  const int Ho = (d->H + 2 - d->k) / d->stride + 1, Wo = (d->W + 2 - d->k) / d->stride + 1;
+  const int64_t M = (int64_t)d->B * Ho * Wo, K = (int64_t)d->k * d->k * Cpad, N = Cout;
+  SVR_CHECK(M > 0 && M < (1 << 24) && (int64_t)d->B * d->H * d->W < (1 << 24), SVR_E_UNSUPPORTED, "conv2d_bwd_weight: %ld output pixels (row decode limit 2^24)", (long)M);
+  hipStream_t s = (hipStream_t)stream;
+  int64_t rps;
+  const int splits = conv_wgrad_splits(M, N, K, &rps);
+  char *w = (char *)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+  float *slab = (float *)w;
+  float *dbpart = (float *)(w + align256b((int64_t)splits * N * K * 4));
+  CwGeom G{CvSrc{d->src0, d->src1, d->C0, d->C1, d->H, d->W, d->act}, Wo, Ho * Wo, 1.0f / (float)Wo, 1.0f / (float)(Ho * Wo), d->k, d->stride, 1, Cpad};
+  const bool vec4 = d->C0 % 4 == 0 && d->C1 % 4 == 0 && (((uintptr_t)d->src0 | (uintptr_t)d->src1 | (uintptr_t)dY) & 15) == 0;
+  dim3 grid(xcd_grid(cdiv(K, TN_TN) * cdiv(N, TN_TM) * splits));
+  if (vec4)
+    hipLaunchKernelGGL((linear_tn_x3_tr_kernel<1, true, true, true>), grid, dim3(256), 0, s, dY, (int64_t)Cout, (const float *)nullptr, (int64_t)0,
+                       slab, db ? dbpart : nullptr, M, N, K, rps, splits, amax_dy, G);
+  else
+    hipLaunchKernelGGL((linear_tn_x3_tr_kernel<1, true, true, false>), grid, dim3(256), 0, s, dY, (int64_t)Cout, (const float *)nullptr, (int64_t)0,
+                       slab, db ? dbpart : nullptr, M, N, K, rps, splits, amax_dy, G);
+  const int64_t total = (int64_t)Cout * C * d->k * d->k;
+  hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, s, (const float *)slab, dW, Cout, C,
+                     d->k * d->k, Cpad, splits);
+  if (db) hipLaunchKernelGGL(dy_db_reduce_kernel, dim3((unsigned)N), dim3(256), 0, s, dbpart, db, N, (int64_t)splits);
+  return launch_status("conv2d_bwd_weight");
 }

@@ -72,6 +72,50 @@ class _ConvBlockFn(torch.autograd.Function):
         return d0, d1, dw, db[:Cout].contiguous(), None, None, None, None
 
 
+class _ConvBlockIgemmFn(torch.autograd.Function):
+    """The same block as implicit GEMMs (conv2d_igemm.hip): no patch matrix, the weight gradient comes out in nn.Conv2d's own
+    layout, no torch glue ops.  A decoder block writes its activated, upsampled, concatenated input V once and keeps it for
+    the backward (1x the activation; the patch matrix was 9x and was built twice)."""
+
+    @staticmethod
+    def forward(ctx, src0, src1, weight, bias, k, stride, act, up):
+        src0 = src0.contiguous()
+        src1 = src1.contiguous() if src1 is not None else None
+        planes = ops.Conv2dPlanes(weight, stride, want_bwd=ctx.needs_input_grad[0] or ctx.needs_input_grad[1])
+        if up:
+            a0, a1, aact = ops.conv2d_virtual(src0, src1, act, True), None, ops.ACT_NONE
+        else:
+            a0, a1, aact = src0, src1, act
+        y = ops.conv2d_fwd(a0, a1, k, stride, aact, planes, bias.detach())
+        ctx.save_for_backward(src0, src1, a0 if up else None)
+        ctx.planes = planes
+        ctx.cfg = (k, stride, act, up, int(weight.shape[0]))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        src0, src1, V = ctx.saved_tensors
+        k, stride, act, up, Cout = ctx.cfg
+        a0, a1, aact = (V, None, ops.ACT_NONE) if up else (src0, src1, act)
+        dy = dy.contiguous()
+        dw, db = ops.conv2d_bwd_weight(a0, a1, k, stride, aact, dy, Cout)
+        need0, need1 = ctx.needs_input_grad[0], ctx.needs_input_grad[1] and src1 is not None
+        d0 = d1 = None
+        if need0 or need1:
+            dvirt = ops.conv2d_bwd_data(a0, a1, k, stride, ctx.planes, dy)
+            d0, d1 = ops.conv2d_finish_bwd(src0, src1, act, up, dvirt, need0, need1)
+        ctx.planes = None
+        return d0, d1, dw, db, None, None, None, None
+
+
+def _conv_block(*args):
+    """The block's autograd function: implicit GEMMs with the f32-level backward split (default), the explicit patch-matrix
+    path for the other backward arithmetics (SVR_BACKWARD=bf16x3 / f32) and for SVR_UNET_IGEMM=0 (A/B)."""
+    if ops.UNET_IGEMM and ops.BACKWARD_GEMM == "f16x3s":
+        return _ConvBlockIgemmFn.apply(*args)
+    return _ConvBlockFn.apply(*args)
+
+
 class _BN2dFn(torch.autograd.Function):
     """BatchNorm2d on a channels-last (B,H,W,C) tensor through the 3-D encoder's BatchNorm kernels (D = 1)."""
 
@@ -126,7 +170,7 @@ class _UNetBase(nn.Module):
         skips = []
         for i in range(1, len(self.ENC) + 1):
             conv = getattr(self, f"conv{i}")
-            x = _ConvBlockFn.apply(x, None, conv.weight, conv.bias, 4, 2, ops.ACT_LEAKY if i > 1 else ops.ACT_NONE, False)
+            x = _conv_block(x, None, conv.weight, conv.bias, 4, 2, ops.ACT_LEAKY if i > 1 else ops.ACT_NONE, False)
             bn = self.ENC_BN[i - 1]
             if bn is not None:
                 m = getattr(self, bn)
@@ -135,7 +179,7 @@ class _UNetBase(nn.Module):
         d0, d1 = skips.pop(), None                                                # innermost code: no skip of itself
         for name, _, _, bn in self.DEC:
             conv = getattr(self, name)
-            d = _ConvBlockFn.apply(d0, d1, conv.weight, conv.bias, 3, 1, ops.ACT_RELU, True)   # cat(d0, d1) never materialised
+            d = _conv_block(d0, d1, conv.weight, conv.bias, 3, 1, ops.ACT_RELU, True)   # cat(d0, d1) never materialised
             if bn is not None:
                 m = getattr(self, bn)
                 d0, d1 = _BN2dFn.apply(d, m.weight, m.bias, m), skips.pop()

@@ -1269,3 +1269,97 @@ def conv2d_col2im(src0, src1, k, stride, act, up, dcol, need0=True, need1=True):
         return None, None
     check(_lib.lib().svr_conv2d_col2im(C.byref(d), _p(dcol), _p(dvirt), _p(d0), _p(d1), _stream()), "conv2d_col2im")
     return d0, d1
+
+
+# ---- the same blocks as implicit GEMMs (conv2d_igemm.hip; the default of model/unet.py) -------------------------------------
+UNET_IGEMM = os.environ.get("SVR_UNET_IGEMM", "1") != "0"      # "0": the explicit patch-matrix path above (A/B)
+
+
+class Conv2dPlanes:
+    """Split f16 planes of one nn.Conv2d weight (forward and backward-data products) + the word holding max|W|."""
+
+    def __init__(self, weight, stride, want_bwd=True):
+        _f32(weight)
+        w = weight.detach().contiguous()
+        self.Cout, self.C, self.k = int(w.shape[0]), int(w.shape[1]), int(w.shape[2])
+        self.stride, self.has_bwd = stride, bool(want_bwd)
+        nbytes = 256 + _lib.lib().svr_conv2d_planes_bytes(self.Cout, self.C, self.k)
+        self.buf = torch.empty(nbytes, device=w.device, dtype=torch.uint8)
+        check(_lib.lib().svr_conv2d_prepare(_p(w), self.Cout, self.C, self.k, stride, int(self.has_bwd), self.amax_ptr(),
+                                            self.planes_ptr(), _stream()), "conv2d_prepare")
+
+    def amax_ptr(self):
+        return self.buf.data_ptr()
+
+    def planes_ptr(self):
+        return self.buf.data_ptr() + 256
+
+
+def _amax_any(t):
+    """amax word of a gradient tensor of any element count (amax_of wants multiples of 4 and 16-byte alignment)."""
+    if t.numel() % 4 == 0 and t.data_ptr() % 16 == 0:
+        return amax_of(t)
+    return t.detach().abs().max().reshape(1).view(torch.int32)
+
+
+def _conv2d_ws(nbytes, device):
+    return torch.empty(max(int(nbytes), 256), device=device, dtype=torch.uint8)
+
+
+def conv2d_virtual(src0, src1, act, up):
+    """V (B,Hv,Wv,C0+C1) = [x2 upsample](act(cat(src0, src1))): a decoder block's input, written once."""
+    d, (Hv, Wv, _, _) = _conv2d_desc(src0, src1, 3, 1, act, up)
+    V = torch.empty(d.B, Hv, Wv, d.C0 + d.C1, device=src0.device, dtype=torch.float32)
+    check(_lib.lib().svr_conv2d_virtual(C.byref(d), _p(V), _stream()), "conv2d_virtual")
+    return V
+
+
+def conv2d_fwd(src0, src1, k, stride, act, planes, bias):
+    """y (B,Ho,Wo,Cout) = conv_k(act(cat(src0, src1))) + bias as one implicit GEMM (no upsample here: conv2d_virtual first)."""
+    d, (_, _, Ho, Wo) = _conv2d_desc(src0, src1, k, stride, act, False)
+    if planes.C != d.C0 + d.C1 or planes.k != k or planes.stride != stride:
+        raise ValueError("conv2d_fwd: the planes were prepared for another layer")
+    _f32(bias)
+    y = torch.empty(d.B, Ho, Wo, planes.Cout, device=src0.device, dtype=torch.float32)
+    ws = _conv2d_ws(_lib.lib().svr_conv2d_workspace_bytes(C.byref(d), planes.Cout), src0.device)
+    check(_lib.lib().svr_conv2d_fwd(C.byref(d), planes.planes_ptr(), planes.amax_ptr(), _p(bias), _p(y), planes.Cout, _p(ws),
+                                    _stream()), "conv2d_fwd")
+    return y
+
+
+def conv2d_bwd_data(src0, src1, k, stride, planes, dy):
+    """dIn (B,H,W,C0+C1): gradient of the convolution's activated, concatenated input (scaled f16 split on dy)."""
+    d, _ = _conv2d_desc(src0, src1, k, stride, 0, False)
+    if not planes.has_bwd:
+        raise ValueError("conv2d_bwd_data: the planes were prepared without the backward product")
+    _f32(dy)
+    dy = dy.contiguous()
+    din = torch.empty(d.B, d.H, d.W, d.C0 + d.C1, device=dy.device, dtype=torch.float32)
+    ws = _conv2d_ws(_lib.lib().svr_conv2d_workspace_bytes(C.byref(d), planes.Cout), dy.device)
+    check(_lib.lib().svr_conv2d_bwd_data(C.byref(d), planes.planes_ptr(), planes.amax_ptr(), _p(dy), _amax_any(dy).data_ptr(),
+                                         planes.Cout, _p(din), _p(ws), _stream()), "conv2d_bwd_data")
+    return din
+
+
+def conv2d_finish_bwd(src0, src1, act, up, dvirt, need0=True, need1=True):
+    """dvirt (B,Hv,Wv,C) -> gradients of src0 / src1 (upsample adjoint, activation derivative, channel split)."""
+    d, _ = _conv2d_desc(src0, src1, 3, 1, act, up)
+    d0 = torch.empty_like(src0) if need0 else None
+    d1 = torch.empty_like(src1) if (src1 is not None and need1) else None
+    if d0 is None and d1 is None:
+        return None, None
+    check(_lib.lib().svr_conv2d_finish_bwd(C.byref(d), _p(dvirt), _p(d0), _p(d1), _stream()), "conv2d_finish_bwd")
+    return d0, d1
+
+
+def conv2d_bwd_weight(src0, src1, k, stride, act, dy, Cout, want_bias=True):
+    """dW (Cout, C0+C1, k, k) in nn.Conv2d's layout and db from dy (B,Ho,Wo,Cout) and the gathered input."""
+    d, _ = _conv2d_desc(src0, src1, k, stride, act, False)
+    _f32(dy)
+    dy = dy.contiguous()
+    dw = torch.empty(Cout, d.C0 + d.C1, k, k, device=dy.device, dtype=torch.float32)
+    db = torch.empty(Cout, device=dy.device, dtype=torch.float32) if want_bias else None
+    ws = _conv2d_ws(_lib.lib().svr_conv2d_bwd_weight_workspace(C.byref(d), Cout), dy.device)
+    check(_lib.lib().svr_conv2d_bwd_weight(C.byref(d), _p(dy), _amax_any(dy).data_ptr(), Cout, _p(dw), _p(db), _p(ws), _stream()),
+          "conv2d_bwd_weight")
+    return dw, db
