@@ -59,7 +59,8 @@ out["fwd_ms_gpu"], out["fwd_ms_wall"] = timeit(fwd, a.reps)
 out["step_ms_gpu"], out["step_ms_wall"] = timeit(step, a.reps)
 if a.layers and a.backend == "hip":
     ev = []
-    F = U._ConvBlockFn
+    from svr_amd import ops
+    F = U._ConvBlockIgemmFn if (ops.UNET_IGEMM and ops.BACKWARD_GEMM == "f16x3s") else U._ConvBlockFn
     of, ob = F.forward, F.backward
 
     def tf(ctx, *args):
@@ -75,7 +76,7 @@ if a.layers and a.backend == "hip":
         e0.record()
         r = ob(ctx, dy)
         e1.record()
-        ev.append(("bwd", tuple(dy.shape), ctx.cfg[6], e0, e1))
+        ev.append(("bwd", tuple(dy.shape), ctx.cfg[-1], e0, e1))
         return r
     F.forward, F.backward = staticmethod(tf), staticmethod(tb)
     step()
