@@ -555,6 +555,15 @@ int svr_conv2d_col2im(const svr_conv2d_desc *d, const float *dcol, float *dvirt,
  *                        input; workspace svr_conv2d_bwd_weight_workspace bytes.
  * Layers with few output tiles split the reduction over workgroups and sum the partial outputs in a fixed order (workspace
  * svr_conv2d_workspace_bytes; deterministic, no atomics).  Limits: B*H*W and B*Ho*Wo < 2^24.                                  */
+/* Blocks with 1..4 output channels (the UNet's last layer, 64 -> channels_out: a GEMM tile would be 1/64 full) run on the vector
+ * ALUs in plain f32 FMAs straight from W (Cout, C, k, k): no planes, no amax words.  svr_conv2d_small_supported: Cout in 1..4 and
+ * Cout*C*k*k <= 8192 (the weights live in LDS).  Same descriptors (upsample = 0) and the same results layout as above.             */
+int svr_conv2d_small_supported(int32_t Cout, int32_t C, int32_t k);
+int svr_conv2d_small_fwd(const svr_conv2d_desc *d, const float *W, const float *bias, float *Y, int32_t Cout, void *stream);
+int svr_conv2d_small_bwd_data(const svr_conv2d_desc *d, const float *W, const float *dY, int32_t Cout, float *dIn, void *stream);
+int64_t svr_conv2d_small_bwd_weight_workspace(const svr_conv2d_desc *d, int32_t Cout);
+int svr_conv2d_small_bwd_weight(const svr_conv2d_desc *d, const float *dY, int32_t Cout, float *dW, float *db, void *workspace,
+                                void *stream);
 int64_t svr_conv2d_planes_bytes(int32_t Cout, int32_t C, int32_t k);
 int svr_conv2d_prepare(const float *W, int32_t Cout, int32_t C, int32_t k, int32_t stride, int32_t want_bwd, uint32_t *amax,
                        void *planes, void *stream);

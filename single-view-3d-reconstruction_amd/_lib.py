@@ -126,6 +126,11 @@ SIGNATURES = {
     "svr_stage1_bwd": (C.c_int, [P, P, P, P, P, P, P, P, P, P, P, P, P, P, I32, I32, I32, I32, I32, C.c_int, C.c_int, P, P]),
     "svr_conv2d_im2col": (C.c_int, [C.POINTER(Conv2dDesc), P, P]),
     "svr_conv2d_col2im": (C.c_int, [C.POINTER(Conv2dDesc), P, P, P, P, P]),
+    "svr_conv2d_small_supported": (C.c_int, [I32, I32, I32]),
+    "svr_conv2d_small_fwd": (C.c_int, [C.POINTER(Conv2dDesc), P, P, P, I32, P]),
+    "svr_conv2d_small_bwd_data": (C.c_int, [C.POINTER(Conv2dDesc), P, P, I32, P, P]),
+    "svr_conv2d_small_bwd_weight_workspace": (I64, [C.POINTER(Conv2dDesc), I32]),
+    "svr_conv2d_small_bwd_weight": (C.c_int, [C.POINTER(Conv2dDesc), P, I32, P, P, P, P]),
     "svr_conv2d_planes_bytes": (I64, [I32, I32, I32]),
     "svr_conv2d_prepare": (C.c_int, [P, I32, I32, I32, I32, I32, P, P, P]),
     "svr_conv2d_workspace_bytes": (I64, [C.POINTER(Conv2dDesc), I32]),

@@ -13,6 +13,8 @@
 // Bilinear upsample = at::upsample_bilinear2d, align_corners = False, scale 2: src = max(0, 0.5 * (dst + 0.5) - 0.5),
 // i0 = (int)src, i1 = i0 + (i0 < n - 1), l1 = src - i0, l0 = 1 - l1; value = l0y*(l0x*v00 + l1x*v01) + l1y*(l0x*v10 + l1x*v11).
 #include "common.h"
+#include "conv2d_virt.h"
+#include <algorithm>
 
 using namespace svr;
 
@@ -268,4 +270,324 @@ extern "C" int svr_conv2d_finish_bwd(const svr_conv2d_desc *d, const float *dvir
     hipLaunchKernelGGL(conv2d_finish_bwd_kernel<1>, dim3((unsigned)cdiv(ts, 256)), dim3(256), 0, (hipStream_t)stream, dvirt, S, dsrc0, dsrc1,
                        d->B, d->H, d->W, d->act, d->upsample, ts);
   return launch_status("conv2d_finish_bwd");
+}
+
+// ---- convolutions with 1..4 output channels (the UNet's last layer, model/unet.py:60: 64 -> channels_out) ------------------
+// A GEMM tile would be 1/64 .. 1/32 full, so these run on the vector ALUs in plain f32 FMAs (no split, no amax): 16 lanes per
+// pixel, one channel quad each.  Weights are staged in LDS as [tap][c][co]; limit CO * C * k * k <= 8192 floats.
+namespace {
+constexpr int SM_MAXW = 8192;
+
+template <int CO>
+__device__ __forceinline__ void sm_stage_w(const float *__restrict__ W, float *wl, int C, int kk) {
+  for (int i = threadIdx.x; i < CO * C * kk; i += blockDim.x) {   // W[co][c][tap] -> wl[(tap C + c) CO + co]
+    const int tap = i % kk, c = (i / kk) % C, co = i / (kk * C);
+    wl[(tap * C + c) * CO + co] = W[i];
+  }
+  __syncthreads();
+}
+
+// y[(b,oy,ox)][co] = bias[co] + sum_{tap,c} act(in)[b][oy s - 1 + ky][ox s - 1 + kx][c] W[co][c][ky][kx]     (K = 3: s = 1, K = 4: s = 2)
+template <int CO, int K, bool VEC4>
+__global__ __launch_bounds__(256) void conv2d_small_fwd_kernel(const CvSrc S, const float *__restrict__ W, const float *__restrict__ bias,
+                                                               float *__restrict__ Y, int B, int Ho, int Wo) {
+  constexpr int ST = K == 4 ? 2 : 1;
+  __shared__ float wl[SM_MAXW];
+  const int C = S.C0 + S.C1;
+  sm_stage_w<CO>(W, wl, C, K * K);
+  const int64_t M = (int64_t)B * Ho * Wo;
+  const int l16 = threadIdx.x & 15;
+  // (a workgroup stages the weights once and then walks pixel groups: with one group per workgroup the staging was the kernel)
+  for (int64_t pix0 = (int64_t)blockIdx.x * 16; pix0 < M; pix0 += (int64_t)gridDim.x * 16) {
+  const int64_t pix = pix0 + (threadIdx.x >> 4);
+  float acc[CO];
+#pragma unroll
+  for (int o = 0; o < CO; ++o) acc[o] = 0.f;
+  if (pix < M) {
+    const int ox = (int)(pix % Wo), oy = (int)((pix / Wo) % Ho), b = (int)(pix / ((int64_t)Wo * Ho));
+    const int64_t p0 = (int64_t)b * S.H * S.W;
+    for (int c = l16 * 4; c < C; c += 64) {
+      float4 v[K * K];
+#pragma unroll
+      for (int ky = 0; ky < K; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < K; ++kx) v[ky * K + kx] = cv_load4<VEC4>(S, p0, oy * ST - 1 + ky, ox * ST - 1 + kx, c);   // all taps in flight
+#pragma unroll
+      for (int tap = 0; tap < K * K; ++tap) {
+        const float4 a = cv_act4(v[tap], S.act);
+        const float *w = wl + (tap * C + c) * CO;
+        const float e[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (c + u < C) {
+#pragma unroll
+            for (int o = 0; o < CO; ++o) acc[o] = fmaf(e[u], w[u * CO + o], acc[o]);
+          }
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 0; o < CO; ++o) {
+#pragma unroll
+    for (int d = 8; d > 0; d >>= 1) acc[o] += __shfl_xor(acc[o], d);
+  }
+  if (pix < M && l16 == 0) {
+#pragma unroll
+    for (int o = 0; o < CO; ++o) Y[pix * CO + o] = acc[o] + (bias ? bias[o] : 0.f);
+  }
+  }
+}
+
+// dIn[(b,y,x)][c] = sum over the taps that reach the pixel of dY[b][(y + 1 - ky) / s][(x + 1 - kx) / s][co] W[co][c][ky][kx]
+template <int CO, int K>
+__global__ __launch_bounds__(256) void conv2d_small_bwd_data_kernel(const float *__restrict__ dY, const float *__restrict__ W,
+                                                                    float *__restrict__ dIn, int B, int H, int Wd, int C, int Ho, int Wo) {
+  constexpr int ST = K == 4 ? 2 : 1;
+  __shared__ float wl[SM_MAXW];
+  const int CQ = (C + 3) / 4;
+  sm_stage_w<CO>(W, wl, C, K * K);
+  const int64_t total = (int64_t)B * H * Wd * CQ;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+  const int c = (int)(idx % CQ) * 4;
+  const int64_t r = idx / CQ;
+  const int x = (int)(r % Wd), y = (int)((r / Wd) % H), b = (int)(r / ((int64_t)Wd * H));
+  float g[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int ky = 0; ky < K; ++ky) {
+    const int ty = y + 1 - ky;
+    if (ty < 0 || (ST == 2 && (ty & 1)) || ty / ST >= Ho) continue;
+#pragma unroll
+    for (int kx = 0; kx < K; ++kx) {
+      const int tx = x + 1 - kx;
+      if (tx < 0 || (ST == 2 && (tx & 1)) || tx / ST >= Wo) continue;
+      const float *q = dY + (((int64_t)b * Ho + ty / ST) * Wo + tx / ST) * CO;
+      const float *w = wl + ((ky * K + kx) * C + c) * CO;
+#pragma unroll
+      for (int o = 0; o < CO; ++o) {
+        const float d = q[o];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (c + u < C) g[u] = fmaf(d, w[u * CO + o], g[u]);
+      }
+    }
+  }
+  float *o = dIn + r * C + c;
+  if (c + 4 <= C && (C & 3) == 0) *reinterpret_cast<float4 *>(o) = make_float4(g[0], g[1], g[2], g[3]);
+  else
+    for (int u = 0; u < 4 && c + u < C; ++u) o[u] = g[u];
+  }
+}
+
+// partial[block][(tap C + c) CO + co] = sum over the block's pixels of dY[m][co] act(in)[m + tap][c]; partial db behind it.
+// A thread owns one (tap, channel quad) item; the 1024 threads of a workgroup are G groups of `ipg` items that take the
+// block's pixels in turns, four at a time (four gathers in flight per thread), and are summed through LDS in group order.
+template <int CO, int K, bool VEC4>
+__global__ __launch_bounds__(1024) void conv2d_small_bwd_weight_kernel(const CvSrc S, const float *__restrict__ dY, float *__restrict__ part,
+                                                                       int B, int Ho, int Wo, float rWo, float rHoWo, int rows_per_block,
+                                                                       int ipg, int G) {
+  constexpr int ST = K == 4 ? 2 : 1, U = 4;
+  __shared__ float red[1024 * (4 * CO + 1)];
+  const int C = S.C0 + S.C1, CQ = (C + 3) / 4, items = K * K * CQ;
+  const int g = threadIdx.x / ipg, il = threadIdx.x % ipg, it = blockIdx.y * ipg + il;
+  const int64_t M = (int64_t)B * Ho * Wo, m0 = (int64_t)blockIdx.x * rows_per_block, m1 = min(M, m0 + rows_per_block);
+  const int tap = it / CQ, c = (it % CQ) * 4;
+  const bool live = g < G && it < items;
+  const int ty = tap / K - 1, tx = tap % K - 1, HoWo = Ho * Wo;
+  float acc[CO][4];
+  float dbs[CO];
+#pragma unroll
+  for (int o = 0; o < CO; ++o) {
+    dbs[o] = 0.f;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc[o][u] = 0.f;
+  }
+  if (live) {
+    for (int64_t mb = m0 + (int64_t)g * U; mb < m1; mb += (int64_t)G * U) {
+      float d[U][CO];
+      float4 v[U];
+#pragma unroll
+      for (int j = 0; j < U; ++j) {
+        const int64_t m = mb + j;
+        const bool ok = m < m1;
+        int b, rem, oy, ox;
+        cv_divmod((int)(ok ? m : m0), HoWo, rHoWo, b, rem);
+        cv_divmod(rem, Wo, rWo, oy, ox);
+#pragma unroll
+        for (int o = 0; o < CO; ++o) d[j][o] = ok ? dY[m * CO + o] : 0.f;
+        v[j] = ok ? cv_load4<VEC4>(S, (int64_t)b * S.H * S.W, oy * ST + ty, ox * ST + tx, c) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int j = 0; j < U; ++j) {
+        const float4 a = cv_act4(v[j], S.act);
+#pragma unroll
+        for (int o = 0; o < CO; ++o) {
+          acc[o][0] = fmaf(d[j][o], a.x, acc[o][0]); acc[o][1] = fmaf(d[j][o], a.y, acc[o][1]);
+          acc[o][2] = fmaf(d[j][o], a.z, acc[o][2]); acc[o][3] = fmaf(d[j][o], a.w, acc[o][3]);
+          dbs[o] += d[j][o];
+        }
+      }
+    }
+  }
+  float *mine = red + threadIdx.x * (4 * CO + 1);       // (odd stride: conflict-free column walks)
+#pragma unroll
+  for (int o = 0; o < CO; ++o) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) mine[o * 4 + u] = acc[o][u];
+  }
+  mine[4 * CO] = 0.f;
+  __syncthreads();
+  const int64_t stride_p = (int64_t)K * K * C * CO + CO;
+  float *p = part + blockIdx.x * stride_p;
+  if (g == 0 && it < items) {
+#pragma unroll
+    for (int o = 0; o < CO; ++o)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        float sum = 0.f;
+        for (int q = 0; q < G; ++q) sum += red[(q * ipg + il) * (4 * CO + 1) + o * 4 + u];
+        if (c + u < C) p[(tap * C + c + u) * CO + o] = sum;
+      }
+  }
+  __syncthreads();
+  if (il == 0 && g < G && blockIdx.y == 0) {   // db: every group summed dY over its own pixels
+#pragma unroll
+    for (int o = 0; o < CO; ++o) red[g * CO + o] = dbs[o];
+  }
+  __syncthreads();
+  if (threadIdx.x < CO && blockIdx.y == 0) {
+    float sum = 0.f;
+    for (int q = 0; q < G; ++q) sum += red[q * CO + threadIdx.x];
+    p[(int64_t)K * K * C * CO + threadIdx.x] = sum;
+  }
+}
+// dW (CO, C, k, k) and db from the per-block partials, fixed order: 16 outputs per workgroup, sixteen lane groups walk the parts
+__global__ __launch_bounds__(256) void conv2d_small_wgrad_reduce_kernel(const float *__restrict__ part, float *__restrict__ dW,
+                                                                        float *__restrict__ db, int CO, int C, int kk, int parts) {
+  __shared__ float red[256];
+  const int total = kk * C * CO + CO, e = blockIdx.x * 16 + (threadIdx.x & 15), g = threadIdx.x >> 4;
+  float s = 0.f;
+  if (e < total)
+    for (int p = g; p < parts; p += 16) s += part[(int64_t)p * total + e];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  if (g == 0 && e < total) {
+    float v = 0.f;
+    for (int q = 0; q < 16; ++q) v += red[q * 16 + (threadIdx.x & 15)];
+    if (e >= kk * C * CO) {
+      if (db) db[e - kk * C * CO] = v;
+    } else {
+      const int co = e % CO, c = (e / CO) % C, tap = e / (CO * C);
+      dW[((int64_t)co * C + c) * kk + tap] = v;
+    }
+  }
+}
+
+int sm_check(const svr_conv2d_desc *d, int Cout, const char *what) {
+  SVR_CHECK(d && d->src0 && d->B > 0 && d->H > 0 && d->W > 0 && d->C0 > 0 && d->C1 >= 0, SVR_E_BADARG, "%s: bad descriptor", what);
+  SVR_CHECK(d->C1 == 0 || d->src1, SVR_E_BADARG, "%s: C1 = %d without a second source", what, d->C1);
+  SVR_CHECK((d->k == 4 && d->stride == 2) || (d->k == 3 && d->stride == 1), SVR_E_UNSUPPORTED, "%s: k=%d stride=%d", what, d->k, d->stride);
+  SVR_CHECK(!d->upsample, SVR_E_UNSUPPORTED, "%s: the x2 upsample is materialised first (svr_conv2d_virtual)", what);
+  SVR_CHECK((int64_t)d->B * d->H * d->W < (1 << 24), SVR_E_UNSUPPORTED, "%s: %ld pixels (row decode limit 2^24)", what, (long)d->B * d->H * d->W);
+  SVR_CHECK(Cout >= 1 && Cout <= 4 && (int64_t)Cout * (d->C0 + d->C1) * d->k * d->k <= SM_MAXW, SVR_E_UNSUPPORTED,
+            "%s: Cout=%d C=%d (1..4 output channels, Cout*C*k*k <= %d)", what, Cout, d->C0 + d->C1, SM_MAXW);
+  return SVR_OK;
+}
+bool sm_vec4(const svr_conv2d_desc *d) {
+  return d->C0 % 4 == 0 && d->C1 % 4 == 0 && (((uintptr_t)d->src0 | (uintptr_t)d->src1) & 15) == 0;
+}
+int sm_rows_per_block(int64_t M) { return (int)std::max<int64_t>(64, cdiv(cdiv(M, 1024), 4) * 4); }
+}  // namespace
+
+extern "C" int svr_conv2d_small_supported(int32_t Cout, int32_t C, int32_t k) { return Cout >= 1 && Cout <= 4 && (int64_t)Cout * C * k * k <= SM_MAXW; }
+
+#define SM_CO(CALL)              \
+  switch (Cout) {                \
+    case 1: { CALL(1); } break;  \
+    case 2: { CALL(2); } break;  \
+    case 3: { CALL(3); } break;  \
+    default: { CALL(4); } break; \
+  }
+
+extern "C" int svr_conv2d_small_fwd(const svr_conv2d_desc *d, const float *W, const float *bias, float *Y, int32_t Cout, void *stream) {
+  if (int rc = sm_check(d, Cout, "conv2d_small_fwd")) return rc;
+  SVR_CHECK(W && Y, SVR_E_BADARG, "conv2d_small_fwd: null pointer");
+  int Hv, Wv, Ho, Wo;
+  out_dims(d, Hv, Wv, Ho, Wo);
+  const CvSrc S{d->src0, d->src1, d->C0, d->C1, d->H, d->W, d->act};
+  const int64_t M = (int64_t)d->B * Ho * Wo;
+  const dim3 grid((unsigned)std::min<int64_t>(cdiv(M, 16), 2048));
+  hipStream_t s = (hipStream_t)stream;
+  const bool v4 = sm_vec4(d);
+#define CALL(N)                                                                                                          \
+  if (d->k == 3) {                                                                                                       \
+    if (v4) hipLaunchKernelGGL((conv2d_small_fwd_kernel<N, 3, true>), grid, dim3(256), 0, s, S, W, bias, Y, d->B, Ho, Wo);   \
+    else hipLaunchKernelGGL((conv2d_small_fwd_kernel<N, 3, false>), grid, dim3(256), 0, s, S, W, bias, Y, d->B, Ho, Wo);     \
+  } else {                                                                                                               \
+    if (v4) hipLaunchKernelGGL((conv2d_small_fwd_kernel<N, 4, true>), grid, dim3(256), 0, s, S, W, bias, Y, d->B, Ho, Wo);   \
+    else hipLaunchKernelGGL((conv2d_small_fwd_kernel<N, 4, false>), grid, dim3(256), 0, s, S, W, bias, Y, d->B, Ho, Wo);     \
+  }
+  SM_CO(CALL)
+#undef CALL
+  return launch_status("conv2d_small_fwd");
+}
+
+extern "C" int svr_conv2d_small_bwd_data(const svr_conv2d_desc *d, const float *W, const float *dY, int32_t Cout, float *dIn, void *stream) {
+  if (int rc = sm_check(d, Cout, "conv2d_small_bwd_data")) return rc;
+  SVR_CHECK(W && dY && dIn, SVR_E_BADARG, "conv2d_small_bwd_data: null pointer");
+  int Hv, Wv, Ho, Wo;
+  out_dims(d, Hv, Wv, Ho, Wo);
+  const int C = d->C0 + d->C1;
+  const int64_t total = (int64_t)d->B * d->H * d->W * ((C + 3) / 4);
+  SVR_CHECK((((uintptr_t)dIn) & 15) == 0, SVR_E_ALIGN, "conv2d_small_bwd_data: dIn must be 16-byte aligned");
+  const unsigned gridx = (unsigned)std::min<int64_t>(cdiv(total, 256), 4096);
+  hipStream_t s = (hipStream_t)stream;
+#define CALL(N)                                                                                                                              \
+  if (d->k == 3) hipLaunchKernelGGL((conv2d_small_bwd_data_kernel<N, 3>), dim3(gridx), dim3(256), 0, s, dY, W, dIn, d->B, d->H, d->W, C, Ho, Wo); \
+  else hipLaunchKernelGGL((conv2d_small_bwd_data_kernel<N, 4>), dim3(gridx), dim3(256), 0, s, dY, W, dIn, d->B, d->H, d->W, C, Ho, Wo)
+  SM_CO(CALL)
+#undef CALL
+  return launch_status("conv2d_small_bwd_data");
+}
+
+extern "C" int64_t svr_conv2d_small_bwd_weight_workspace(const svr_conv2d_desc *d, int32_t Cout) {
+  if (!d) return 0;
+  int Hv, Wv, Ho, Wo;
+  out_dims(d, Hv, Wv, Ho, Wo);
+  const int64_t M = (int64_t)d->B * Ho * Wo;
+  const int64_t parts = cdiv(M, sm_rows_per_block(M));
+  return parts * ((int64_t)d->k * d->k * (d->C0 + d->C1) * Cout + Cout) * 4 + 256;
+}
+
+extern "C" int svr_conv2d_small_bwd_weight(const svr_conv2d_desc *d, const float *dY, int32_t Cout, float *dW, float *db, void *workspace,
+                                           void *stream) {
+  if (int rc = sm_check(d, Cout, "conv2d_small_bwd_weight")) return rc;
+  SVR_CHECK(dY && dW && workspace, SVR_E_BADARG, "conv2d_small_bwd_weight: null pointer");
+  int Hv, Wv, Ho, Wo;
+  out_dims(d, Hv, Wv, Ho, Wo);
+  const int C = d->C0 + d->C1, kk = d->k * d->k;
+  const CvSrc S{d->src0, d->src1, d->C0, d->C1, d->H, d->W, d->act};
+  const int64_t M = (int64_t)d->B * Ho * Wo;
+  const int rpb = sm_rows_per_block(M);
+  const int parts = (int)cdiv(M, rpb);
+  float *part = (float *)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+  const int items = kk * ((C + 3) / 4);
+  const int ipg = std::min(1024, (items + 63) / 64 * 64), G = std::max(1, 1024 / ipg);   // items per group, groups per workgroup
+  const dim3 grid((unsigned)parts, (unsigned)cdiv(items, ipg));
+  hipStream_t s = (hipStream_t)stream;
+  const bool v4 = sm_vec4(d);
+  const float rWo = 1.0f / (float)Wo, rHW = 1.0f / (float)(Ho * Wo);
+#define CALL(N)                                                                                                                                  \
+  if (d->k == 3) {                                                                                                                               \
+    if (v4) hipLaunchKernelGGL((conv2d_small_bwd_weight_kernel<N, 3, true>), grid, dim3(1024), 0, s, S, dY, part, d->B, Ho, Wo, rWo, rHW, rpb, ipg, G);    \
+    else hipLaunchKernelGGL((conv2d_small_bwd_weight_kernel<N, 3, false>), grid, dim3(1024), 0, s, S, dY, part, d->B, Ho, Wo, rWo, rHW, rpb, ipg, G);      \
+  } else {                                                                                                                                       \
+    if (v4) hipLaunchKernelGGL((conv2d_small_bwd_weight_kernel<N, 4, true>), grid, dim3(1024), 0, s, S, dY, part, d->B, Ho, Wo, rWo, rHW, rpb, ipg, G);    \
+    else hipLaunchKernelGGL((conv2d_small_bwd_weight_kernel<N, 4, false>), grid, dim3(1024), 0, s, S, dY, part, d->B, Ho, Wo, rWo, rHW, rpb, ipg, G);      \
+  }
+  SM_CO(CALL)
+#undef CALL
+  const int total = kk * C * Cout + Cout;
+  hipLaunchKernelGGL(conv2d_small_wgrad_reduce_kernel, dim3((unsigned)cdiv(total, 16)), dim3(256), 0, s, (const float *)part, dW, db, Cout, C, kk,
+                     parts);
+  return launch_status("conv2d_small_bwd_weight");
 }

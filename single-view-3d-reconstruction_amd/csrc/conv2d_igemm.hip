@@ -278,6 +278,18 @@ __global__ __launch_bounds__(256) void ig_reduce_kernel(const float *__restrict_
   Y[i] = s + (bias ? bias[i % N] : 0.f);
 }
 
+// max |W| of a contiguous weight -> amax[0] (zeroed first); one wave-level reduction and at most one atomic per wave
+__global__ __launch_bounds__(256) void ig_amax_kernel(const float *__restrict__ W, int64_t n, uint32_t *__restrict__ amax) {
+  float m = 0.f;
+  const int64_t n4 = n >> 2;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    const float4 v = reinterpret_cast<const float4 *>(W)[i];
+    m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) m = fmaxf(m, fabsf(W[(n4 << 2) + threadIdx.x]));
+  svr_amax_publish(amax, m);
+}
+
 // ---- weight planes ------------------------------------------------------------------------------------------------------
 // forward: rows n = co, reduction k' = (ky k + kx) Cpad + c; [k-step][hi / lo][n][16 halves] (gemm_f16x3.hip's layout)
 __global__ __launch_bounds__(256) void ig_split_fwd_kernel(const float *__restrict__ W, const uint32_t *__restrict__ amax,
@@ -375,8 +387,11 @@ extern "C" int svr_conv2d_prepare(const float *W, int32_t Cout, int32_t C, int32
   uint16_t *pf = (uint16_t *)(((uintptr_t)planes + 255) & ~(uintptr_t)255);
   uint16_t *pb = (uint16_t *)((char *)pf + a256(4LL * Cout * k * k * pad16(C)));
   (void)hipMemsetAsync(amax, 0, sizeof(uint32_t), s);
-  hipLaunchKernelGGL(w_amax_kernel, dim3((unsigned)std::min<int64_t>(cdiv(numel, 1024), 1024)), dim3(256), 0, s, W, numel, (int64_t)1,
-                     numel, amax);
+  if ((((uintptr_t)W) & 15) == 0)
+    hipLaunchKernelGGL(ig_amax_kernel, dim3((unsigned)std::min<int64_t>(cdiv(numel, 4096), 256)), dim3(256), 0, s, W, numel, amax);
+  else
+    hipLaunchKernelGGL(w_amax_kernel, dim3((unsigned)std::min<int64_t>(cdiv(numel, 1024), 1024)), dim3(256), 0, s, W, numel, (int64_t)1,
+                       numel, amax);
   const int Cpad = pad16(C), Copad = pad16(Cout);
   hipLaunchKernelGGL(ig_split_fwd_kernel, dim3((unsigned)cdiv((int64_t)Cout * k * k * Cpad / 2, 256)), dim3(256), 0, s, W, amax, pf,
                      Cout, C, k, Cpad);

@@ -1276,13 +1276,18 @@ UNET_IGEMM = os.environ.get("SVR_UNET_IGEMM", "1") != "0"      # "0": the explic
 
 
 class Conv2dPlanes:
-    """Split f16 planes of one nn.Conv2d weight (forward and backward-data products) + the word holding max|W|."""
+    """Split f16 planes of one nn.Conv2d weight (forward and backward-data products) + the word holding max|W|.  Layers with
+    1..4 output channels keep the f32 weight itself (`small`: plain-FMA kernels, conv2d.hip)."""
 
     def __init__(self, weight, stride, want_bwd=True):
         _f32(weight)
         w = weight.detach().contiguous()
         self.Cout, self.C, self.k = int(w.shape[0]), int(w.shape[1]), int(w.shape[2])
         self.stride, self.has_bwd = stride, bool(want_bwd)
+        self.small = bool(_lib.lib().svr_conv2d_small_supported(self.Cout, self.C, self.k))
+        if self.small:
+            self.w, self.has_bwd = w, True
+            return
         nbytes = 256 + _lib.lib().svr_conv2d_planes_bytes(self.Cout, self.C, self.k)
         self.buf = torch.empty(nbytes, device=w.device, dtype=torch.uint8)
         check(_lib.lib().svr_conv2d_prepare(_p(w), self.Cout, self.C, self.k, stride, int(self.has_bwd), self.amax_ptr(),
@@ -1321,6 +1326,9 @@ def conv2d_fwd(src0, src1, k, stride, act, planes, bias):
         raise ValueError("conv2d_fwd: the planes were prepared for another layer")
     _f32(bias)
     y = torch.empty(d.B, Ho, Wo, planes.Cout, device=src0.device, dtype=torch.float32)
+    if planes.small:
+        check(_lib.lib().svr_conv2d_small_fwd(C.byref(d), _p(planes.w), _p(bias), _p(y), planes.Cout, _stream()), "conv2d_small_fwd")
+        return y
     ws = _conv2d_ws(_lib.lib().svr_conv2d_workspace_bytes(C.byref(d), planes.Cout), src0.device)
     check(_lib.lib().svr_conv2d_fwd(C.byref(d), planes.planes_ptr(), planes.amax_ptr(), _p(bias), _p(y), planes.Cout, _p(ws),
                                     _stream()), "conv2d_fwd")
@@ -1335,6 +1343,9 @@ def conv2d_bwd_data(src0, src1, k, stride, planes, dy):
     _f32(dy)
     dy = dy.contiguous()
     din = torch.empty(d.B, d.H, d.W, d.C0 + d.C1, device=dy.device, dtype=torch.float32)
+    if planes.small:
+        check(_lib.lib().svr_conv2d_small_bwd_data(C.byref(d), _p(planes.w), _p(dy), planes.Cout, _p(din), _stream()), "conv2d_small_bwd_data")
+        return din
     ws = _conv2d_ws(_lib.lib().svr_conv2d_workspace_bytes(C.byref(d), planes.Cout), dy.device)
     check(_lib.lib().svr_conv2d_bwd_data(C.byref(d), planes.planes_ptr(), planes.amax_ptr(), _p(dy), _amax_any(dy).data_ptr(),
                                          planes.Cout, _p(din), _p(ws), _stream()), "conv2d_bwd_data")
@@ -1359,6 +1370,10 @@ def conv2d_bwd_weight(src0, src1, k, stride, act, dy, Cout, want_bias=True):
     dy = dy.contiguous()
     dw = torch.empty(Cout, d.C0 + d.C1, k, k, device=dy.device, dtype=torch.float32)
     db = torch.empty(Cout, device=dy.device, dtype=torch.float32) if want_bias else None
+    if _lib.lib().svr_conv2d_small_supported(Cout, d.C0 + d.C1, k):
+        ws = _conv2d_ws(_lib.lib().svr_conv2d_small_bwd_weight_workspace(C.byref(d), Cout), dy.device)
+        check(_lib.lib().svr_conv2d_small_bwd_weight(C.byref(d), _p(dy), Cout, _p(dw), _p(db), _p(ws), _stream()), "conv2d_small_bwd_weight")
+        return dw, db
     ws = _conv2d_ws(_lib.lib().svr_conv2d_bwd_weight_workspace(C.byref(d), Cout), dy.device)
     check(_lib.lib().svr_conv2d_bwd_weight(C.byref(d), _p(dy), _amax_any(dy).data_ptr(), Cout, _p(dw), _p(db), _p(ws), _stream()),
           "conv2d_bwd_weight")
