@@ -3,11 +3,13 @@ the stage in front of the hot path in BASELINE config 5 (SURVEY.md section 8 row
 
 Same constructor arguments, forward signature ((B,Cin,H,W) -> (B,Cout,H,W)) and parameter / buffer names, so `unet.*`
 checkpoint entries load (trainer/trainer_scene_net.py:204-212).  The nn.Conv2d / nn.BatchNorm2d submodules only HOLD the
-parameters.  backend="hip" (default on GPU tensors): every layer runs in the library's kernels -- an explicit im2col with
-the LeakyReLU / ReLU, the bilinear x2 upsample and the decoder's torch.cat fused into the gather (conv2d.hip), the
-split-precision MFMA GEMMs of the point MLP for the products (f16x3 forward, bf16x3 backward), and the BatchNorm kernels
-of the 3-D encoder on (B,1,H,W,C) views; activations are channels-last inside.  backend="stock": the layers as stock
-PyTorch-ROCm ops (MIOpen), kept for A/B measurements (15-50 ms per config-5 step against ~3 ms)."""
+parameters.  backend="hip" (default on GPU tensors): every convolution block runs in the library's kernels as an IMPLICIT GEMM
+(conv2d_igemm.hip: the A operand of the split-precision MFMA GEMM is gathered from the channels-last activation, LeakyReLU /
+ReLU and the decoder's torch.cat applied on the way in; a decoder block writes its x2-upsampled input once; stride-2 backward-data
+as four parity-class problems; the weight gradient through a gather loader in the dW kernel; the 1-channel output layer on
+plain-FMA kernels), BatchNorm in the 3-D encoder's kernels on (B,1,H,W,C) views; activations are channels-last inside.  The explicit
+patch-matrix path of rounds 2-3 (_ConvBlockFn) is kept for A/B (SVR_UNET_IGEMM=0) and for the bf16x3 / exact-f32 backward modes.
+backend="stock": the layers as stock PyTorch-ROCm ops (MIOpen), kept for A/B measurements (15-50 ms per config-5 step)."""
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
