@@ -189,6 +189,69 @@ __global__ __launch_bounds__(256) void conv3d_to1_kernel(const float *__restrict
   out[m] = acc;
 }
 
+// The same sum, round 4 (config 5 needs the occupancy grid's gradient: 0.87 ms at 4 x 128^3 x 16 with the kernel above, which
+// issues 27 x CI/4 sixteen-byte loads per output at 64-byte lane strides -- bound by the address path, 32 lines per wave load).
+// Here a wave owns 64 / (CI/4) consecutive x and a column of ZT outputs along z; a lane owns ONE channel quad of one x, so a wave
+// load is 1 KB contiguous (8 lines); for every (dy, dx) the lane walks the ZT + 2 input voxels of its column once and feeds each
+// into the (up to) three outputs it belongs to, with that (dy, dx)'s 3 x 4 weights in registers: (ZT + 2) / ZT x 9 loads per
+// output and quad instead of 27.  The quads of an output are summed with two (three) xor-shuffles.
+template <int CI, int ZT>
+__global__ __launch_bounds__(256) void conv3d_to1_col_kernel(const float *__restrict__ in, const float *__restrict__ Wp,
+                                                             float *__restrict__ out, ConvShape s, int nxb, int nzb) {
+  constexpr int QL = CI / 4, XL = 64 / QL;
+  __shared__ __attribute__((aligned(16))) float w[27 * CI];
+  for (int i = threadIdx.x; i < 27 * CI; i += blockDim.x) w[i] = Wp[i];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, q = lane % QL, xi = lane / QL;
+  const int64_t wid = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);      // one wave = one (b, z block, y, x block)
+  const int64_t total = (int64_t)s.B * nzb * s.H * nxb;
+  if (wid >= total) return;
+  const int xb = (int)(wid % nxb);
+  int64_t r = wid / nxb;
+  const int y = (int)(r % s.H);
+  r /= s.H;
+  const int z0 = (int)(r % nzb) * ZT;
+  const int64_t b = r / nzb;
+  const int x = xb * XL + xi;
+  const float *ib = in + b * s.D * s.H * s.W * CI + q * 4;
+  float acc[ZT];
+#pragma unroll
+  for (int o = 0; o < ZT; ++o) acc[o] = 0.f;
+  // (runtime loops: fully unrolled, the compiler put all nine columns' loads in flight -- 500 registers, one wave per SIMD)
+#pragma unroll 1
+  for (int dy = 0; dy < 3; ++dy) {
+    const int yy = y + dy - 1;
+#pragma unroll 1
+    for (int dx = 0; dx < 3; ++dx) {
+      const int xx = x + dx - 1;
+      const bool okxy = yy >= 0 && yy < s.H && xx >= 0 && xx < s.W;
+      float4 k[3];
+#pragma unroll
+      for (int dz = 0; dz < 3; ++dz) k[dz] = *reinterpret_cast<const float4 *>(w + ((dz * 3 + dy) * 3 + dx) * CI + q * 4);
+      const float *col = ib + ((int64_t)(okxy ? yy : 0) * s.W + (okxy ? xx : 0)) * CI;
+      float4 v[ZT + 2];
+#pragma unroll
+      for (int j = 0; j < ZT + 2; ++j) {     // input voxel z0 - 1 + j
+        const int zz = z0 - 1 + j;
+        v[j] = (okxy && zz >= 0 && zz < s.D) ? *reinterpret_cast<const float4 *>(col + (int64_t)zz * s.H * s.W * CI) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int o = 0; o < ZT; ++o)
+#pragma unroll
+        for (int dz = 0; dz < 3; ++dz) {      // output z0 + o reads input z0 + o + dz - 1 = v[o + dz]
+          const float4 a = v[o + dz];
+          acc[o] += a.x * k[dz].x + a.y * k[dz].y + a.z * k[dz].z + a.w * k[dz].w;
+        }
+    }
+  }
+#pragma unroll
+  for (int o = 0; o < ZT; ++o) {
+#pragma unroll
+    for (int d = 1; d < QL; d <<= 1) acc[o] += __shfl_xor(acc[o], d);
+    if (q == 0 && x < s.W && z0 + o < s.D) out[((b * s.D + z0 + o) * s.H + y) * s.W + x] = acc[o];
+  }
+}
+
 constexpr int BW_ROWS = 64;   // (b,z,y) rows per workgroup of the Ci == 1 weight-gradient kernel: 2048 workgroups at
                               // 128^3 x 8 (with 256 rows the grid was 2 workgroups per CU and the kernel latency bound)
 
@@ -809,7 +872,14 @@ extern "C" int svr_conv3d_k3(const float *in, const float *Wp, const float *bias
   if (Co == 1) {
     SVR_CHECK(epilogue == SVR_EPI_NONE, SVR_E_UNSUPPORTED, "conv3d: Co=1 supports no epilogue");
     unsigned grid = (unsigned)cdiv(M, 256);
-    if (Ci == 16) hipLaunchKernelGGL(conv3d_to1_kernel<16>, dim3(grid), dim3(256), 0, s, in, Wp, out, sh);
+    static const int to1_col = getenv("SVR_TO1_COL") ? atoi(getenv("SVR_TO1_COL")) : 1;   // measurement switch: 0 = one output per thread
+    constexpr int ZT = 8;
+    const int nzb = (int)cdiv(D, ZT), nxb16 = (int)cdiv(W, 16), nxb32 = (int)cdiv(W, 8);
+    if (to1_col && Ci == 16 && (((uintptr_t)in) & 15) == 0)
+      hipLaunchKernelGGL((conv3d_to1_col_kernel<16, ZT>), dim3((unsigned)cdiv((int64_t)B * nzb * H * nxb16, 4)), dim3(256), 0, s, in, Wp, out, sh, nxb16, nzb);
+    else if (to1_col && Ci == 32 && (((uintptr_t)in) & 15) == 0)
+      hipLaunchKernelGGL((conv3d_to1_col_kernel<32, ZT>), dim3((unsigned)cdiv((int64_t)B * nzb * H * nxb32, 4)), dim3(256), 0, s, in, Wp, out, sh, nxb32, nzb);
+    else if (Ci == 16) hipLaunchKernelGGL(conv3d_to1_kernel<16>, dim3(grid), dim3(256), 0, s, in, Wp, out, sh);
     else if (Ci == 32) hipLaunchKernelGGL(conv3d_to1_kernel<32>, dim3(grid), dim3(256), 0, s, in, Wp, out, sh);
     else SVR_CHECK(false, SVR_E_UNSUPPORTED, "conv3d: Co=1 supports Ci in {16,32}, got %d", Ci);
     return launch_status("conv3d_to1");

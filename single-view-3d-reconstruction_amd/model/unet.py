@@ -106,7 +106,6 @@ class _ConvBlockIgemmFn(torch.autograd.Function):
         if need0 or need1:
             dvirt = ops.conv2d_bwd_data(a0, a1, k, stride, ctx.planes, dy)
             d0, d1 = ops.conv2d_finish_bwd(src0, src1, act, up, dvirt, need0, need1)
-        ctx.planes = None
         return d0, d1, dw, db, None, None, None, None
 
 
