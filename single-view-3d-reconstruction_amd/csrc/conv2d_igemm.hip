@@ -346,7 +346,8 @@ int ig_check(const svr_conv2d_desc *d, int Cout, const char *what) {
 
 // reduction splits: enough workgroups to fill the chip, at least 8 k-steps each
 int ig_splits(int64_t tiles, int ksteps, int *ksplit) {
-  int splits = (int)std::min<int64_t>(std::max<int64_t>(1, 512 / std::max<int64_t>(tiles, 1)), std::max(1, ksteps / 8));
+  static const int target = getenv("SVR_IG_TARGET") ? atoi(getenv("SVR_IG_TARGET")) : 512;   // measurement switch
+  int splits = (int)std::min<int64_t>(std::max<int64_t>(1, target / std::max<int64_t>(tiles, 1)), std::max(1, ksteps / 8));
   splits = std::min(splits, 64);
   static const int forced = getenv("SVR_IG_SPLITS") ? atoi(getenv("SVR_IG_SPLITS")) : 0;   // measurement switch
   if (forced > 0) splits = std::min(forced, ksteps);
