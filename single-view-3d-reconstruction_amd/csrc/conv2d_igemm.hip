@@ -344,9 +344,12 @@ int ig_check(const svr_conv2d_desc *d, int Cout, const char *what) {
   return SVR_OK;
 }
 
-// reduction splits: enough workgroups to fill the chip, at least 8 k-steps each
-int ig_splits(int64_t tiles, int ksteps, int *ksplit) {
-  static const int target = getenv("SVR_IG_TARGET") ? atoi(getenv("SVR_IG_TARGET")) : 512;   // measurement switch
+// reduction splits: enough workgroups to fill the chip (512 four-wave or 1 024 two-wave ones: two waves per SIMD -- a k-step is a
+// dependent chain load -> split -> LDS -> MFMA, and with one wave per SIMD the 512-tile layers ran at 2.8 us per k-step;
+// tools/exp/unet_target.sh), at least 8 k-steps each
+int ig_splits(int64_t tiles, int ksteps, int n_out, int *ksplit) {
+  static const int forced_target = getenv("SVR_IG_TARGET") ? atoi(getenv("SVR_IG_TARGET")) : 0;   // measurement switch
+  const int target = forced_target > 0 ? forced_target : (n_out <= 64 ? 1024 : 512);
   int splits = (int)std::min<int64_t>(std::max<int64_t>(1, target / std::max<int64_t>(tiles, 1)), std::max(1, ksteps / 8));
   splits = std::min(splits, 64);
   static const int forced = getenv("SVR_IG_SPLITS") ? atoi(getenv("SVR_IG_SPLITS")) : 0;   // measurement switch
@@ -410,11 +413,11 @@ extern "C" int64_t svr_conv2d_workspace_bytes(const svr_conv2d_desc *d, int32_t 
   const int Ho = (d->H + 2 - d->k) / d->stride + 1, Wo = (d->W + 2 - d->k) / d->stride + 1;
   int ks;
   const int64_t mf = cdiv((int64_t)d->B * Ho * Wo, GTM) * cdiv(Cout, Cout <= 64 ? 64 : 128);
-  const int sf = ig_splits(mf, d->k * d->k * pad16(C) / GK, &ks);
+  const int sf = ig_splits(mf, d->k * d->k * pad16(C) / GK, Cout, &ks);
   const int64_t fwd = sf > 1 ? (int64_t)sf * d->B * Ho * Wo * Cout * 4 : 0;
   const int ncls = d->stride == 2 ? 4 : 1;
   const int64_t mb = cdiv((int64_t)d->B * cdiv(d->H, d->stride) * cdiv(d->W, d->stride), GTM) * cdiv(C, C <= 64 ? 64 : 128);
-  const int sb = ig_splits(mb * ncls, (d->stride == 2 ? 4 : 9) * pad16(Cout) / GK, &ks);
+  const int sb = ig_splits(mb * ncls, (d->stride == 2 ? 4 : 9) * pad16(Cout) / GK, C, &ks);
   const int64_t bwd = sb > 1 ? (int64_t)sb * d->B * d->H * d->W * C * 4 : 0;
   return a256(std::max(fwd, bwd)) + 256;
 }
@@ -430,7 +433,7 @@ extern "C" int svr_conv2d_fwd(const svr_conv2d_desc *d, const void *planes, cons
   G.B = d->B; G.mode = 0; G.k = d->k; G.stride = d->stride; G.pad = 1; G.Qh = Ho; G.Qw = Wo;
   G.Cpad = pad16(C); G.N = Cout; G.ksteps = d->k * d->k * G.Cpad / GK; G.class_stride = 0;
   const int64_t mtiles = cdiv((int64_t)d->B * Ho * Wo, GTM);
-  const int splits = ig_splits(mtiles * cdiv(Cout, Cout <= 64 ? 64 : 128), G.ksteps, &G.ksplit);
+  const int splits = ig_splits(mtiles * cdiv(Cout, Cout <= 64 ? 64 : 128), G.ksteps, Cout, &G.ksplit);
   G.split_stride = (int64_t)d->B * Ho * Wo * Cout;
   float *partial = nullptr;
   if (splits > 1) {
@@ -462,7 +465,7 @@ extern "C" int svr_conv2d_bwd_data(const svr_conv2d_desc *d, const void *planes,
   G.ksteps = taps * G.Cpad / GK;
   G.class_stride = 2LL * taps * G.Cpad * C;
   const int64_t mtiles = cdiv((int64_t)d->B * cdiv(d->H, G.mode == 2 ? 2 : 1) * cdiv(d->W, G.mode == 2 ? 2 : 1), GTM);
-  const int splits = ig_splits(mtiles * ncls * cdiv(C, C <= 64 ? 64 : 128), G.ksteps, &G.ksplit);
+  const int splits = ig_splits(mtiles * ncls * cdiv(C, C <= 64 ? 64 : 128), G.ksteps, C, &G.ksplit);
   G.split_stride = (int64_t)d->B * d->H * d->W * C;
   float *partial = nullptr;
   if (splits > 1) {
