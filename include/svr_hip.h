@@ -545,7 +545,11 @@ int svr_conv2d_col2im(const svr_conv2d_desc *d, const float *dcol, float *dvirt,
  *   svr_conv2d_prepare   W (Cout, C, k, k) as nn.Conv2d holds it -> f16 hi / lo planes of the forward product and (want_bwd)
  *                        of the backward-data product in `planes` (svr_conv2d_planes_bytes); amax: one device word, left with
  *                        max|W| (the scale of the split).  Once per weight version.
- *   svr_conv2d_fwd       Y (B, Ho, Wo, Cout) = conv(act(cat(src0, src1))) + bias (bias may be NULL)
+ *   svr_conv2d_fwd       Y (B, Ho, Wo, Cout) = conv(act(cat(src0, src1))) + bias (bias may be NULL).  amax_x (may be NULL): word
+ *                        holding max|input| -- the input is then a GRADIENT operand, scaled by a power of two into f16's range
+ *                        (f16x3s); amax_y (may be NULL): zeroed word, left with max|Y|.  k = 1, stride 1 (no padding) is a plain
+ *                        row-major GEMM Y (M, Cout) = X (M, C) W^T with the reduction split of the deep layers: B = H = 1, W = M
+ *                        (svr_amd.ops.linear_bwd_data_splitk: few output tiles, long reductions).
  *   svr_conv2d_bwd_data  dIn (B, H, W, C0 + C1) = gradient of the convolution's (activated, concatenated) input from
  *                        dY (B, Ho, Wo, Cout); amax_dy: word holding max|dY| (scaled f16 split), NULL = unscaled.  Stride-2
  *                        layers run as four stride-1 problems, one per parity class of the input pixel.
@@ -570,7 +574,7 @@ int svr_conv2d_prepare(const float *W, int32_t Cout, int32_t C, int32_t k, int32
 int64_t svr_conv2d_workspace_bytes(const svr_conv2d_desc *d, int32_t Cout);
 int svr_conv2d_virtual(const svr_conv2d_desc *d, float *V, void *stream);
 int svr_conv2d_fwd(const svr_conv2d_desc *d, const void *planes, const uint32_t *amax_w, const float *bias, float *Y, int32_t Cout,
-                   void *workspace, void *stream);
+                   const uint32_t *amax_x, uint32_t *amax_y, void *workspace, void *stream);
 int svr_conv2d_bwd_data(const svr_conv2d_desc *d, const void *planes, const uint32_t *amax_w, const float *dY,
                         const uint32_t *amax_dy, int32_t Cout, float *dIn, void *workspace, void *stream);
 int svr_conv2d_finish_bwd(const svr_conv2d_desc *d, const float *dvirt, float *dsrc0, float *dsrc1, void *stream);

@@ -135,7 +135,7 @@ SIGNATURES = {
     "svr_conv2d_prepare": (C.c_int, [P, I32, I32, I32, I32, I32, P, P, P]),
     "svr_conv2d_workspace_bytes": (I64, [C.POINTER(Conv2dDesc), I32]),
     "svr_conv2d_virtual": (C.c_int, [C.POINTER(Conv2dDesc), P, P]),
-    "svr_conv2d_fwd": (C.c_int, [C.POINTER(Conv2dDesc), P, P, P, P, I32, P, P]),
+    "svr_conv2d_fwd": (C.c_int, [C.POINTER(Conv2dDesc), P, P, P, P, I32, P, P, P, P]),
     "svr_conv2d_bwd_data": (C.c_int, [C.POINTER(Conv2dDesc), P, P, P, P, I32, P, P, P]),
     "svr_conv2d_finish_bwd": (C.c_int, [C.POINTER(Conv2dDesc), P, P, P, P]),
     "svr_conv2d_bwd_weight_workspace": (I64, [C.POINTER(Conv2dDesc), I32]),

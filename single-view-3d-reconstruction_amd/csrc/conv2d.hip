@@ -305,7 +305,7 @@ __global__ __launch_bounds__(256) void conv2d_small_fwd_kernel(const CvSrc S, co
   for (int o = 0; o < CO; ++o) acc[o] = 0.f;
   if (pix < M) {
     const int ox = (int)(pix % Wo), oy = (int)((pix / Wo) % Ho), b = (int)(pix / ((int64_t)Wo * Ho));
-    const int64_t p0 = (int64_t)b * S.H * S.W;
+    const int p0 = b * S.H * S.W;
     for (int c = l16 * 4; c < C; c += 64) {
       float4 v[K * K];
 #pragma unroll
@@ -414,7 +414,7 @@ __global__ __launch_bounds__(1024) void conv2d_small_bwd_weight_kernel(const CvS
         cv_divmod(rem, Wo, rWo, oy, ox);
 #pragma unroll
         for (int o = 0; o < CO; ++o) d[j][o] = ok ? dY[m * CO + o] : 0.f;
-        v[j] = ok ? cv_load4<VEC4>(S, (int64_t)b * S.H * S.W, oy * ST + ty, ox * ST + tx, c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        v[j] = ok ? cv_load4<VEC4>(S, b * S.H * S.W, oy * ST + ty, ox * ST + tx, c) : make_float4(0.f, 0.f, 0.f, 0.f);
       }
 #pragma unroll
       for (int j = 0; j < U; ++j) {

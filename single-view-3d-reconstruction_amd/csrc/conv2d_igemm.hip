@@ -78,9 +78,9 @@ __device__ __forceinline__ IgClass ig_class(const IgGeom &G, int cls) {
 // Y (or a partial of it) = A_gathered W^T.  TN = 128: 4 waves (2 x 2 of 64 x 64), TN = 64: 2 waves; k-step 16, two LDS stages,
 // operands prefetched two k-steps ahead (gemm_f16x3.hip's schedule).
 template <int TN, bool VEC4>
-__global__ __launch_bounds__(2 * TN, TN == 128 ? 2 : 4) void conv2d_igemm_kernel(
+__global__ __launch_bounds__(2 * TN, TN == 128 ? 3 : 2) void conv2d_igemm_kernel(
     const IgGeom G, const uint16_t *__restrict__ W0, const uint32_t *__restrict__ amax_w, const uint32_t *__restrict__ amax_x,
-    const float *__restrict__ bias, float *__restrict__ Y, float *__restrict__ partial) {
+    const float *__restrict__ bias, float *__restrict__ Y, float *__restrict__ partial, uint32_t *__restrict__ amax_y) {
   constexpr int NT = 2 * TN, BPLANE = TN * GLW, XPT = 512 / NT, STAGE = 2 * GAPLANE + 2 * BPLANE;
   __shared__ __attribute__((aligned(16))) uint32_t lds[2 * STAGE];
   const int t = threadIdx.x;
@@ -100,14 +100,14 @@ __global__ __launch_bounds__(2 * TN, TN == 128 ? 2 : 4) void conv2d_igemm_kernel
 
   // rows of this thread: pixel base of the sample and the input coordinates of tap (0, 0); rows past the class get
   // coordinates that fail every bounds test (their outputs are never stored)
-  int64_t rpix[XPT];
+  int rpix[XPT];
   int riy[XPT], rix[XPT];
 #pragma unroll
   for (int i = 0; i < XPT; ++i) {
     const int64_t m = m0 + (t >> 2) + (NT / 4) * i;
     const int b = (int)(m / HW), rem = (int)(m % HW);
     const int gy = rem / Cg.Gw, gx = rem % Cg.Gw;
-    rpix[i] = (int64_t)b * G.S.H * G.S.W;
+    rpix[i] = m < Mc ? b * G.S.H * G.S.W : 0;      // (host: B H W < 2^24)
     riy[i] = m < Mc ? gy * Cg.sy + Cg.by : -(1 << 24);
     rix[i] = gx * Cg.sy + Cg.bx;
   }
@@ -212,6 +212,7 @@ __global__ __launch_bounds__(2 * TN, TN == 128 ? 2 : 4) void conv2d_igemm_kernel
   if (amax_x) inv *= w_scale(amax_x[0], true);
   float *out = partial ? partial + split * G.split_stride : Y;
   const float *bp = partial ? nullptr : bias;
+  float vmax = 0.f;    // |max| of what this workgroup stores (amax_y: the next consumer's f16x3s scale; unsplit launches only)
   // address of tile row r's output pixel (class rows are strided over the image in mode 2)
   auto row_out = [&](int r, bool &ok) -> float * {
     const int64_t m = m0 + r;
@@ -247,6 +248,7 @@ __global__ __launch_bounds__(2 * TN, TN == 128 ? 2 : 4) void conv2d_igemm_kernel
         if (ok && c < G.N) {
           float4 v = *reinterpret_cast<const float4 *>(ct + row * 128 + c4);
           v.x = v.x * inv + b4.x; v.y = v.y * inv + b4.y; v.z = v.z * inv + b4.z; v.w = v.w * inv + b4.w;
+          vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
           *reinterpret_cast<float4 *>(o + c) = v;
         }
       }
@@ -262,20 +264,50 @@ __global__ __launch_bounds__(2 * TN, TN == 128 ? 2 : 4) void conv2d_igemm_kernel
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           const int64_t n = n0 + wc * 64 + j * 32 + l31;
-          if (ok && n < G.N) o[n] = acc[i][j][r] * inv + (bp ? bp[n] : 0.f);
+          if (ok && n < G.N) {
+            const float v = acc[i][j][r] * inv + (bp ? bp[n] : 0.f);
+            vmax = fmaxf(vmax, fabsf(v));
+            o[n] = v;
+          }
         }
       }
   }
+  if (amax_y && !partial) svr_amax_publish(amax_y, vmax);   // (uniform)
 }
 
-// Y = sum over the splits of the partial outputs (+ bias), fixed order
+// Y = sum over the splits of the partial outputs (+ bias), fixed order.  Grid-stride over float4 groups with at most 1 024
+// workgroups: one |max| publication per wave at the END (with one workgroup per 256 outputs the publication -- tens of thousands
+// of waves reading and raising one word -- was the kernel: 114 us for 4 M outputs).  total % 4 == 0 or the scalar tail below.
 __global__ __launch_bounds__(256) void ig_reduce_kernel(const float *__restrict__ partial, int64_t split_stride, int splits,
-                                                        const float *__restrict__ bias, float *__restrict__ Y, int64_t total, int N) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= total) return;
-  float s = 0.f;
-  for (int p = 0; p < splits; ++p) s += partial[p * split_stride + i];
-  Y[i] = s + (bias ? bias[i % N] : 0.f);
+                                                        const float *__restrict__ bias, float *__restrict__ Y, int64_t total, int N,
+                                                        uint32_t *__restrict__ amax_y) {
+  float vmax = 0.f;
+  const bool v4 = (N & 3) == 0 && (split_stride & 3) == 0;    // (uniform) a float4 group stays inside one output row
+  if (v4) {
+    const int64_t groups = total >> 2;
+    for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < groups; g += (int64_t)gridDim.x * 256) {
+      float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int p = 0; p < splits; ++p) {
+        const float4 t = *reinterpret_cast<const float4 *>(partial + p * split_stride + g * 4);
+        s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+      }
+      if (bias) {
+        const float4 b = *reinterpret_cast<const float4 *>(bias + (g * 4) % N);
+        s.x += b.x; s.y += b.y; s.z += b.z; s.w += b.w;
+      }
+      *reinterpret_cast<float4 *>(Y + g * 4) = s;
+      vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(s.x), fabsf(s.y))), fmaxf(fabsf(s.z), fabsf(s.w)));
+    }
+  } else {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+      float s = 0.f;
+      for (int p = 0; p < splits; ++p) s += partial[p * split_stride + i];
+      s += bias ? bias[i % N] : 0.f;
+      Y[i] = s;
+      vmax = fmaxf(vmax, fabsf(s));
+    }
+  }
+  if (amax_y) svr_amax_publish(amax_y, vmax);   // (uniform; every wave arrives)
 }
 
 // max |W| of a contiguous weight -> amax[0] (zeroed first); one wave-level reduction and at most one atomic per wave
@@ -335,8 +367,8 @@ int64_t a256(int64_t x) { return (x + 255) / 256 * 256; }
 int ig_check(const svr_conv2d_desc *d, int Cout, const char *what) {
   SVR_CHECK(d && d->src0 && d->B > 0 && d->H > 0 && d->W > 0 && d->C0 > 0 && d->C1 >= 0 && Cout > 0, SVR_E_BADARG, "%s: bad descriptor", what);
   SVR_CHECK(d->C1 == 0 || d->src1, SVR_E_BADARG, "%s: C1 = %d without a second source", what, d->C1);
-  SVR_CHECK((d->k == 4 && d->stride == 2) || (d->k == 3 && d->stride == 1), SVR_E_UNSUPPORTED, "%s: k=%d stride=%d (k4 s2 / k3 s1)", what,
-            d->k, d->stride);
+  SVR_CHECK((d->k == 4 && d->stride == 2) || (d->k == 3 && d->stride == 1) || (d->k == 1 && d->stride == 1), SVR_E_UNSUPPORTED,
+            "%s: k=%d stride=%d (k4 s2 p1 / k3 s1 p1 / k1 s1 p0)", what, d->k, d->stride);
   SVR_CHECK(d->act >= 0 && d->act <= 2, SVR_E_BADARG, "%s: act %d", what, d->act);
   SVR_CHECK(!d->upsample, SVR_E_UNSUPPORTED, "%s: the x2 upsample is materialised first (svr_conv2d_virtual)", what);
   SVR_CHECK((int64_t)d->B * d->H * d->W < (1 << 24), SVR_E_UNSUPPORTED, "%s: %ld pixels (row decode limit 2^24)", what,
@@ -360,13 +392,13 @@ int ig_splits(int64_t tiles, int ksteps, int n_out, int *ksplit) {
 
 template <bool VEC4>
 void ig_launch(const IgGeom &G, int ncls, int64_t mtiles, int splits, const uint16_t *planes, const uint32_t *amax_w,
-               const uint32_t *amax_x, const float *bias, float *Y, float *partial, hipStream_t s) {
+               const uint32_t *amax_x, const float *bias, float *Y, float *partial, uint32_t *amax_y, hipStream_t s) {
   if (G.N <= 64) {
     dim3 grid(xcd_grid(cdiv(G.N, 64) * mtiles), ncls, splits);
-    hipLaunchKernelGGL((conv2d_igemm_kernel<64, VEC4>), grid, dim3(128), 0, s, G, planes, amax_w, amax_x, bias, Y, partial);
+    hipLaunchKernelGGL((conv2d_igemm_kernel<64, VEC4>), grid, dim3(128), 0, s, G, planes, amax_w, amax_x, bias, Y, partial, amax_y);
   } else {
     dim3 grid(xcd_grid(cdiv(G.N, 128) * mtiles), ncls, splits);
-    hipLaunchKernelGGL((conv2d_igemm_kernel<128, VEC4>), grid, dim3(256), 0, s, G, planes, amax_w, amax_x, bias, Y, partial);
+    hipLaunchKernelGGL((conv2d_igemm_kernel<128, VEC4>), grid, dim3(256), 0, s, G, planes, amax_w, amax_x, bias, Y, partial, amax_y);
   }
 }
 
@@ -385,7 +417,8 @@ extern "C" int64_t svr_conv2d_planes_bytes(int32_t Cout, int32_t C, int32_t k) {
 extern "C" int svr_conv2d_prepare(const float *W, int32_t Cout, int32_t C, int32_t k, int32_t stride, int32_t want_bwd,
                                   uint32_t *amax, void *planes, void *stream) {
   SVR_CHECK(W && amax && planes && Cout > 0 && C > 0, SVR_E_BADARG, "conv2d_prepare: null pointer / empty weight");
-  SVR_CHECK((k == 4 && stride == 2) || (k == 3 && stride == 1), SVR_E_UNSUPPORTED, "conv2d_prepare: k=%d stride=%d", k, stride);
+  SVR_CHECK((k == 4 && stride == 2) || (k == 3 && stride == 1) || (k == 1 && stride == 1 && !want_bwd), SVR_E_UNSUPPORTED,
+            "conv2d_prepare: k=%d stride=%d (k = 1: forward planes only)", k, stride);
   hipStream_t s = (hipStream_t)stream;
   const int64_t numel = (int64_t)Cout * C * k * k;
   uint16_t *pf = (uint16_t *)(((uintptr_t)planes + 255) & ~(uintptr_t)255);
@@ -410,7 +443,7 @@ extern "C" int64_t svr_conv2d_workspace_bytes(const svr_conv2d_desc *d, int32_t 
   // where there are fewer than 512 tiles -- bound by 64 * 512 tiles * 128 * 128 floats; sized exactly instead:
   if (!d) return 0;
   const int C = d->C0 + d->C1;
-  const int Ho = (d->H + 2 - d->k) / d->stride + 1, Wo = (d->W + 2 - d->k) / d->stride + 1;
+  const int pad = d->k == 1 ? 0 : 1, Ho = (d->H + 2 * pad - d->k) / d->stride + 1, Wo = (d->W + 2 * pad - d->k) / d->stride + 1;
   int ks;
   const int64_t mf = cdiv((int64_t)d->B * Ho * Wo, GTM) * cdiv(Cout, Cout <= 64 ? 64 : 128);
   const int sf = ig_splits(mf, d->k * d->k * pad16(C) / GK, Cout, &ks);
@@ -418,19 +451,20 @@ extern "C" int64_t svr_conv2d_workspace_bytes(const svr_conv2d_desc *d, int32_t 
   const int ncls = d->stride == 2 ? 4 : 1;
   const int64_t mb = cdiv((int64_t)d->B * cdiv(d->H, d->stride) * cdiv(d->W, d->stride), GTM) * cdiv(C, C <= 64 ? 64 : 128);
   const int sb = ig_splits(mb * ncls, (d->stride == 2 ? 4 : 9) * pad16(Cout) / GK, C, &ks);
-  const int64_t bwd = sb > 1 ? (int64_t)sb * d->B * d->H * d->W * C * 4 : 0;
+  const int64_t bwd = (sb > 1 && d->k != 1) ? (int64_t)sb * d->B * d->H * d->W * C * 4 : 0;   // (k = 1: forward only)
   return a256(std::max(fwd, bwd)) + 256;
 }
 
 extern "C" int svr_conv2d_fwd(const svr_conv2d_desc *d, const void *planes, const uint32_t *amax_w, const float *bias, float *Y,
-                              int32_t Cout, void *workspace, void *stream) {
+                              int32_t Cout, const uint32_t *amax_x, uint32_t *amax_y, void *workspace, void *stream) {
   if (int rc = ig_check(d, Cout, "conv2d_fwd")) return rc;
   SVR_CHECK(planes && amax_w && Y, SVR_E_BADARG, "conv2d_fwd: null pointer");
-  const int C = d->C0 + d->C1, Ho = (d->H + 2 - d->k) / d->stride + 1, Wo = (d->W + 2 - d->k) / d->stride + 1;
+  const int pad = d->k == 1 ? 0 : 1;
+  const int C = d->C0 + d->C1, Ho = (d->H + 2 * pad - d->k) / d->stride + 1, Wo = (d->W + 2 * pad - d->k) / d->stride + 1;
   SVR_CHECK(Ho > 0 && Wo > 0, SVR_E_BADSHAPE, "conv2d_fwd: empty output");
   IgGeom G{};
   G.S = CvSrc{d->src0, d->src1, d->C0, d->C1, d->H, d->W, d->act};
-  G.B = d->B; G.mode = 0; G.k = d->k; G.stride = d->stride; G.pad = 1; G.Qh = Ho; G.Qw = Wo;
+  G.B = d->B; G.mode = 0; G.k = d->k; G.stride = d->stride; G.pad = pad; G.Qh = Ho; G.Qw = Wo;
   G.Cpad = pad16(C); G.N = Cout; G.ksteps = d->k * d->k * G.Cpad / GK; G.class_stride = 0;
   const int64_t mtiles = cdiv((int64_t)d->B * Ho * Wo, GTM);
   const int splits = ig_splits(mtiles * cdiv(Cout, Cout <= 64 ? 64 : 128), G.ksteps, Cout, &G.ksplit);
@@ -442,11 +476,11 @@ extern "C" int svr_conv2d_fwd(const svr_conv2d_desc *d, const void *planes, cons
   }
   const uint16_t *pf = (const uint16_t *)(((uintptr_t)planes + 255) & ~(uintptr_t)255);
   hipStream_t s = (hipStream_t)stream;
-  if (vec4_ok(G.S)) ig_launch<true>(G, 1, mtiles, splits, pf, amax_w, nullptr, bias, Y, partial, s);
-  else ig_launch<false>(G, 1, mtiles, splits, pf, amax_w, nullptr, bias, Y, partial, s);
+  if (vec4_ok(G.S)) ig_launch<true>(G, 1, mtiles, splits, pf, amax_w, amax_x, bias, Y, partial, amax_y, s);
+  else ig_launch<false>(G, 1, mtiles, splits, pf, amax_w, amax_x, bias, Y, partial, amax_y, s);
   if (splits > 1)
-    hipLaunchKernelGGL(ig_reduce_kernel, dim3((unsigned)cdiv(G.split_stride, 256)), dim3(256), 0, s, (const float *)partial, G.split_stride,
-                       splits, bias, Y, G.split_stride, Cout);
+    hipLaunchKernelGGL(ig_reduce_kernel, dim3((unsigned)std::min<int64_t>(cdiv(G.split_stride, 1024), 1024)), dim3(256), 0, s,
+                       (const float *)partial, G.split_stride, splits, bias, Y, G.split_stride, Cout, amax_y);
   return launch_status("conv2d_fwd");
 }
 
@@ -475,10 +509,10 @@ extern "C" int svr_conv2d_bwd_data(const svr_conv2d_desc *d, const void *planes,
   const uint16_t *pf = (const uint16_t *)(((uintptr_t)planes + 255) & ~(uintptr_t)255);
   const uint16_t *pb = (const uint16_t *)((const char *)pf + a256(4LL * Cout * d->k * d->k * pad16(C)));
   hipStream_t s = (hipStream_t)stream;
-  if (vec4_ok(G.S)) ig_launch<true>(G, ncls, mtiles, splits, pb, amax_w, amax_dy, nullptr, dIn, partial, s);
-  else ig_launch<false>(G, ncls, mtiles, splits, pb, amax_w, amax_dy, nullptr, dIn, partial, s);
+  if (vec4_ok(G.S)) ig_launch<true>(G, ncls, mtiles, splits, pb, amax_w, amax_dy, nullptr, dIn, partial, nullptr, s);
+  else ig_launch<false>(G, ncls, mtiles, splits, pb, amax_w, amax_dy, nullptr, dIn, partial, nullptr, s);
   if (splits > 1)
-    hipLaunchKernelGGL(ig_reduce_kernel, dim3((unsigned)cdiv(G.split_stride, 256)), dim3(256), 0, s, (const float *)partial, G.split_stride,
-                       splits, (const float *)nullptr, dIn, G.split_stride, C);
+    hipLaunchKernelGGL(ig_reduce_kernel, dim3((unsigned)std::min<int64_t>(cdiv(G.split_stride, 1024), 1024)), dim3(256), 0, s,
+                       (const float *)partial, G.split_stride, splits, (const float *)nullptr, dIn, G.split_stride, C, (uint32_t *)nullptr);
   return launch_status("conv2d_bwd_data");
 }

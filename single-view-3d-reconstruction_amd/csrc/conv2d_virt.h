@@ -19,22 +19,32 @@ __device__ __forceinline__ float4 cv_act4(float4 v, int act) {
   return make_float4(cv_act(v.x, act), cv_act(v.y, act), cv_act(v.z, act), cv_act(v.w, act));
 }
 
-// channels c .. c+3 of pixel (iy, ix) of sample `pix0 / (H W)`, RAW (no activation); zero outside the image or past the last
-// channel.  VEC4: C0, C1 multiples of 4 and 16-byte aligned sources (one 16-byte load); otherwise four predicated loads.
+// channels c .. c+3 of pixel (iy, ix) of the sample whose first pixel is `pix0` (= b H W; every caller checks B H W < 2^24, so
+// pixel indices are 32-bit and an element offset is ONE v_mad_u64_u32), RAW (no activation); zero outside the image or past the
+// last channel.  VEC4: C0, C1 multiples of 4 and 16-byte aligned sources (one 16-byte load); otherwise four predicated loads.
 template <bool VEC4>
-__device__ __forceinline__ float4 cv_load4(const CvSrc &S, int64_t pix0, int iy, int ix, int c) {
+__device__ __forceinline__ float4 cv_load4(const CvSrc &S, int pix0, int iy, int ix, int c) {
   float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-  if ((unsigned)iy >= (unsigned)S.H || (unsigned)ix >= (unsigned)S.W) return v;
-  const int64_t pix = pix0 + (int64_t)iy * S.W + ix;
   if constexpr (VEC4) {
-    if (c < S.C0) v = *reinterpret_cast<const float4 *>(S.p0 + pix * S.C0 + c);
-    else if (c < S.C0 + S.C1) v = *reinterpret_cast<const float4 *>(S.p1 + pix * S.C1 + (c - S.C0));
+    // branch free: ONE unconditional load from clamped coordinates, zeroed by a select (a load inside a bounds branch is waited
+    // for on its own; the GEMM loaders issue 2-4 of these per k-step and want them in flight together)
+    const bool ok = (unsigned)iy < (unsigned)S.H && (unsigned)ix < (unsigned)S.W && c < S.C0 + S.C1;
+    const int cy = min(max(iy, 0), S.H - 1), cx = min(max(ix, 0), S.W - 1);
+    const uint32_t pix = (uint32_t)(pix0 + cy * S.W + cx);
+    const bool first = c < S.C0 || S.C1 == 0;
+    const float *base = first ? S.p0 : S.p1;
+    const uint32_t Cs = (uint32_t)(first ? S.C0 : S.C1), cc = (uint32_t)(ok ? (c < S.C0 ? c : c - S.C0) : 0);
+    const float4 t = *reinterpret_cast<const float4 *>(base + ((uint64_t)pix * Cs + cc));
+    v = make_float4(ok ? t.x : 0.f, ok ? t.y : 0.f, ok ? t.z : 0.f, ok ? t.w : 0.f);
   } else {
+    if ((unsigned)iy >= (unsigned)S.H || (unsigned)ix >= (unsigned)S.W) return v;
+    const uint32_t pix = (uint32_t)(pix0 + iy * S.W + ix);
     float e[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int ci = c + i;
-      e[i] = ci < S.C0 ? S.p0[pix * S.C0 + ci] : (ci < S.C0 + S.C1 ? S.p1[pix * S.C1 + (ci - S.C0)] : 0.f);
+      e[i] = ci < S.C0 ? S.p0[(uint64_t)pix * (uint32_t)S.C0 + (uint32_t)ci]
+                       : (ci < S.C0 + S.C1 ? S.p1[(uint64_t)pix * (uint32_t)S.C1 + (uint32_t)(ci - S.C0)] : 0.f);
     }
     v = make_float4(e[0], e[1], e[2], e[3]);
   }

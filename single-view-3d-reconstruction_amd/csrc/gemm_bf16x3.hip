@@ -463,7 +463,7 @@ __global__ __launch_bounds__(256, 2) void linear_tn_x3_tr_kernel(const float *__
         int b, rem, oy, ox;
         cv_divmod((int)m, G.HoWo, G.rHoWo, b, rem);
         cv_divmod(rem, G.Wo, G.rWo, oy, ox);
-        xv[i] = cv_load4<VEC4>(G.S, (int64_t)b * G.S.H * G.S.W, oy * G.stride + ctap_y, ox * G.stride + ctap_x, cch);
+        xv[i] = cv_load4<VEC4>(G.S, b * G.S.H * G.S.W, oy * G.stride + ctap_y, ox * G.stride + ctap_x, cch);
       } else {
         av[i] = *reinterpret_cast<const float4 *>(dY + m * lddy + acol);
         xv[i] = *reinterpret_cast<const float4 *>(X + m * ldx + xcol);

@@ -890,3 +890,21 @@ def test_conv_epilogue_batchnorm_statistics(B, dims, Ci, Co):
         assert G.rel_err(a1[1].cpu().numpy(), a0[1].cpu().numpy()) < 1e-6
     assert G.rel_err(rm1.cpu().numpy(), rm0.cpu().numpy()) < 1e-6 and G.rel_err(rv1.cpu().numpy(), rv0.cpu().numpy()) < 1e-6
     assert G.rel_err(a1[3].cpu().numpy(), a0[3].cpu().numpy()) < 1e-6 and abs(n - B * dims[0] * dims[1] * dims[2]) == 0
+
+
+@pytest.mark.parametrize("M,N,K", [(4096, 1792, 128), (1000, 1792, 128), (77, 256, 64), (8192, 448, 32)])
+def test_linear_bwd_data_with_split_reduction(M, N, K):
+    """ops.linear_bwd_data_splitk (the implicit-GEMM kernel's k = 1 mode: few output tiles, the reduction split over workgroups
+    and summed in a fixed order) against float64 and against the point MLP's dX kernel; the |max| word it leaves; bit-reproducible."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(M + N)
+    for scale in (1.0, 1e-6):
+        dy = (torch.randn(M, N, generator=g) * scale).cuda()
+        w = (torch.randn(N, K, generator=g) / N ** 0.5).cuda()
+        ref = dy.double() @ w.double()
+        got = ops.linear_bwd_data_splitk(dy, w.t().contiguous())
+        old = ops.linear_bwd_data(dy, w, mode="f16x3s")
+        rel = lambda x: float((x.double() - ref).abs().max() / ref.abs().max())     # noqa: E731
+        assert rel(got) < 2e-6 and rel(old) < 3e-6, (rel(got), rel(old))
+        assert got._svr_amax.view(torch.float32).item() == float(got.abs().max())
+        assert torch.equal(got, ops.linear_bwd_data_splitk(dy, w.t().contiguous()))
