@@ -30,6 +30,10 @@ hipError_t sort_pairs_u32(void *tmp, size_t tmp_bytes, const uint32_t *kin, uint
                           int64_t n, int bits, hipStream_t s);
 size_t scan_max_i32_temp_bytes(int64_t n);
 hipError_t scan_max_i32(void *tmp, size_t tmp_bytes, const int32_t *in, int32_t *out, int64_t n, hipStream_t s);
+// gemm_bf16x3.hip: dX = dY W on the scaled f16 split through the k-step-32 kernel (planes [K][N]); see svr_linear_bwd_data_f16x3
+int linear_bwd_data_f16_nn(const float *dY, int64_t lddy, const float *W, int64_t ldw, float *dX, int64_t lddx, int64_t M, int64_t N,
+                           int64_t K, int epilogue, const float *mask, int64_t ldmask, const uint32_t *amax_dy, uint32_t *amax_dx,
+                           void *workspace, hipStream_t s);
 size_t scan_sum_excl_i32_temp_bytes(int64_t n);
 hipError_t scan_sum_excl_i32(void *tmp, size_t tmp_bytes, const int32_t *in, int32_t *out, int64_t n, hipStream_t s);
 }  // namespace svr

@@ -57,11 +57,14 @@ __device__ __forceinline__ void split2(float x0, float x1, uint32_t &hi, uint32_
 // path free of per-element branches and 64-bit index arithmetic.  Only the reduction tail needs zeros.
 //
 // RowK: f32 source, tile row = operand row, k contiguous.  thread -> (row = t/8 + (NT/8) i, float4 t%8)
-template <int ROWS, int NT>
+// F16: the scaled 3-product f16 split ("f16x3s"): the operand is multiplied by `sy` (a power of two from its |max|) and split
+// into hi = rn16(x), lo' = rn16((x - hi) 2^11) (f16x3.h)
+template <int ROWS, int NT, bool F16 = false>
 struct RowKLoader {
   static constexpr int R = ROWS * 8 / NT;
   const float *rowp[R];
   float4 v[R];
+  float sy = 1.f;
   __device__ __forceinline__ RowKLoader(const float *src, int64_t ld, int64_t row0, int64_t nrows) {
     const int t = threadIdx.x;
 #pragma unroll
@@ -80,8 +83,13 @@ struct RowKLoader {
 #pragma unroll
     for (int i = 0; i < R; ++i) {
       uint32_t h0, m0, h1, m1;
-      split2(v[i].x, v[i].y, h0, m0);
-      split2(v[i].z, v[i].w, h1, m1);
+      if constexpr (F16) {
+        split_x(v[i].x * sy, v[i].y * sy, h0, m0);
+        split_x(v[i].z * sy, v[i].w * sy, h1, m1);
+      } else {
+        split2(v[i].x, v[i].y, h0, m0);
+        split2(v[i].z, v[i].w, h1, m1);
+      }
       const int off = ((t >> 3) + (NT / 8) * i) * XLW + (t & 7) * 2;
       *reinterpret_cast<uint2 *>(planes + off) = make_uint2(h0, h1);
       *reinterpret_cast<uint2 *>(planes + ROWS * XLW + off) = make_uint2(m0, m1);
@@ -186,7 +194,9 @@ struct Geo {
   static constexpr int LDS_DWORDS = STAGE;           // ONE stage: see mainloop
 };
 
-template <int WR, int WC>
+// F16: A = (hi, lo') of the operand split on the fly, B = planes (wh, wl) of a weight scaled to [2^13, 2^14):
+// acc += lo' (wh 2^-11) + hi wl + hi wh  (gemm_f16x3.hip's arithmetic; the caller multiplies by 2^-(s_w + s_x))
+template <int WR, int WC, bool F16 = false>
 __device__ __forceinline__ void compute_step(const uint32_t *pa, f32x16 (&acc)[2][2]) {
   using G = Geo<WR, WC>;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -209,6 +219,25 @@ __device__ __forceinline__ void compute_step(const uint32_t *pa, f32x16 (&acc)[2
       bh[j] = read_frag(pb, row, kw);
       bm[j] = read_frag(pb + G::TN * XLW, row, kw);
     }
+    if constexpr (F16) {
+      f16x8 fah[2], fal[2], fbh[2], fbl[2], fbq[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        fah[i] = __builtin_bit_cast(f16x8, ah[i]);
+        fal[i] = __builtin_bit_cast(f16x8, am[i]);
+        fbh[i] = __builtin_bit_cast(f16x8, bh[i]);
+        fbl[i] = __builtin_bit_cast(f16x8, bm[i]);
+        fbq[i] = scale_2m11(fbh[i]);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fal[i], fbq[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[i], fbl[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[i], fbh[j], acc[i][j], 0, 0, 0);
+        }
+    } else {
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -217,6 +246,7 @@ __device__ __forceinline__ void compute_step(const uint32_t *pa, f32x16 (&acc)[2
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bm[j], acc[i][j], 0, 0, 0);
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
       }
+    }
   }
 }
 
@@ -225,7 +255,7 @@ __device__ __forceinline__ void compute_step(const uint32_t *pa, f32x16 (&acc)[2
 // (SQ_WAIT_ANY 0.55-0.67 of the wave cycles, matrix pipe ~20 % busy), and halving the LDS footprint doubles the
 // workgroups per CU, i.e. the loads in flight; the extra barrier is covered by the other workgroups.
 // (Two register sets -- loads two steps ahead -- were tried: 200..256 VGPRs, spills, 1.5-4x slower.)
-template <int WR, int WC, class AL, class BL>
+template <int WR, int WC, class AL, class BL, bool F16 = false>
 __device__ __forceinline__ void mainloop(AL &al, BL &bl, uint32_t *lds, int64_t kbeg, int64_t kend, f32x16 (&acc)[2][2]) {
   using G = Geo<WR, WC>;
 #pragma unroll
@@ -247,7 +277,7 @@ __device__ __forceinline__ void mainloop(AL &al, BL &bl, uint32_t *lds, int64_t 
       bl.load(k0 + XK, kend);
     }
     __builtin_amdgcn_sched_barrier(0);  // the loads stay in front of the MFMAs (the scheduler would sink them to the stores)
-    compute_step<WR, WC>(lds, acc);
+    compute_step<WR, WC, F16>(lds, acc);
     __syncthreads();  // every wave has read its fragments
     if (more) {
       al.store(lds);
@@ -288,11 +318,15 @@ __global__ void pack_planes_kernel(const float *__restrict__ W, int64_t ldw, uin
 // as) whole 512-byte row pieces with 16 bytes per lane; the MFMA register layout would give 128-byte pieces
 // of 64 dword stores per lane.
 constexpr int NN_TM = 128, NN_TN = 128, NN_CLD = NN_TN + 4;
+// F16 (round 4): the same kernel on the scaled f16 split -- dY scaled by 2^sy from its |max| (amax_dy), W planes from
+// pack_planes_f16_kernel (scaled by 2^sw, amax_w), result times 2^-(sw + sy); amax_dx (optional) is left with max|dX|.
+template <bool F16>
 __global__ __launch_bounds__(256, 3) void linear_nn_x3_kernel(const float *__restrict__ dY, int64_t lddy,
                                                            const uint16_t *__restrict__ Wh,
                                                            const uint16_t *__restrict__ Wm, float *__restrict__ dX,
                                                            int64_t lddx, const float *__restrict__ mask, int64_t ldmask,
-                                                           int64_t M, int64_t N, int64_t K) {
+                                                           int64_t M, int64_t N, int64_t K, const uint32_t *__restrict__ amax_w,
+                                                           const uint32_t *__restrict__ amax_dy, uint32_t *__restrict__ amax_dx) {
   using G = Geo<2, 2>;
   static_assert(G::LDS_DWORDS >= (NN_TM / 2) * NN_CLD, "half the epilogue tile must fit the staging buffer");
   __shared__ __attribute__((aligned(16))) uint32_t lds[G::LDS_DWORDS];
@@ -300,10 +334,15 @@ __global__ __launch_bounds__(256, 3) void linear_nn_x3_kernel(const float *__res
   const int64_t nct = cdiv(K, NN_TN), lidx = xcd_logical(blockIdx.x, gridDim.x);
   if (lidx >= nct * cdiv(M, NN_TM)) return;
   const int64_t c0 = (lidx % nct) * NN_TN, m0 = (lidx / nct) * NN_TM;
-  RowKLoader<NN_TM, 256> al(dY, lddy, m0, M);
+  RowKLoader<NN_TM, 256, F16> al(dY, lddy, m0, M);
   PlaneLoader<NN_TN, 256> bl(Wh, Wm, N, c0, K);
+  float inv = 1.f, vmax = 0.f;
+  if constexpr (F16) {
+    al.sy = amax_dy ? w_scale(amax_dy[0], false) : 1.f;
+    inv = w_scale(amax_w[0], true) * (amax_dy ? w_scale(amax_dy[0], true) : 1.f);
+  }
   f32x16 acc[2][2];
-  mainloop<2, 2>(al, bl, lds, 0, N, acc);   // ends with a barrier: the operand buffers are free
+  mainloop<2, 2, RowKLoader<NN_TM, 256, F16>, PlaneLoader<NN_TN, 256>, F16>(al, bl, lds, 0, N, acc);   // ends with a barrier: the operand buffers are free
   float *ct = reinterpret_cast<float *>(lds);
   const int t = threadIdx.x;
   const int wave = t >> 6;
@@ -328,17 +367,36 @@ __global__ __launch_bounds__(256, 3) void linear_nn_x3_kernel(const float *__res
       const int64_t m = m0 + 64 * pass + row, c = c0 + c4;
       if (m < M && c < K) {  // K % 4 == 0 (host-checked), so a float4 never straddles the edge
         float4 v = *reinterpret_cast<const float4 *>(ct + row * NN_CLD + c4);
+        if constexpr (F16) { v.x *= inv; v.y *= inv; v.z *= inv; v.w *= inv; }
         if (mask) {
           v.x = k4[i].x > 0.f ? v.x : 0.f;
           v.y = k4[i].y > 0.f ? v.y : 0.f;
           v.z = k4[i].z > 0.f ? v.z : 0.f;
           v.w = k4[i].w > 0.f ? v.w : 0.f;
         }
+        if constexpr (F16) vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
         *reinterpret_cast<float4 *>(dX + m * lddx + c) = v;
       }
     }
     __syncthreads();
   }
+  if constexpr (F16) {
+    if (amax_dx) svr_amax_publish(amax_dx, vmax);   // (uniform)
+  }
+}
+
+// W[n][k] f32 -> f16 planes [k][n] of W 2^s (amax: max|W| -> s with max|W 2^s| in [2^13, 2^14)): wh = rn16, wl = rn16(W 2^s - wh)
+__global__ void pack_planes_f16_kernel(const float *__restrict__ W, int64_t ldw, const uint32_t *__restrict__ amax,
+                                       uint16_t *__restrict__ hi, uint16_t *__restrict__ lo, int64_t N, int64_t K) {
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // over (k, n/2)
+  if (idx >= K * (N / 2)) return;
+  const int64_t k = idx / (N / 2), n = (idx % (N / 2)) * 2;
+  const float sc = w_scale(amax[0], false);
+  const float w0 = W[n * ldw + k] * sc, w1 = W[(n + 1) * ldw + k] * sc;
+  const uint32_t h = pack_f16(w0, w1);
+  const f32x2 hf = unpack_f16(h);
+  *reinterpret_cast<uint32_t *>(hi + k * N + n) = h;
+  *reinterpret_cast<uint32_t *>(lo + k * N + n) = pack_f16(w0 - hf.x, w1 - hf.y);
 }
 
 // slab[z][N,K] = dY[rows of split z]^T X[rows of split z].  128 x 128 tile, 4 waves, 36 KB of LDS: three
@@ -739,10 +797,33 @@ extern "C" int svr_linear_bwd_data_bf16x3(const float *dY, int64_t lddy, const f
   SVR_CHECK(lddy % 4 == 0 && ((uintptr_t)dY & 15) == 0, SVR_E_ALIGN, "linear_bwd_data_bf16x3: dY must be 16-byte aligned");
   SVR_CHECK(epilogue == SVR_EPI_NONE || (epilogue == SVR_EPI_MASK && mask), SVR_E_BADARG, "linear_bwd_data_bf16x3: epilogue %d", epilogue);
   dim3 grid(xcd_grid(cdiv(K, NN_TN) * cdiv(M, NN_TM)));
-  hipLaunchKernelGGL(linear_nn_x3_kernel, grid, dim3(256), 0, s, dY, lddy, hi, mid, dX, lddx,
-                     epilogue == SVR_EPI_MASK ? mask : nullptr, ldmask, M, N, K);
+  hipLaunchKernelGGL(linear_nn_x3_kernel<false>, grid, dim3(256), 0, s, dY, lddy, hi, mid, dX, lddx,
+                     epilogue == SVR_EPI_MASK ? mask : nullptr, ldmask, M, N, K, (const uint32_t *)nullptr, (const uint32_t *)nullptr,
+                     (uint32_t *)nullptr);
   return launch_status("linear_bwd_data_bf16x3");
 }
+
+// dX = dY W on the scaled f16 split through the kernel above (called by svr_linear_bwd_data_f16x3, gemm_f16x3.hip, for N % 32 == 0:
+// 0.26 instead of 0.33 ms per 400 000 x 256 x 256 layer and 64-79 instead of 170 us for the projected levels' voxel GEMMs against
+// the forward kernel reused with transposed planes -- a k-step of 32 halves the barrier steps).  Workspace: amax word | planes.
+namespace svr {
+int linear_bwd_data_f16_nn(const float *dY, int64_t lddy, const float *W, int64_t ldw, float *dX, int64_t lddx, int64_t M, int64_t N,
+                           int64_t K, int epilogue, const float *mask, int64_t ldmask, const uint32_t *amax_dy, uint32_t *amax_dx,
+                           void *workspace, hipStream_t s) {
+  uint32_t *amax = (uint32_t *)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+  uint16_t *hi = (uint16_t *)(amax + 64), *lo = hi + N * K;
+  if (W) {
+    (void)hipMemsetAsync(amax, 0, sizeof(uint32_t), s);
+    hipLaunchKernelGGL(w_amax_kernel, dim3((unsigned)std::min<int64_t>(cdiv(N * K, 1024), 1024)), dim3(256), 0, s, W, ldw, N, K, amax);
+    hipLaunchKernelGGL(pack_planes_f16_kernel, dim3((unsigned)cdiv(K * (N / 2), 256)), dim3(256), 0, s, W, ldw, amax, hi, lo, N, K);
+  }
+  if (!dY) return launch_status("linear_bwd_data_f16x3 (prepare)");
+  dim3 grid(xcd_grid(cdiv(K, NN_TN) * cdiv(M, NN_TM)));
+  hipLaunchKernelGGL(linear_nn_x3_kernel<true>, grid, dim3(256), 0, s, dY, lddy, hi, lo, dX, lddx,
+                     epilogue == SVR_EPI_MASK ? mask : nullptr, ldmask, M, N, K, (const uint32_t *)amax, amax_dy, amax_dx);
+  return launch_status("linear_bwd_data_f16x3");
+}
+}  // namespace svr
 
 namespace {
 int64_t tn_mpad(int64_t M) { return cdiv(M, 64) * 64; }

@@ -381,6 +381,18 @@ extern "C" int svr_linear_bwd_data_f16x3(const float *dY, int64_t lddy, const fl
   SVR_CHECK((dY || W) && (!dY || dX) && workspace, SVR_E_BADARG, "linear_bwd_data_f16x3: null pointer");
   SVR_CHECK(M >= 0 && N > 0 && K > 0 && N % YK == 0, SVR_E_BADSHAPE, "linear_bwd_data_f16x3: M=%ld N=%ld K=%ld (N %% 16)", (long)M, (long)N, (long)K);
   hipStream_t s = (hipStream_t)stream;
+  // SVR_DX_KERNEL=nt: the forward kernel with transposed planes (k-step 16) instead of the k-step-32 kernel of gemm_bf16x3.hip
+  // (process-wide: a workspace prepared under one setting is run under the same one)
+  static const bool dx_nn = !(getenv("SVR_DX_KERNEL") && getenv("SVR_DX_KERNEL")[0] == 'n' && getenv("SVR_DX_KERNEL")[1] == 't');
+  if (dx_nn && N % 32 == 0 && K % 4 == 0) {   // (a function of the SHAPE only: PREPARE and RUN calls must agree on the plane layout)
+    if (dY) {
+      SVR_CHECK(lddy % 4 == 0 && ((uintptr_t)dY & 15) == 0, SVR_E_ALIGN, "linear_bwd_data_f16x3: dY must be 16-byte aligned");
+      SVR_CHECK(epilogue == SVR_EPI_NONE || (epilogue == SVR_EPI_MASK && mask), SVR_E_BADARG, "linear_bwd_data_f16x3: epilogue %d", epilogue);
+      SVR_CHECK(lddx % 4 == 0 && (((uintptr_t)dX) & 15) == 0 && (epilogue != SVR_EPI_MASK || (ldmask % 4 == 0 && (((uintptr_t)mask) & 15) == 0)),
+                SVR_E_ALIGN, "linear_bwd_data_f16x3: dX and the mask must be 16-byte aligned with leading dimensions that are multiples of 4");
+    }
+    return svr::linear_bwd_data_f16_nn(dY, lddy, W, ldw, dX, lddx, M, N, K, epilogue, mask, ldmask, amax_dy, amax_dx, workspace, s);
+  }
   uint32_t *amax = (uint32_t *)(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
   uint16_t *p0 = (uint16_t *)(amax + 64);
   if (W) {   // planes of W^T: K rows (dX columns) x N reduction elements

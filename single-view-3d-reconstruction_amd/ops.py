@@ -756,7 +756,8 @@ def linear_bwd_data(dy, w, mask=None, out=None, mode=None):
         out = torch.empty(M, K, device=dy.device, dtype=torch.float32)
     epi = EPI_MASK if mask is not None else EPI_NONE
     if ((mode or BACKWARD_GEMM) == "f16x3s" and N % 16 == 0 and dy.stride(1) == 1 and dy.stride(0) % 4 == 0
-            and dy.data_ptr() % 16 == 0 and out.stride(1) == 1):
+            and dy.data_ptr() % 16 == 0 and out.stride(1) == 1 and out.stride(0) % 4 == 0 and out.data_ptr() % 16 == 0
+            and (mask is None or (mask.stride(1) == 1 and mask.stride(0) % 4 == 0 and mask.data_ptr() % 16 == 0))):
         l = _lib.lib()
         ws = _lookup("lbh", w, mode, "f16x3s") if (w.stride(0) == K and w.stride(1) == 1) else None
         wptr = C.c_void_p(0) if ws is not None else C.c_void_p(w.data_ptr())      # W NULL: the workspace is prepared
