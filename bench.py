@@ -195,7 +195,16 @@ class _KernelTimer:
         return [e0.elapsed_time(e1) for e0, e1 in self.ev.get(k, [])]
 
     def ms_per_step(self, k, steps):
-        return sum(self.times(k)) / max(steps, 1)
+        """Time of the key's launches per step: the brackets are step-major, so they split into `steps` equal runs; the MINIMUM
+        over the steps is reported (a transient inside one bracket -- an allocator refill in the first single-stream step put
+        66 ms into one BatchNorm bracket of profiles/r04_bench_v3_detail.json -- must not become a kernel's time)."""
+        v = self.times(k)
+        if not v:
+            return 0.0
+        if steps <= 1 or len(v) % steps:
+            return sum(v) / max(steps, 1)
+        n = len(v) // steps
+        return min(sum(v[i * n:(i + 1) * n]) for i in range(steps))
 
     def ms_per_launch(self, k):
         v = self.times(k)
