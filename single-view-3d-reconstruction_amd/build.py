@@ -14,7 +14,7 @@ LIB = os.path.join(LIBDIR, "libsvr_hip.so")
 # compiled with FP contraction off (see gather.hip / projection.hip headers).
 SOURCES = {
     "capi.cpp": [],
-    "gather.hip": ["-ffp-contract=off"],
+    "gather.hip": ["-ffp-contract=off"] + ["-D" + d for d in os.environ.get("SVR_GATHER_DEFS", "").split()],   # experiments
     "gather_fc0.hip": ["-ffp-contract=off"] + [f"-D{k}={os.environ[e]}" for k, e in (("FC_TM", "SVR_FC_TM"), ("FC_DEPTH", "SVR_FC_DEPTH"), ("FC_FMA", "SVR_FC_FMA"))
                                                if os.environ.get(e)]    # tile-shape experiments
                       + (["-DSVR_FC0_MEASURE"] if os.environ.get("SVR_FC0_MEASURE") else [])   # role switches (SVR_FC0_DBG)

@@ -180,7 +180,15 @@ __device__ __forceinline__ void gather_fwd_shared_body(const LevelArgs L, const 
       }
     }
     if (I.m & 0x100) {
+#ifndef SVR_GATHER_NO_NT
+      // streaming stores: the rows (4.2 GB at config 3) are never read back by this kernel, and as ordinary stores they pushed the
+      // volumes' lines out of L2 -- 2.16 -> 1.90 ms stand-alone (tools/exp/bench_fc0.py)
+      float *o = feat + I.ro + q4;
+      __builtin_nontemporal_store(acc.x, o); __builtin_nontemporal_store(acc.y, o + 1);
+      __builtin_nontemporal_store(acc.z, o + 2); __builtin_nontemporal_store(acc.w, o + 3);
+#else
       *reinterpret_cast<float4 *>(feat + I.ro + q4) = acc;
+#endif
       if ((I.m & 0x200) && q4 == 0) {
         float *row = feat + (I.ro - L.col);  // j == 0: ro = row start + L.col
         for (int cc = pad_start; cc < row_stride; ++cc) row[cc] = 0.f;
@@ -1001,7 +1009,7 @@ __global__ __launch_bounds__(256) void gather_bwd_pull_kernel(float *__restrict_
   float *out = gvol + ((((int64_t)b * D + z) * H + y) * W + x0) * C + q4;
 #pragma unroll
   for (int i = 0; i < XS; ++i)
-    if (x0 + i < W) *reinterpret_cast<float4 *>(out + (int64_t)i * C) = acc[i];
+    if (x0 + i < W) *reinterpret_cast<float4 *>(out + (int64_t)i * C) = acc[i];   // (streaming stores here: no change of the step)
 }
 
 // x-strip length of the pull kernel per channel count (measured at config 3: 0.55 / 0.38 / 0.57 ms; strips of 4 / 2 / 2:
