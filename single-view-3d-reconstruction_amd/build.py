@@ -26,7 +26,8 @@ SOURCES = {
     "gemm_bf16x6.hip": [],
     "gemm_f16x3.hip": [],
     "conv3d.hip": [],
-    "conv3d_bf16.hip": [f"-DSVR_CONV_EXP={os.environ['SVR_CONV_EXP']}"] if os.environ.get("SVR_CONV_EXP") else [],   # measurement builds
+    "conv3d_bf16.hip": ([f"-DSVR_CONV_EXP={os.environ['SVR_CONV_EXP']}"] if os.environ.get("SVR_CONV_EXP") else [])   # measurement builds
+                       + ["-D" + d for d in os.environ.get("SVR_CONV_DEFS", "").split()],
     "conv3d_bwdw_bf16.hip": [f"-DSVR_WG_EXP={os.environ['SVR_WG_EXP']}"] if os.environ.get("SVR_WG_EXP") else [],   # measurement builds
     "bn_pool.hip": [],
     "stage1.hip": [f"-DS1_EXP={os.environ['SVR_S1_EXP']}"] if os.environ.get("SVR_S1_EXP") else [],   # measurement builds
