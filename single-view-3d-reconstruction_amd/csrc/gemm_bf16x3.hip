@@ -590,8 +590,14 @@ __global__ __launch_bounds__(256, 2) void linear_tn_x3_tr_kernel(const float *__
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  // CONV: output-channel counts of 32 / 64 fill a quarter / half of the tile's 128 rows -- the waves (and the 32-row blocks) past the
+  // last valid row skip their fragment reads and matrix instructions (uniform per wave)
+  const int nrows_valid = CONV ? (int)min<int64_t>(N - i0, (int64_t)TN_TM) - wr * 64 : 64;
   auto mma = [&](int stage) {
     const uint32_t *la = lds + stage * 4 * TR_XPLANE, *lx = la + 2 * TR_XPLANE;
+    if constexpr (CONV) {
+      if (nrows_valid <= 0) return;
+    }
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       bf16x8 ah[2], am[2], bh[2], bm[2];
@@ -614,13 +620,17 @@ __global__ __launch_bounds__(256, 2) void linear_tn_x3_tr_kernel(const float *__
           fbhs[j] = scale_2m11(fbh[j]);
         }
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 2; ++i) {
+          if constexpr (CONV) {
+            if (i * 32 >= nrows_valid) continue;
+          }
 #pragma unroll
           for (int j = 0; j < 2; ++j) {
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fam[i], fbhs[j], acc[i][j], 0, 0, 0);   // lo'(dY) hi(x) 2^-11
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fahs[i], fbm[j], acc[i][j], 0, 0, 0);   // hi(dY) 2^-11 lo'(x)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[i], fbh[j], acc[i][j], 0, 0, 0);
           }
+        }
       } else {
 #pragma unroll
       for (int i = 0; i < 2; ++i)
