@@ -23,6 +23,7 @@ the kernel's MFMA fraction too (it is bound by the vector-L1 rate of the corner 
 backward scatter against the float-atomic roof and the point-MLP GEMMs against the f16 / bf16 MFMA peak.
 """
 import argparse
+import gc
 import json
 import os
 import subprocess
@@ -308,6 +309,12 @@ def main():
     mem0 = torch.cuda.memory_stats(dev)
     arena = trainer.ifnet.ifnet_feature_extractor._arena
     grown0 = arena.grown
+    # Python's cyclic collector: a gen-2 collection over the module / autograd object graph stalls the enqueueing thread for
+    # 40-200 ms (one 54.7 ms step in a 200-step run, profiles/r04_bench_200steps_gc_default.json; INTEGRATION.md section 6
+    # tells a training loop to do the same).  Everything alive now is moved to the permanent generation; the collector stays
+    # on for what the timed steps allocate.
+    gc.collect()
+    gc.freeze()
     sync()
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]
     host_ms, malloc_at = [], []
@@ -323,6 +330,7 @@ def main():
         malloc_at.append(torch.cuda.memory_stats(dev).get("num_device_alloc", 0))      # host-side counter, no device call
     sync()
     dt = time.perf_counter() - t0
+    gc.unfreeze()
     mem1 = torch.cuda.memory_stats(dev)
     malloc_sites = None
     if a.alloc_trace:
