@@ -571,6 +571,10 @@ int svr_conv2d_small_bwd_weight(const svr_conv2d_desc *d, const float *dY, int32
 int64_t svr_conv2d_planes_bytes(int32_t Cout, int32_t C, int32_t k);
 int svr_conv2d_prepare(const float *W, int32_t Cout, int32_t C, int32_t k, int32_t stride, int32_t want_bwd, uint32_t *amax,
                        void *planes, void *stream);
+/* All layers of a network at once (n <= 16; three launches instead of four per layer): arrays of n weights / shapes / plane
+ * buffers; amax_base: n words 256 bytes apart (layer i's word = amax_base + 64 i), zeroed here.  Same planes as n single calls. */
+int svr_conv2d_prepare_many(int32_t n, const float *const *W, const int32_t *Cout, const int32_t *C, const int32_t *k,
+                            const int32_t *stride, const int32_t *want_bwd, uint32_t *amax_base, void *const *planes, void *stream);
 int64_t svr_conv2d_workspace_bytes(const svr_conv2d_desc *d, int32_t Cout);
 int svr_conv2d_virtual(const svr_conv2d_desc *d, float *V, void *stream);
 int svr_conv2d_fwd(const svr_conv2d_desc *d, const void *planes, const uint32_t *amax_w, const float *bias, float *Y, int32_t Cout,

@@ -133,6 +133,7 @@ SIGNATURES = {
     "svr_conv2d_small_bwd_weight": (C.c_int, [C.POINTER(Conv2dDesc), P, I32, P, P, P, P]),
     "svr_conv2d_planes_bytes": (I64, [I32, I32, I32]),
     "svr_conv2d_prepare": (C.c_int, [P, I32, I32, I32, I32, I32, P, P, P]),
+    "svr_conv2d_prepare_many": (C.c_int, [I32, P, P, P, P, P, P, P, P, P]),
     "svr_conv2d_workspace_bytes": (I64, [C.POINTER(Conv2dDesc), I32]),
     "svr_conv2d_virtual": (C.c_int, [C.POINTER(Conv2dDesc), P, P]),
     "svr_conv2d_fwd": (C.c_int, [C.POINTER(Conv2dDesc), P, P, P, P, I32, P, P, P, P]),

@@ -17,6 +17,7 @@ import torch.nn.functional as F
 from .. import ops
 
 
+PREPARE_MANY = __import__("os").environ.get("SVR_UNET_PREP_MANY", "1") != "0"    # "0": every block prepares its own planes (A/B)
 SMALL_M = 1024      # output pixels (times batch) up to which a layer's forward product runs as a split-reduction GEMM
 
 
@@ -80,10 +81,14 @@ class _ConvBlockIgemmFn(torch.autograd.Function):
     the backward (1x the activation; the patch matrix was 9x and was built twice)."""
 
     @staticmethod
-    def forward(ctx, src0, src1, weight, bias, k, stride, act, up):
+    def forward(ctx, src0, src1, weight, bias, k, stride, act, up, *rest):
+        planes = rest[0] if rest else None           # optional ninth argument: planes prepared by the caller
+        ctx.nrest = len(rest)
         src0 = src0.contiguous()
         src1 = src1.contiguous() if src1 is not None else None
-        planes = ops.Conv2dPlanes(weight, stride, want_bwd=ctx.needs_input_grad[0] or ctx.needs_input_grad[1])
+        want_bwd = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
+        if planes is None or (want_bwd and not planes.has_bwd):      # (the network prepares all its layers at once: _UNetBase.forward)
+            planes = ops.Conv2dPlanes(weight, stride, want_bwd=want_bwd)
         if up:
             a0, a1, aact = ops.conv2d_virtual(src0, src1, act, True), None, ops.ACT_NONE
         else:
@@ -106,14 +111,18 @@ class _ConvBlockIgemmFn(torch.autograd.Function):
         if need0 or need1:
             dvirt = ops.conv2d_bwd_data(a0, a1, k, stride, ctx.planes, dy)
             d0, d1 = ops.conv2d_finish_bwd(src0, src1, act, up, dvirt, need0, need1)
-        return d0, d1, dw, db, None, None, None, None
+        return (d0, d1, dw, db, None, None, None, None) + (None,) * ctx.nrest
 
 
-def _conv_block(*args):
+def _igemm_on():
+    return ops.UNET_IGEMM and ops.BACKWARD_GEMM == "f16x3s"
+
+
+def _conv_block(*args, planes=None):
     """The block's autograd function: implicit GEMMs with the f32-level backward split (default), the explicit patch-matrix
     path for the other backward arithmetics (SVR_BACKWARD=bf16x3 / f32) and for SVR_UNET_IGEMM=0 (A/B)."""
-    if ops.UNET_IGEMM and ops.BACKWARD_GEMM == "f16x3s":
-        return _ConvBlockIgemmFn.apply(*args)
+    if _igemm_on():
+        return _ConvBlockIgemmFn.apply(*args, planes)
     return _ConvBlockFn.apply(*args)
 
 
@@ -168,10 +177,18 @@ class _UNetBase(nn.Module):
         if not input.is_cuda:
             raise RuntimeError("UNet HIP path needs GPU tensors (no CPU fallback; backend='stock' runs stock torch ops)")
         x = input.float().permute(0, 2, 3, 1).contiguous()                       # NCHW -> channels-last
+        planes = {}
+        if _igemm_on() and PREPARE_MANY:    # the weight planes of all layers in three launches (instead of four per layer)
+            grad = torch.is_grad_enabled()
+            names = [f"conv{i}" for i in range(1, len(self.ENC) + 1)] + [name for name, _, _, _ in self.DEC]
+            items = [(getattr(self, nm).weight, 2 if nm.startswith("conv") else 1,
+                      grad and (nm != "conv1" or input.requires_grad)) for nm in names]
+            planes = dict(zip(names, ops.conv2d_prepare_many(items)))
         skips = []
         for i in range(1, len(self.ENC) + 1):
             conv = getattr(self, f"conv{i}")
-            x = _conv_block(x, None, conv.weight, conv.bias, 4, 2, ops.ACT_LEAKY if i > 1 else ops.ACT_NONE, False)
+            x = _conv_block(x, None, conv.weight, conv.bias, 4, 2, ops.ACT_LEAKY if i > 1 else ops.ACT_NONE, False,
+                            planes=planes.get(f"conv{i}"))
             bn = self.ENC_BN[i - 1]
             if bn is not None:
                 m = getattr(self, bn)
@@ -180,7 +197,7 @@ class _UNetBase(nn.Module):
         d0, d1 = skips.pop(), None                                                # innermost code: no skip of itself
         for name, _, _, bn in self.DEC:
             conv = getattr(self, name)
-            d = _conv_block(d0, d1, conv.weight, conv.bias, 3, 1, ops.ACT_RELU, True)   # cat(d0, d1) never materialised
+            d = _conv_block(d0, d1, conv.weight, conv.bias, 3, 1, ops.ACT_RELU, True, planes=planes.get(name))   # cat(d0, d1) never materialised
             if bn is not None:
                 m = getattr(self, bn)
                 d0, d1 = _BN2dFn.apply(d, m.weight, m.bias, m), skips.pop()

@@ -1292,14 +1292,51 @@ class Conv2dPlanes:
             return
         nbytes = 256 + _lib.lib().svr_conv2d_planes_bytes(self.Cout, self.C, self.k)
         self.buf = torch.empty(nbytes, device=w.device, dtype=torch.uint8)
+        self._amax, self._planes = self.buf.data_ptr(), self.buf.data_ptr() + 256
         check(_lib.lib().svr_conv2d_prepare(_p(w), self.Cout, self.C, self.k, stride, int(self.has_bwd), self.amax_ptr(),
                                             self.planes_ptr(), _stream()), "conv2d_prepare")
 
     def amax_ptr(self):
-        return self.buf.data_ptr()
+        return self._amax
 
     def planes_ptr(self):
-        return self.buf.data_ptr() + 256
+        return self._planes
+
+
+def conv2d_prepare_many(items):
+    """[(weight, stride, want_bwd), ...] -> [Conv2dPlanes, ...]: the planes of all layers of a network in three launches per
+    16 layers (svr_conv2d_prepare_many) instead of four per layer; bit-identical to preparing them one by one."""
+    l = _lib.lib()
+    out, todo = [None] * len(items), []
+    for i, (weight, stride, want_bwd) in enumerate(items):
+        _f32(weight)
+        w = weight.detach().contiguous()
+        pl = Conv2dPlanes.__new__(Conv2dPlanes)
+        pl.Cout, pl.C, pl.k = int(w.shape[0]), int(w.shape[1]), int(w.shape[2])
+        pl.stride, pl.has_bwd = stride, bool(want_bwd)
+        pl.small = bool(l.svr_conv2d_small_supported(pl.Cout, pl.C, pl.k))
+        out[i] = pl
+        if pl.small:
+            pl.w, pl.has_bwd = w, True
+        else:
+            todo.append((pl, w))
+    for g0 in range(0, len(todo), 16):
+        grp = todo[g0:g0 + 16]
+        n = len(grp)
+        sizes = [(int(l.svr_conv2d_planes_bytes(pl.Cout, pl.C, pl.k)) + 255) // 256 * 256 for pl, _ in grp]
+        buf = torch.empty(256 * n + sum(sizes), device=grp[0][1].device, dtype=torch.uint8)
+        base, off = buf.data_ptr(), 256 * n
+        ptrs = []
+        for i, (pl, _) in enumerate(grp):
+            pl.buf, pl._amax, pl._planes = buf, base + 256 * i, base + off
+            ptrs.append(base + off)
+            off += sizes[i]
+        I32A, PA = C.c_int32 * n, C.c_void_p * n
+        check(l.svr_conv2d_prepare_many(n, PA(*[w.data_ptr() for _, w in grp]), I32A(*[pl.Cout for pl, _ in grp]),
+                                        I32A(*[pl.C for pl, _ in grp]), I32A(*[pl.k for pl, _ in grp]),
+                                        I32A(*[pl.stride for pl, _ in grp]), I32A(*[int(pl.has_bwd) for pl, _ in grp]),
+                                        C.c_void_p(base), PA(*ptrs), _stream()), "conv2d_prepare_many")
+    return out
 
 
 def _amax_any(t):

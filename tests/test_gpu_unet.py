@@ -60,6 +60,30 @@ def test_conv_block_forward_backward(B, H, W, C0, C1, Cout, k, stride, act, up, 
         assert G.rel_err(a.numpy(), r.numpy()) < (5e-6 if path == "igemm" else 5e-5), (a.shape,)
 
 
+def test_batched_weight_preparation_gives_the_same_planes():
+    """ops.conv2d_prepare_many (all layers of a network in three launches) leaves the same bits as preparing layer by layer:
+    amax words, forward planes, backward planes (4 parity classes at stride 2); 1-4-channel layers keep the f32 weight."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(5)
+    shapes = [(32, 3, 4, 2, False), (64, 32, 4, 2, True), (256, 512, 3, 1, True), (72, 20, 3, 1, True), (1, 64, 3, 1, True)] + \
+             [(32, 16, 3, 1, True)] * 14                     # 19 layers: two batches
+    ws = [(torch.randn(co, c, k, k, generator=g) * 10.0 ** (i % 5 - 2)).cuda() for i, (co, c, k, s, b) in enumerate(shapes)]
+    many = ops.conv2d_prepare_many([(w, s, b) for w, (co, c, k, s, b) in zip(ws, shapes)])
+    for w, (co, c, k, s, b), pl in zip(ws, shapes, many):
+        one = ops.Conv2dPlanes(w, s, want_bwd=b)
+        assert pl.small == one.small and pl.has_bwd == one.has_bwd
+        if one.small:
+            assert torch.equal(pl.w, one.w)
+            continue
+        nbytes = int(ops._lib.lib().svr_conv2d_planes_bytes(co, c, k))
+        fwd = 4 * co * k * k * ((c + 15) // 16 * 16)
+        used = fwd if not b else (fwd + 255) // 256 * 256 + 4 * c * k * k * ((co + 15) // 16 * 16)
+        assert used <= nbytes
+        a = pl.buf[pl._amax - pl.buf.data_ptr():][:4]
+        p = pl.buf[pl._planes - pl.buf.data_ptr():][:used]
+        assert torch.equal(a, one.buf[:4]) and torch.equal(p, one.buf[256:256 + used])
+
+
 @pytest.mark.parametrize("variant,B,H,W", [("full", 2, 256, 256), ("mini", 2, 48, 64)])
 def test_unet_matches_oracle(variant, B, H, W):
     import svr_amd  # noqa: F401
