@@ -187,6 +187,7 @@ FUSE_FC0 = os.environ.get("SVR_NO_FUSED_FC0") is None
 # ... and its bf16-storage variant for the query path's throughput mode (SVR_NO_FUSED_FC0_BF16=1: gather + fc_0 as two kernels)
 FUSE_FC0_BF16 = os.environ.get("SVR_NO_FUSED_FC0_BF16") is None
 # Fused + projected backward: the kept-column branch on the side stream beside the projected branch (SVR_NO_BWD_OVERLAP=1: serial)
+PREPARE_FORWARD_FIRST = os.environ.get("SVR_PREP_FWD_FIRST", "1") != "0"   # "0": one event behind all weight planes (A/B)
 OVERLAP_BACKWARD = os.environ.get("SVR_NO_BWD_OVERLAP") is None
 # First stage of the 128-architecture (conv_in -> ReLU -> BatchNorm -> pool) with conv_in's activation recomputed instead
 # of stored (stage1.hip): 3 of 5 forward and 5 of 7 backward passes over 1 GB tensors less.  SVR_NO_STAGE1=1: the separate
@@ -870,12 +871,17 @@ class IFNet(nn.Module):
         side.wait_stream(main)          # the optimizer step that produced these parameters
         with torch.cuda.stream(side):
             prep.begin()
-            for convs, _ in ext._stages:
-                for conv in convs:
-                    if conv.weight.shape[1] > 1:
-                        prep.add_conv(conv.weight.detach())
-            prep.add_linear(self.fc_1.weight.detach().squeeze(2))
-            prep.add_linear(self.fc_2.weight.detach().squeeze(2))
+            # forward planes first, with their own event: the forward pass waits for those only, the backward planes (as many
+            # launches again) are made while it runs
+            for which in (("fwd", "bwd") if PREPARE_FORWARD_FIRST else ("both",)):
+                for convs, _ in ext._stages:
+                    for conv in convs:
+                        if conv.weight.shape[1] > 1:
+                            prep.add_conv(conv.weight.detach(), which)
+                prep.add_linear(self.fc_1.weight.detach().squeeze(2), which)
+                prep.add_linear(self.fc_2.weight.detach().squeeze(2), which)
+                if which == "fwd":
+                    prep.mark(side)
             prep.finish(side)
         ops.set_prepared(prep)
 

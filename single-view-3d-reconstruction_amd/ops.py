@@ -550,9 +550,10 @@ class PreparedWeights:
 
     def __init__(self):
         self._ws = {}
-        self._valid = {}          # key -> the parameter's version counter when its planes were made
+        self._valid = {}          # key -> (the parameter's version counter when its planes were made, index of their event)
+        self._events = []
         self.ready = None
-        self._waited = True
+        self._waited = set()
 
     def _buf(self, key, nbytes, device):
         t = self._ws.get(key)
@@ -562,55 +563,67 @@ class PreparedWeights:
 
     def begin(self):
         self._valid.clear()
+        self._events = []
+        self._waited = set()      # (event index, stream): waits already enqueued
 
-    def add_conv(self, w):
-        """w (Co,Ci,3,3,3): forward (f16x3) and backward-data (bf16x3) planes, where those modes apply."""
+    def add_conv(self, w, which="both"):
+        """w (Co,Ci,3,3,3): forward (f16x3) and backward-data (bf16x3 / f16x3s) planes, where those modes apply.  which: "fwd",
+        "bwd" or "both" -- the caller prepares every layer's forward planes first and marks them (mark()), so that the forward
+        pass waits for those only."""
         _f32(w)
         Co, Ci = w.shape[0], w.shape[1]
         l = _lib.lib()
         z = C.c_void_p(0)
-        if FORWARD_CONV == "f16x3" and Ci % 16 == 0:
+        fwd, bwd = which in ("fwd", "both"), which in ("bwd", "both")
+        if fwd and FORWARD_CONV == "f16x3" and Ci % 16 == 0:
             ws = self._buf(("cf", w.data_ptr()), l.svr_conv3d_fwd_f16x3_workspace(Ci, Co), w.device)
             check(l.svr_conv3d_k3_fwd_f16x3(z, _p(w), z, z, 0, 0, 0, 0, Ci, Co, EPI_NONE, _p(ws), _stream()), "conv3d_fwd_f16x3 prepare")
-            self._valid[("cf", w.data_ptr())] = w._version
-        if BACKWARD_CONV == "bf16x3" and Ci % 2 == 0 and Co % 16 == 0:
+            self._valid[("cf", w.data_ptr())] = (w._version, len(self._events))
+        if bwd and BACKWARD_CONV == "bf16x3" and Ci % 2 == 0 and Co % 16 == 0:
             ws = self._buf(("cb", w.data_ptr()), l.svr_conv3d_bwd_data_bf16x3_workspace(Ci, Co), w.device)
             check(l.svr_conv3d_k3_bwd_data_bf16x3(z, _p(w), z, 0, 0, 0, 0, Ci, Co, EPI_NONE, z, _p(ws), _stream()),
                   "conv3d_bwd_data_bf16x3 prepare")
-            self._valid[("cb", w.data_ptr())] = w._version
-        if BACKWARD_CONV == "f16x3s" and Ci % 2 == 0 and Co % 16 == 0:
+            self._valid[("cb", w.data_ptr())] = (w._version, len(self._events))
+        if bwd and BACKWARD_CONV == "f16x3s" and Ci % 2 == 0 and Co % 16 == 0:
             ws = self._buf(("cbh", w.data_ptr()), l.svr_conv3d_bwd_data_f16x3_workspace(Ci, Co), w.device)
             check(l.svr_conv3d_k3_bwd_data_f16x3(z, _p(w), z, 0, 0, 0, 0, Ci, Co, EPI_NONE, z, z, z, _p(ws), _stream()),
                   "conv3d_bwd_data_f16x3 prepare")
-            self._valid[("cbh", w.data_ptr())] = w._version
+            self._valid[("cbh", w.data_ptr())] = (w._version, len(self._events))
 
-    def add_linear(self, w):
-        """w (N,K) row-major: forward (f16x3) and backward-data (bf16x3) planes, where those modes apply."""
+    def add_linear(self, w, which="both"):
+        """w (N,K) row-major: forward (f16x3) and backward-data (bf16x3 / f16x3s) planes, where those modes apply."""
         _f32(w)
         N, K = w.shape
         assert w.stride(1) == 1
         l = _lib.lib()
         z = C.c_void_p(0)
-        if FORWARD_GEMM == "f16x3" and K % 16 == 0:
+        fwd, bwd = which in ("fwd", "both"), which in ("bwd", "both")
+        if fwd and FORWARD_GEMM == "f16x3" and K % 16 == 0:
             ws = self._buf(("lf", w.data_ptr()), l.svr_linear_fwd_f16x3_workspace(N, K), w.device)
             check(l.svr_linear_fwd_f16x3(z, 0, C.c_void_p(w.data_ptr()), w.stride(0), z, z, 0, 0, N, K, EPI_NONE, _p(ws), _stream()),
                   "linear_fwd_f16x3 prepare")
-            self._valid[("lf", w.data_ptr())] = w._version
-        if BACKWARD_GEMM == "bf16x3" and N % 32 == 0 and K % 4 == 0:
+            self._valid[("lf", w.data_ptr())] = (w._version, len(self._events))
+        if bwd and BACKWARD_GEMM == "bf16x3" and N % 32 == 0 and K % 4 == 0:
             ws = self._buf(("lb", w.data_ptr()), l.svr_linear_bwd_data_bf16x3_workspace(N, K), w.device)
             check(l.svr_linear_bwd_data_bf16x3(z, 0, C.c_void_p(w.data_ptr()), w.stride(0), z, 0, 0, N, K, EPI_NONE, z, 0, _p(ws),
                                                _stream()), "linear_bwd_data_bf16x3 prepare")
-            self._valid[("lb", w.data_ptr())] = w._version
-        if BACKWARD_GEMM == "f16x3s" and N % 16 == 0:
+            self._valid[("lb", w.data_ptr())] = (w._version, len(self._events))
+        if bwd and BACKWARD_GEMM == "f16x3s" and N % 16 == 0:
             ws = self._buf(("lbh", w.data_ptr()), l.svr_linear_bwd_data_f16x3_workspace(N, K), w.device)
             check(l.svr_linear_bwd_data_f16x3(z, 0, C.c_void_p(w.data_ptr()), w.stride(0), z, 0, 0, N, K, EPI_NONE, z, 0, z, z,
                                               _p(ws), _stream()), "linear_bwd_data_f16x3 prepare")
-            self._valid[("lbh", w.data_ptr())] = w._version
+            self._valid[("lbh", w.data_ptr())] = (w._version, len(self._events))
+
+    def mark(self, stream):
+        """An event behind the planes added so far: a lookup waits for the event of ITS planes only (the forward pass does not
+        wait for the backward planes -- 54 launch-bound kernels per step, 0.5 ms of side-stream time)."""
+        ev = torch.cuda.Event()
+        ev.record(stream)
+        self._events.append(ev)
 
     def finish(self, stream):
-        self.ready = torch.cuda.Event()
-        self.ready.record(stream)
-        self._waited = False
+        self.mark(stream)
+        self.ready = self._events[-1]
 
     def invalidate(self):
         self._valid.clear()
@@ -619,11 +632,13 @@ class PreparedWeights:
         """The prepared workspace of `w` for `kind` ("cf" / "cb" / "lf" / "lb"), or None.  The first hit of a step makes
         the calling stream wait for the preparation (the step's later work on other streams is ordered behind it)."""
         key = (kind, w.data_ptr())
-        if self._valid.get(key, -1) != w._version:      # not prepared, or modified in place since (an optimizer step)
+        ver, idx = self._valid.get(key, (-1, 0))
+        if ver != w._version or idx >= len(self._events):      # not prepared, or modified in place since (an optimizer step)
             return None
-        if not self._waited:
-            torch.cuda.current_stream().wait_event(self.ready)
-            self._waited = True
+        cur = torch.cuda.current_stream()
+        if (idx, cur.cuda_stream) not in self._waited:     # once per event and stream
+            cur.wait_event(self._events[idx])
+            self._waited.add((idx, cur.cuda_stream))
         return self._ws[key]
 
 
