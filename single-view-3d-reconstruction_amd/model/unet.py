@@ -10,6 +10,8 @@ as four parity-class problems; the weight gradient through a gather loader in th
 plain-FMA kernels), BatchNorm in the 3-D encoder's kernels on (B,1,H,W,C) views; activations are channels-last inside.  The explicit
 patch-matrix path of rounds 2-3 (_ConvBlockFn) is kept for A/B (SVR_UNET_IGEMM=0) and for the bf16x3 / exact-f32 backward modes.
 backend="stock": the layers as stock PyTorch-ROCm ops (MIOpen), kept for A/B measurements (15-50 ms per config-5 step)."""
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -17,7 +19,7 @@ import torch.nn.functional as F
 from .. import ops
 
 
-PREPARE_MANY = __import__("os").environ.get("SVR_UNET_PREP_MANY", "1") != "0"    # "0": every block prepares its own planes (A/B)
+PREPARE_MANY = os.environ.get("SVR_UNET_PREP_MANY", "1") != "0"    # "0": every block prepares its own planes (A/B)
 SMALL_M = 1024      # output pixels (times batch) up to which a layer's forward product runs as a split-reduction GEMM
 
 
