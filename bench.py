@@ -298,6 +298,8 @@ def main():
     for _ in range(SETUP_STEPS):
         dp.step(batch)
     sync()
+    gc.collect()      # (see below: in FRONT of the warm-up steps, so that the GPU does not sit idle for the ~0.1 s of the collection
+    gc.freeze()       #  right before the timed region -- the first timed step then also pays for the clock ramp)
     for _ in range(a.warmup):
         dp.step(batch)
     # live HIP-event timing over the timed region, on the stream the work is enqueued on: the roofline kernel (the fused
@@ -311,10 +313,8 @@ def main():
     grown0 = arena.grown
     # Python's cyclic collector: a gen-2 collection over the module / autograd object graph stalls the enqueueing thread for
     # 40-200 ms (one 54.7 ms step in a 200-step run, profiles/r04_bench_200steps_gc_default.json; INTEGRATION.md section 6
-    # tells a training loop to do the same).  Everything alive now is moved to the permanent generation; the collector stays
-    # on for what the timed steps allocate.
-    gc.collect()
-    gc.freeze()
+    # tells a training loop to do the same).  Everything alive after the set-up steps was moved to the permanent generation
+    # (above, in front of the warm-up steps); the collector stays on for what the timed steps allocate.
     sync()
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]
     host_ms, malloc_at = [], []
